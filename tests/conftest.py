@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    here = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(here, "constants.json")) as f:
+        consts = json.load(f)
+    with open(os.path.join(here, "varuna_circuit0.json")) as f:
+        varuna = json.load(f)
+    with open(os.path.join(here, "srs_g1_1024.bin"), "rb") as f:
+        srs = f.read()
+    with open(os.path.join(here, "beta_h_g2.bin"), "rb") as f:
+        beta_h = f.read()
+    return {"constants": consts, "varuna": varuna, "srs_g1": srs, "beta_h_g2": beta_h}
