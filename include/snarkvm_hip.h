@@ -1,0 +1,129 @@
+/* snarkvm_hip.h - C ABI of the MI355X (gfx950) MSM / NTT backend for snarkVM.
+ *
+ * Part 1 is the drop-in boundary: the three symbols that `snarkvm-algorithms-cuda` binds
+ * (reference: algorithms/cuda/src/lib.rs:42-69, defined by algorithms/cuda/cuda/snarkvm_api.cu:52-84).
+ * A build of the reference with its `cuda` feature can link this library instead of the nvcc object
+ * without touching any Rust caller (INTEGRATION.md shows the binding).
+ *
+ * Part 2 is an extension ABI (not in the reference): device-resident operands, SRS registration,
+ * timing hooks.  Part 3 are test hooks.
+ *
+ * All functions are thread-safe (calls are serialised per device, like the reference's resource
+ * channel, snarkvm.cu:146-150) and never unwind.  No torch / C++ types cross this boundary.
+ */
+#ifndef SNARKVM_HIP_H
+#define SNARKVM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sppark `cuda::Error` as seen by Rust (algorithms/cuda/src/lib.rs:20 `sppark::cuda_error!()`):
+ * code == 0 means success; `message` is NULL or a malloc()ed C string that the caller frees
+ * (build.rs:79 -DTAKE_RESPONSIBILITY_FOR_ERROR_MESSAGE).  Any non-zero code makes the Rust caller
+ * fall back to its CPU path (msm/variable_base/mod.rs:39-43, fft/domain.rs:385-391). */
+typedef struct {
+    int32_t code;
+    char *message;
+} RustError;
+
+enum NTTInputOutputOrder { NN = 0, NR = 1, RN = 2, RR = 3 }; /* lib.rs:22-28 */
+enum NTTDirection { Forward = 0, Inverse = 1 };              /* lib.rs:30-34 */
+enum NTTType { Standard = 0, Coset = 1 };                    /* lib.rs:36-40 */
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 1 - the reference's FFI
+ * ------------------------------------------------------------------------------------------- */
+
+/* lib.rs:43-49 / snarkvm_api.cu:53-62.  In-place NTT of 2^lg_domain_size Fr elements (32 B each,
+ * Montgomery form, host memory).  NN/Forward/Standard == EvaluationDomain::fft_in_place;
+ * Inverse includes the 1/n scaling; Forward+Coset multiplies x[j] by 22^j first; Inverse+Coset
+ * multiplies the result by 22^-j (fft/domain.rs:201-206, 403-443).  Returns an error for
+ * lg_domain_size > 24 (the caller then uses its CPU path). */
+RustError snarkvm_ntt(void *inout, uint32_t lg_domain_size, enum NTTInputOutputOrder ntt_order,
+                      enum NTTDirection ntt_direction, enum NTTType ntt_type);
+
+/* lib.rs:51-60 / snarkvm_api.cu:64-75.  Product of `pcount` coefficient-form polynomials and
+ * `ecount` evaluation-form vectors over the 2^lg_domain_size domain (PolyMultiplier::multiply,
+ * fft/polynomial/multiplier.rs:70-134).  `polynomials` / `evaluations` are arrays of pointers to Fr
+ * vectors, `plens` / `elens` their lengths (size_t); every elens[i] must equal the domain size.
+ * `out` holds 2^lg_domain_size elements.  Corner cases follow snarkvm.cu:196-210. */
+RustError snarkvm_polymul(void *out, size_t pcount, const void *polynomials, const void *plens, size_t ecount,
+                          const void *evaluations, const void *elens, uint32_t lg_domain_size);
+
+/* lib.rs:62-68 / snarkvm_api.cu:77-83.  out (G1Projective: Jacobian X, Y, Z, 3 x 48 B Montgomery)
+ * = sum_i scalars[i] * points[i].  `points_with_infinity` is a Rust `[G1Affine]` (x, y, infinity flag;
+ * stride `ffi_affine_sz` = 104 bytes), `scalars` are npoints canonical 256-bit integers < r. */
+RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoints, const void *scalars,
+                      size_t ffi_affine_sz);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 2 - extension ABI (device-resident data, SRS registration, instrumentation)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Number of visible HIP devices (0 if none).  Never fails. */
+int snarkvm_hip_device_count(void);
+/* Select the HIP device used by this process' context (default: device 0 / LOCAL_RANK mapping is the
+ * caller's business).  Must be called before the first compute call. */
+RustError snarkvm_hip_set_device(int device);
+
+/* Same as snarkvm_ntt but `d_inout` is device memory on the context's device. */
+RustError snarkvm_hip_ntt_device(void *d_inout, uint32_t lg_domain_size, int ntt_order, int ntt_direction,
+                                 int ntt_type);
+
+/* Register a base vector once (SRS powers are static per proving key; the reference re-uploads
+ * 104 B/point on every call, snarkvm.cu:262-275).  `points` is a Rust `[G1Affine]` with the given
+ * stride, in host (on_device = 0) or device (on_device = 1) memory.  Returns an opaque handle. */
+typedef struct snarkvm_hip_bases snarkvm_hip_bases_t;
+RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t **handle, const void *points, size_t npoints,
+                                     size_t ffi_affine_sz, int on_device);
+void snarkvm_hip_free_bases(snarkvm_hip_bases_t *handle);
+
+/* MSM over registered bases [offset, offset + npoints).  `scalars` in host (scalars_on_device = 0) or
+ * device memory.  `out` is a 144-byte host buffer (Jacobian, as snarkvm_msm).  `window_bits` = 0 picks
+ * the window size automatically. */
+RustError snarkvm_hip_msm_registered(void *out, const snarkvm_hip_bases_t *handle, size_t offset, size_t npoints,
+                                     const void *scalars, int scalars_on_device, int window_bits);
+
+/* Fr vector helpers on device memory: out[i] = a[i] * b[i] (polynomial_inner_multiply,
+ * polynomial.cuh:36-45); Fr::to_bigint / from_bigint over a vector (kzg10/mod.rs:469-474). */
+RustError snarkvm_hip_fr_mul_device(void *d_out, const void *d_a, const void *d_b, size_t n);
+RustError snarkvm_hip_fr_convert_device(void *d_out, const void *d_in, size_t n, int to_bigint);
+
+/* Synthetic base set for benchmarks: out[i] = (start + i) * G as Rust G1Affine (104 B stride) in
+ * device memory. */
+RustError snarkvm_hip_g1_generate_bases_device(void *d_out, uint64_t start, size_t npoints);
+
+/* Per-phase timing of the most recent MSM / NTT call, measured with HIP events on the stream the
+ * kernels were launched on.  Enable first; then read `count` (name, milliseconds) pairs. */
+void snarkvm_hip_set_profiling(int enabled);
+int snarkvm_hip_get_phase_count(void);
+const char *snarkvm_hip_get_phase_name(int i);
+double snarkvm_hip_get_phase_ms(int i);
+
+/* Block until all queued work of the context has finished. */
+RustError snarkvm_hip_synchronize(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 3 - test hooks
+ * ------------------------------------------------------------------------------------------- */
+
+/* The device arithmetic (ff.cuh / ec.cuh) compiled for the host and run on the CPU, so that the
+ * limb arithmetic can be checked without a GPU.  field: 0 = Fr, 1 = Fq.  op: 0 add, 1 sub, 2 mul,
+ * 3 sqr, 4 inverse, 5 neg, 6 from_bigint, 7 to_bigint.  Operands / results are in the reference's
+ * memory form (Montgomery R = 2^256 / 2^384), n elements of 32 / 48 bytes. */
+int snarkvm_hip_selftest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
+/* op: 0 = out(Jacobian 144 B) = sum_i (xyzz) points[i] * small_scalars[i] via mixed adds and doublings;
+ * exercises every exceptional branch of ec.cuh on the host. */
+int snarkvm_hip_selftest_g1_msm_naive(const void *points_with_infinity, size_t npoints, size_t ffi_affine_sz,
+                                      const void *scalars, void *out);
+/* Same field operations executed by a GPU kernel (one thread per element). */
+RustError snarkvm_hip_devtest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNARKVM_HIP_H */

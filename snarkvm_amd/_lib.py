@@ -1,0 +1,78 @@
+"""ctypes loader of snarkvm_amd/lib/libsnarkvm_hip.so (the C ABI of include/snarkvm_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or a call fails, an exception is
+raised (the reference's *caller* owns the CPU fallback, msm/variable_base/mod.rs:39-43).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsnarkvm_hip.so")
+
+# every symbol include/snarkvm_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm",
+    "snarkvm_hip_device_count", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
+    "snarkvm_hip_register_bases", "snarkvm_hip_free_bases", "snarkvm_hip_msm_registered",
+    "snarkvm_hip_fr_mul_device", "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device",
+    "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
+    "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_devtest_field",
+]
+
+
+class RustError(ctypes.Structure):
+    """sppark `cuda::Error` (algorithms/cuda/src/lib.rs:20): code 0 == success."""
+    _fields_ = [("code", ctypes.c_int32), ("message", ctypes.c_void_p)]
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"snarkvm_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+_lib = None
+_libc = None
+
+
+def lib():
+    global _lib, _libc
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing - build it with `python -m snarkvm_amd.build` (hipcc, gfx950). "
+                "snarkvm_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
+                   "snarkvm_hip_register_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_fr_mul_device",
+                   "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device", "snarkvm_hip_synchronize",
+                   "snarkvm_hip_devtest_field"]
+        for name in err_fns:
+            getattr(L, name).restype = RustError
+        L.snarkvm_hip_device_count.restype = ctypes.c_int
+        L.snarkvm_hip_get_phase_count.restype = ctypes.c_int
+        L.snarkvm_hip_get_phase_name.restype = ctypes.c_char_p
+        L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double
+        L.snarkvm_hip_selftest_field.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_g1_msm_naive.restype = ctypes.c_int
+        L.snarkvm_hip_free_bases.restype = None
+        L.snarkvm_hip_set_profiling.restype = None
+        _libc = ctypes.CDLL(None)
+        _libc.free.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(err):
+    """Raise HipError for a non-zero RustError (and free its message, as Rust's Drop would)."""
+    if err.code != 0:
+        msg = ctypes.string_at(err.message).decode(errors="replace") if err.message else ""
+        if err.message:
+            _libc.free(err.message)
+        raise HipError(err.code, msg)
+
+
+def device_count():
+    return lib().snarkvm_hip_device_count()

@@ -1,0 +1,654 @@
+// api.hip - C ABI (include/snarkvm_hip.h) and host runtime of the gfx950 MSM / NTT backend.
+//
+// Host runtime = what algorithms/cuda/cuda/snarkvm.cu:73-312 (snarkvm_t) and snarkvm_api.cu:23-84 are in the
+// reference: a lazily constructed per-process context (device arenas, stream, twiddle tables), staging of the
+// caller's host buffers, error reporting as RustError, serialisation of concurrent callers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/snarkvm_hip.h"
+#include "ec.cuh"
+#include "ff.cuh"
+#include "msm.cuh"
+#include "ntt.cuh"
+
+using namespace sv;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static RustError ok() { return RustError{0, nullptr}; }
+static RustError fail(int code, const std::string& msg) {
+    char* m = (char*)malloc(msg.size() + 1);
+    if (m) memcpy(m, msg.c_str(), msg.size() + 1);
+    return RustError{code ? code : 1, m};
+}
+struct hip_failure {
+    hipError_t e;
+    const char* what;
+    int line;
+};
+#define HIP_TRY(x)                                             \
+    do {                                                       \
+        hipError_t _e = (x);                                   \
+        if (_e != hipSuccess) throw hip_failure{_e, #x, __LINE__}; \
+    } while (0)
+static RustError from_failure(const hip_failure& f) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "snarkvm_hip: %s failed at api.hip:%d: %s", f.what, f.line, hipGetErrorString(f.e));
+    return fail((int)f.e, buf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct dev_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T>
+    T* as() const {
+        return (T*)p;
+    }
+};
+
+struct phase_rec {
+    const char* name;
+    hipEvent_t e0, e1;
+    double ms;
+};
+
+struct context_t {
+    std::mutex mu;
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ntt_tables_t tb{};
+    dev_buf tables_mem;
+    // NTT staging
+    dev_buf ntt_data, ntt_scratch, ntt_acc;
+    // MSM workspace
+    dev_buf bases_tmp, scalars_tmp, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b,
+        part_a, part_b, contrib, wsum, result, gen_pts, gen_prod;
+    // profiling
+    bool profiling = false;
+    std::vector<phase_rec> phases;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+
+    void init() {
+        if (ready) return;
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) throw hip_failure{e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount (no MI355X visible)", __LINE__};
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // tables: 4 x (lo + hi) x 4096 + 2 x 128 + 25 + 4, 32 B each
+        const size_t entries = 8 * NTT_TW_SIZE + 256 + 32 + 8;
+        tables_mem.ensure(entries * sizeof(fr_mem_t));
+        fr_mem_t* base = tables_mem.as<fr_mem_t>();
+        size_t off = 0;
+        auto take = [&](size_t n) {
+            fr_mem_t* r = base + off;
+            off += n;
+            return r;
+        };
+        for (int d = 0; d < 2; d++) {
+            tb.pow_lo[d] = take(NTT_TW_SIZE);
+            tb.pow_hi[d] = take(NTT_TW_SIZE);
+            tb.g_lo[d] = take(NTT_TW_SIZE);
+            tb.g_hi[d] = take(NTT_TW_SIZE);
+            tb.local[d] = take(128);
+        }
+        tb.size_inv = take(32);
+        tb.consts = take(8);
+        HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+        hipLaunchKernelGGL(ntt_setup_consts, dim3(1), dim3(64), 0, stream, tb);
+        hipLaunchKernelGGL(ntt_fill_tables, dim3(NTT_TW_SIZE / 256), dim3(256), 0, stream, tb);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        ready = true;
+    }
+    // ---- profiling helpers
+    hipEvent_t new_event() {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+    void begin_call() {
+        phases.clear();
+        events_used = 0;
+    }
+    void phase_begin(const char* name) {
+        if (!profiling) return;
+        phase_rec r{name, new_event(), new_event(), 0.0};
+        HIP_TRY(hipEventRecord(r.e0, stream));
+        phases.push_back(r);
+    }
+    void phase_end() {
+        if (!profiling) return;
+        HIP_TRY(hipEventRecord(phases.back().e1, stream));
+    }
+    void end_call() {
+        if (!profiling) return;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& r : phases) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+            r.ms = ms;
+        }
+    }
+};
+static context_t g_ctx;
+
+struct snarkvm_hip_bases {
+    g1_aff_mem_t* d = nullptr;
+    size_t n = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// MSM driver
+// ------------------------------------------------------------------------------------------------
+static void write_infinity(void* out) {
+    // Projective::zero() = (0, 1, 0) in Montgomery form (projective.rs:49-54)
+    static const uint64_t FQ_R[6] = {202099033278250856ull,  5854854902718660529ull, 11492539364873682930ull,
+                                     8885205928937022213ull, 5545221690922665192ull, 39800542322357402ull};  // fq.rs:134-141
+    uint64_t* o = (uint64_t*)out;
+    memset(o, 0, 144);
+    memcpy(o + 6, FQ_R, 48);
+}
+
+// d_bases: converted device bases; d_scalars: device scalars (32 B each); result written to host `out` (144 B)
+static void msm_run(context_t& c, const g1_aff_mem_t* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits) {
+    if (n == 0) {
+        write_infinity(out);
+        return;
+    }
+    if (n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: npoints must be < 2^31", __LINE__};
+    const msm_plan_t pl = msm_make_plan(n, window_bits);
+    if ((size_t)pl.W * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: W * npoints must be < 2^32", __LINE__};
+    hipStream_t st = c.stream;
+    const size_t E_max = (size_t)pl.W * n;
+    const uint32_t nbt = pl.nbt;
+
+    c.digits.ensure(E_max * sizeof(uint16_t));
+    const size_t ncounts = (size_t)nbt * pl.nchunks;
+    c.counts.ensure(ncounts * 4);
+    c.offsets.ensure(ncounts * 4);
+    c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
+    c.sorted.ensure(E_max * 4);
+    c.boff.ensure(((size_t)nbt + 1) * 4);
+    c.cnt_a.ensure(((size_t)nbt + 1) * 4);
+    c.cnt_b.ensure(((size_t)nbt + 1) * 4);
+    c.start_a.ensure(((size_t)nbt + 1) * 4);
+    c.start_b.ensure(((size_t)nbt + 1) * 4);
+    // thread-count bounds per level: T_(r+1) <= T_r / S2 + nbt + 1 (fixed point ~ nbt * 64/63), plus slack
+    const size_t slack = (size_t)nbt / 32 + 64;
+    const size_t T0_max = E_max / pl.S + nbt + 1 + slack;
+    const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
+    c.part_a.ensure(T0_max * sizeof(g1_xyzz_mem_t));
+    c.part_b.ensure(T1_max * sizeof(g1_xyzz_mem_t));
+    const uint32_t J = pl.nb / pl.L;
+    c.contrib.ensure((size_t)pl.W * J * sizeof(g1_xyzz_mem_t));
+    c.wsum.ensure((size_t)pl.W * sizeof(g1_xyzz_mem_t));
+    c.result.ensure(sizeof(g1_jac_out_t));
+
+    // 1. digits
+    c.phase_begin("msm_digits");
+    {
+        msm_digit_params_t dp;
+        memcpy(dp.bias, pl.bias, sizeof dp.bias);
+        dp.c = pl.c;
+        dp.W = pl.W;
+        dp.n = n;
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
+    }
+    c.phase_end();
+    // 2.-4. counting sort by (window, bucket)
+    msm_sort_params_t sp;
+    sp.n = n;
+    sp.chunk = pl.chunk;
+    sp.nchunks = pl.nchunks;
+    sp.nb = pl.nb;
+    sp.c = pl.c;
+    const size_t lds = (size_t)pl.nb * 4;
+    c.phase_begin("msm_histogram");
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), c.counts.as<uint32_t>(), sp);
+    c.phase_end();
+    c.phase_begin("msm_scan");
+    exclusive_scan_u32(st, c.counts.as<uint32_t>(), c.offsets.as<uint32_t>(), ncounts, c.scan_tmp.as<uint32_t>());
+    hipLaunchKernelGGL(msm_bucket_offsets_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.offsets.as<uint32_t>(),
+                       c.counts.as<uint32_t>(), c.boff.as<uint32_t>(), nbt, pl.nchunks);
+    c.phase_end();
+    c.phase_begin("msm_scatter");
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), c.offsets.as<uint32_t>(),
+                       c.sorted.as<uint32_t>(), sp);
+    c.phase_end();
+    // 5. accumulate
+    c.phase_begin("msm_accumulate");
+    hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.boff.as<uint32_t>(), (const uint32_t*)nullptr,
+                       c.cnt_a.as<uint32_t>(), nbt, pl.S);
+    exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases, c.sorted.as<uint32_t>(),
+                       c.boff.as<uint32_t>(), c.start_a.as<uint32_t>(), c.part_a.as<g1_xyzz_mem_t>(), nbt, pl.S);
+    c.phase_end();
+    // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
+    c.phase_begin("msm_reduce_partials");
+    uint32_t *cnt_in = c.cnt_a.as<uint32_t>(), *cnt_out = c.cnt_b.as<uint32_t>();
+    uint32_t *start_in = c.start_a.as<uint32_t>(), *start_out = c.start_b.as<uint32_t>();
+    g1_xyzz_mem_t *pin = c.part_a.as<g1_xyzz_mem_t>(), *pout = c.part_b.as<g1_xyzz_mem_t>();
+    size_t T_in_max = T0_max;
+    for (int r = 0; r < pl.rounds; r++) {
+        size_t T_out_max = T_in_max / pl.S2 + nbt + 1;
+        if (T_out_max > T1_max) T_out_max = T1_max;  // both ping-pong buffers hold >= T1_max partials
+        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)nullptr, cnt_in, cnt_out, nbt, pl.S2);
+        exclusive_scan_u32(st, cnt_out, start_out, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3((unsigned)((T_out_max + 255) / 256)), dim3(256), 0, st, pin, start_in, cnt_in, start_out, pout,
+                           nbt, pl.S2);
+        std::swap(cnt_in, cnt_out);
+        std::swap(start_in, start_out);
+        std::swap(pin, pout);
+        T_in_max = T_out_max;
+    }
+    c.phase_end();
+    // 7.-9. bucket reduction, window sums, Horner
+    c.phase_begin("msm_bucket_reduce");
+    const uint32_t total_threads = (uint32_t)pl.W * J;
+    hipLaunchKernelGGL(msm_bucket_reduce_kernel, dim3((total_threads + 255) / 256), dim3(256), 0, st, pin, start_in, cnt_in,
+                       c.contrib.as<g1_xyzz_mem_t>(), pl.nb, pl.L, total_threads);
+    hipLaunchKernelGGL(msm_window_sum_kernel, dim3(pl.W), dim3(256), 0, st, c.contrib.as<g1_xyzz_mem_t>(), c.wsum.as<g1_xyzz_mem_t>(), J);
+    c.phase_end();
+    c.phase_begin("msm_final_horner");
+    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, c.wsum.as<g1_xyzz_mem_t>(), c.result.as<g1_jac_out_t>(), pl.W, pl.c);
+    c.phase_end();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(g1_jac_out_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+}
+
+static void convert_bases(context_t& c, const uint8_t* d_in, size_t stride, size_t n, g1_aff_mem_t* d_out) {
+    if (!n) return;
+    hipLaunchKernelGGL(g1_convert_bases_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_in, stride, n, d_out);
+    HIP_TRY(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// exported functions
+// ------------------------------------------------------------------------------------------------
+#define API_BEGIN                                  \
+    std::lock_guard<std::mutex> _lk(g_ctx.mu);     \
+    try {                                          \
+        g_ctx.init();                              \
+        g_ctx.begin_call();
+#define API_END                                    \
+    g_ctx.end_call();                              \
+    return ok();                                   \
+    }                                              \
+    catch (const hip_failure& f) {                 \
+        return from_failure(f);                    \
+    }                                              \
+    catch (const std::exception& e) {              \
+        return fail(1, std::string("snarkvm_hip: ") + e.what()); \
+    }                                              \
+    catch (...) {                                  \
+        return fail(1, "snarkvm_hip: unknown error"); \
+    }
+
+// ---- test-hook helpers (C++ linkage)
+template <class F>
+SV_HD void field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    // operands are memory-form Montgomery residues: convert to internal, operate, convert back
+    F x = F::unpack(a).from_mem_mont();
+    F y = F::unpack(b).from_mem_mont();
+    F r;
+    switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x.sqr(); break;
+        case 4: r = x.inverse(); break;
+        case 5: r = x.neg(); break;
+        case 6: r = F::unpack(a).int_to_mont(); break;                  // from_bigint: integer -> Montgomery
+        case 7: (x.mont_to_int()).pack(out); return;                    // to_bigint: Montgomery -> integer
+        default: r = F::zero();
+    }
+    r.to_mem_mont().pack(out);
+}
+__global__ void devtest_field_kernel(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (field == 0)
+        field_op<fr_t>(op, a + 8 * i, b + 8 * i, out + 8 * i);
+    else
+        field_op<fq_t>(op, a + 12 * i, b + 12 * i, out + 12 * i);
+}
+
+extern "C" {
+
+int snarkvm_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+RustError snarkvm_hip_set_device(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (g_ctx.ready && g_ctx.device != device) return fail(1, "snarkvm_hip_set_device: context already initialised on another device");
+    g_ctx.device = device;
+    return ok();
+}
+void snarkvm_hip_set_profiling(int enabled) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_ctx.profiling = enabled != 0;
+}
+int snarkvm_hip_get_phase_count(void) { return (int)g_ctx.phases.size(); }
+const char* snarkvm_hip_get_phase_name(int i) { return (i >= 0 && i < (int)g_ctx.phases.size()) ? g_ctx.phases[i].name : ""; }
+double snarkvm_hip_get_phase_ms(int i) { return (i >= 0 && i < (int)g_ctx.phases.size()) ? g_ctx.phases[i].ms : 0.0; }
+
+RustError snarkvm_hip_synchronize(void) {
+    API_BEGIN
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    API_END
+}
+
+// ---- NTT -------------------------------------------------------------------------------------
+static void check_ntt_args(uint32_t lg, int order, int dir, int type) {
+    if (lg > (uint32_t)NTT_LG_MAX) throw hip_failure{hipErrorMemoryAllocation, "ntt: lg_domain_size > 24 is not supported by this backend", __LINE__};
+    if (order < 0 || order > 3 || dir < 0 || dir > 1 || type < 0 || type > 1) throw hip_failure{hipErrorInvalidValue, "ntt: bad enum value", __LINE__};
+}
+RustError snarkvm_ntt(void* inout, uint32_t lg, enum NTTInputOutputOrder order, enum NTTDirection dir, enum NTTType type) {
+    API_BEGIN
+    check_ntt_args(lg, (int)order, (int)dir, (int)type);
+    const size_t bytes = sizeof(fr_mem_t) << lg;
+    g_ctx.ntt_data.ensure(bytes);
+    g_ctx.ntt_scratch.ensure(bytes);
+    g_ctx.phase_begin("ntt_h2d");
+    HIP_TRY(hipMemcpyAsync(g_ctx.ntt_data.p, inout, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    g_ctx.phase_end();
+    g_ctx.phase_begin("ntt_kernels");
+    ntt_run(g_ctx.stream, g_ctx.tb, g_ctx.ntt_data.as<fr_mem_t>(), g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, (int)order, (int)dir, (int)type);
+    g_ctx.phase_end();
+    HIP_TRY(hipGetLastError());
+    g_ctx.phase_begin("ntt_d2h");
+    HIP_TRY(hipMemcpyAsync(inout, g_ctx.ntt_data.p, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+    g_ctx.phase_end();
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    API_END
+}
+RustError snarkvm_hip_ntt_device(void* d_inout, uint32_t lg, int order, int dir, int type) {
+    API_BEGIN
+    check_ntt_args(lg, order, dir, type);
+    g_ctx.ntt_scratch.ensure(sizeof(fr_mem_t) << lg);
+    g_ctx.phase_begin("ntt_kernels");
+    ntt_run(g_ctx.stream, g_ctx.tb, (fr_mem_t*)d_inout, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, order, dir, type);
+    g_ctx.phase_end();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    API_END
+}
+
+// ---- polymul -----------------------------------------------------------------------------------
+RustError snarkvm_polymul(void* out, size_t pcount, const void* polynomials, const void* plens, size_t ecount, const void* evaluations,
+                          const void* elens, uint32_t lg) {
+    // corner cases of snarkvm.cu:196-210 first (no device needed for the copy)
+    const fr_mem_t* const* polys = (const fr_mem_t* const*)polynomials;
+    const fr_mem_t* const* evals = (const fr_mem_t* const*)evaluations;
+    const size_t* pl = (const size_t*)plens;
+    const size_t* el = (const size_t*)elens;
+    if (pcount + ecount == 0) return ok();
+    if (pcount + ecount == 1 && pcount == 1) {
+        memcpy(out, polys[0], sizeof(fr_mem_t) * pl[0]);
+        return ok();
+    }
+    API_BEGIN
+    check_ntt_args(lg, 0, 0, 0);
+    const size_t n = (size_t)1 << lg;
+    const size_t bytes = sizeof(fr_mem_t) * n;
+    for (size_t k = 0; k < pcount; k++)
+        if (pl[k] > n) throw hip_failure{hipErrorInvalidValue, "polymul: polynomial longer than the domain", __LINE__};
+    for (size_t k = 0; k < ecount; k++)
+        if (el[k] != n) throw hip_failure{hipErrorInvalidValue, "polymul: evaluation vector length != domain size", __LINE__};
+    g_ctx.ntt_data.ensure(bytes);
+    g_ctx.ntt_scratch.ensure(bytes);
+    g_ctx.ntt_acc.ensure(bytes);
+    hipStream_t st = g_ctx.stream;
+    fr_mem_t* data = g_ctx.ntt_data.as<fr_mem_t>();
+    fr_mem_t* acc = g_ctx.ntt_acc.as<fr_mem_t>();
+    if (pcount + ecount == 1) {  // a single evaluation vector: zero-pad + inverse NTT (snarkvm.cu:203-208)
+        HIP_TRY(hipMemsetAsync(data, 0, bytes, st));
+        HIP_TRY(hipMemcpyAsync(data, evals[0], sizeof(fr_mem_t) * el[0], hipMemcpyHostToDevice, st));
+        ntt_run(st, g_ctx.tb, data, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, NTT_NN, NTT_INVERSE, NTT_STANDARD);
+        HIP_TRY(hipMemcpyAsync(out, data, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        for (size_t k = 0; k < pcount + ecount; k++) {
+            fr_mem_t* dst = (k == 0) ? acc : data;
+            if (k < pcount) {
+                HIP_TRY(hipMemcpyAsync(dst, polys[k], sizeof(fr_mem_t) * pl[k], hipMemcpyHostToDevice, st));
+                if (pl[k] < n) HIP_TRY(hipMemsetAsync(dst + pl[k], 0, sizeof(fr_mem_t) * (n - pl[k]), st));
+                ntt_run(st, g_ctx.tb, dst, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, NTT_NN, NTT_FORWARD, NTT_STANDARD);
+            } else {
+                HIP_TRY(hipMemcpyAsync(dst, evals[k - pcount], bytes, hipMemcpyHostToDevice, st));
+            }
+            if (k > 0) hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, st, acc, acc, data, n, 1);
+        }
+        ntt_run(st, g_ctx.tb, acc, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, NTT_NN, NTT_INVERSE, NTT_STANDARD);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, acc, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    API_END
+}
+
+// ---- MSM ---------------------------------------------------------------------------------------
+RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
+    API_BEGIN
+    if (npoints == 0) {
+        write_infinity(out);
+    } else {
+        if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "msm: ffi_affine_sz must be >= 104 and 8-byte aligned", __LINE__};
+        const size_t aff_bytes = (npoints * sizeof(g1_aff_mem_t) + 255) & ~(size_t)255;
+        g_ctx.bases_tmp.ensure(aff_bytes + npoints * ffi_affine_sz);
+        g_ctx.scalars_tmp.ensure(npoints * 32);
+        uint8_t* raw = g_ctx.bases_tmp.as<uint8_t>() + aff_bytes;
+        g_ctx.phase_begin("msm_h2d");
+        HIP_TRY(hipMemcpyAsync(raw, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
+        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, g_ctx.stream));
+        g_ctx.phase_end();
+        g_ctx.phase_begin("msm_convert_bases");
+        convert_bases(g_ctx, raw, ffi_affine_sz, npoints, g_ctx.bases_tmp.as<g1_aff_mem_t>());
+        g_ctx.phase_end();
+        msm_run(g_ctx, g_ctx.bases_tmp.as<g1_aff_mem_t>(), g_ctx.scalars_tmp.as<uint4>(), npoints, out, 0);
+    }
+    API_END
+}
+
+RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
+    API_BEGIN
+    if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
+    if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
+    snarkvm_hip_bases* h = new snarkvm_hip_bases();
+    h->n = npoints;
+    if (npoints) {
+        HIP_TRY(hipMalloc((void**)&h->d, npoints * sizeof(g1_aff_mem_t)));
+        const uint8_t* src = (const uint8_t*)points;
+        if (!on_device) {
+            g_ctx.bases_tmp.ensure(npoints * ffi_affine_sz);
+            HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
+            src = g_ctx.bases_tmp.as<uint8_t>();
+        }
+        convert_bases(g_ctx, src, ffi_affine_sz, npoints, h->d);
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    *handle = h;
+    API_END
+}
+void snarkvm_hip_free_bases(snarkvm_hip_bases_t* h) {
+    if (!h) return;
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (h->d) (void)hipFree(h->d);
+    delete h;
+}
+RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, size_t offset, size_t npoints, const void* scalars,
+                                     int scalars_on_device, int window_bits) {
+    API_BEGIN
+    if (!h || offset + npoints > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered: range exceeds the registered bases", __LINE__};
+    if (window_bits && (window_bits < 2 || window_bits > 16)) throw hip_failure{hipErrorInvalidValue, "msm_registered: window_bits must be 0 or 2..16", __LINE__};
+    const uint4* d_sc = (const uint4*)scalars;
+    if (!scalars_on_device && npoints) {
+        g_ctx.scalars_tmp.ensure(npoints * 32);
+        g_ctx.phase_begin("msm_h2d");
+        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, g_ctx.stream));
+        g_ctx.phase_end();
+        d_sc = g_ctx.scalars_tmp.as<uint4>();
+    }
+    msm_run(g_ctx, h->d + offset, d_sc, npoints, out, window_bits);
+    API_END
+}
+
+// ---- Fr vector helpers ---------------------------------------------------------------------------
+RustError snarkvm_hip_fr_mul_device(void* d_out, const void* d_a, const void* d_b, size_t n) {
+    API_BEGIN
+    if (n) {
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, g_ctx.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_a, (const fr_mem_t*)d_b, n, 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+RustError snarkvm_hip_fr_convert_device(void* d_out, const void* d_in, size_t n, int to_bigint) {
+    API_BEGIN
+    if (n) {
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(blocks), dim3(256), 0, g_ctx.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_in, n, to_bigint);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+// ---- synthetic bases ---------------------------------------------------------------------------
+// G1 generator (g1.rs:219-253), memory Montgomery form, 64-bit limbs
+static const uint64_t G1_GEN_X[6] = {1171681672315280277ull, 6528257384425852712ull,  7514971432460253787ull,
+                                     2032708395764262463ull, 12876543207309632302ull, 107509843840671767ull};
+static const uint64_t G1_GEN_Y[6] = {13572190014569192121ull, 15344828677741220784ull, 17067903700058808083ull,
+                                     10342263224753415805ull, 1083990386877464092ull,  21335464879237822ull};
+RustError snarkvm_hip_g1_generate_bases_device(void* d_out, uint64_t start, size_t npoints) {
+    API_BEGIN
+    if (npoints) {
+        // convert the generator on the host with the same arithmetic
+        uint32_t xw[12], yw[12];
+        memcpy(xw, G1_GEN_X, 48);
+        memcpy(yw, G1_GEN_Y, 48);
+        g1_aff_t g{fq_t::unpack(xw).from_mem_mont(), fq_t::unpack(yw).from_mem_mont()};
+        g1_aff_mem_t gm;
+        g.x.pack(gm.x.w);
+        g.y.pack(gm.y.w);
+        g_ctx.gen_pts.ensure(npoints * sizeof(g1_xyzz_mem_t));
+        g_ctx.gen_prod.ensure(npoints * sizeof(fq_mem_t));
+        const size_t threads = (npoints + GEN_RUN - 1) / GEN_RUN;
+        hipLaunchKernelGGL(g1_generate_bases_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g_ctx.stream, gm, start, npoints,
+                           (uint8_t*)d_out, (size_t)104, g_ctx.gen_pts.as<g1_xyzz_mem_t>(), g_ctx.gen_prod.as<fq_mem_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+// ---- test hooks ----------------------------------------------------------------------------------
+int snarkvm_hip_selftest_field(int field, int op, const void* a, const void* b, void* out, size_t n) {
+    const uint32_t* A = (const uint32_t*)a;
+    const uint32_t* B = (const uint32_t*)(b ? b : a);
+    uint32_t* O = (uint32_t*)out;
+    for (size_t i = 0; i < n; i++) {
+        if (field == 0)
+            field_op<fr_t>(op, A + 8 * i, B + 8 * i, O + 8 * i);
+        else if (field == 1)
+            field_op<fq_t>(op, A + 12 * i, B + 12 * i, O + 12 * i);
+        else
+            return 1;
+    }
+    return 0;
+}
+RustError snarkvm_hip_devtest_field(int field, int op, const void* a, const void* b, void* out, size_t n) {
+    API_BEGIN
+    if (field < 0 || field > 1) throw hip_failure{hipErrorInvalidValue, "devtest_field: field must be 0 or 1", __LINE__};
+    const size_t bytes = n * (field == 0 ? 32 : 48);
+    dev_buf da, db, dout;
+    da.ensure(bytes);
+    db.ensure(bytes);
+    dout.ensure(bytes);
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db.p, b ? b : a, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(devtest_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ctx.stream, field, op, da.as<uint32_t>(),
+                       db.as<uint32_t>(), dout.as<uint32_t>(), n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da.p);
+    (void)hipFree(db.p);
+    (void)hipFree(dout.p);
+    API_END
+}
+// naive sum_i scalar_i * P_i on the host with the device point arithmetic (scalars: 256-bit, 32 B each)
+int snarkvm_hip_selftest_g1_msm_naive(const void* points, size_t npoints, size_t stride, const void* scalars, void* out) {
+    const uint8_t* P = (const uint8_t*)points;
+    const uint32_t* S = (const uint32_t*)scalars;
+    g1_xyzz_t total = g1_xyzz_t::inf();
+    for (size_t i = 0; i < npoints; i++) {
+        const uint32_t* src = (const uint32_t*)(P + i * stride);
+        g1_aff_t a;
+        if (src[24] & 0xff)
+            a = g1_aff_t::inf();
+        else
+            a = {fq_t::unpack(src).from_mem_mont(), fq_t::unpack(src + 12).from_mem_mont()};
+        g1_xyzz_t acc = g1_xyzz_t::inf();
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = acc.dbl();
+            if ((S[8 * i + bit / 32] >> (bit % 32)) & 1) acc.add_affine(a);
+        }
+        // route half of the additions through the xyzz+xyzz law and the negation path
+        if (i & 1) {
+            g1_xyzz_t neg = acc;
+            neg.y = neg.y.neg();
+            g1_xyzz_t t2 = total;
+            t2.add(acc);
+            t2.add(neg);  // + acc - acc
+            t2.add(acc);
+            total = t2;
+        } else {
+            total.add(acc);
+        }
+    }
+    const g1_jac_t j = total.to_jacobian();
+    uint32_t* o = (uint32_t*)out;
+    j.x.to_mem_mont().pack(o);
+    j.y.to_mem_mont().pack(o + 12);
+    j.z.to_mem_mont().pack(o + 24);
+    return 0;
+}
+
+}  // extern "C"

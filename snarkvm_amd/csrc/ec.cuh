@@ -1,0 +1,179 @@
+// ec.cuh - short-Weierstrass (a = 0) point arithmetic for the MSM kernels, templated on the base
+// field so that G1 (Fq) and G2 (Fq2) share one implementation.
+//
+// Device-side representations
+//   aff_t<F>   {x, y}            bases as stored in HBM by the MSM engine; the point at infinity is the
+//                                sentinel (0, 0), which is not on y^2 = x^3 + b for b != 0.
+//   xyzz_t<F>  {x, y, zz, zzz}   bucket accumulator, x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> zz == 0.
+//   jac_t<F>   {x, y, z}         the reference's `Projective` (Jacobian, projective.rs:37-41): ABI result type.
+//
+// The reference accumulates buckets in batched-affine (G1, batched.rs) or Jacobian (standard.rs)
+// coordinates; any complete addition law yields the same group element, and parity is defined on the
+// affine-normalised result (variable_base/mod.rs:96-105), so XYZZ (cheapest mixed addition: 8M + 2S,
+// https://hyperelliptic.org/EFD/g1p/auto-shortw-xyzz.html) is used here.  All exceptional cases of
+// affine.rs:224-273 / projective.rs:222-291 are handled: either operand infinity, P + P, P + (-P).
+#pragma once
+#include "ff.cuh"
+
+namespace sv {
+
+template <class F>
+struct aff_t {
+    F x, y;
+    SV_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    SV_HD static aff_t inf() { return {F::zero(), F::zero()}; }
+};
+
+template <class F>
+struct jac_t {
+    F x, y, z;
+};
+
+template <class F>
+struct xyzz_t {
+    F x, y, zz, zzz;
+
+    SV_HD static xyzz_t inf() { return {F::zero(), F::one(), F::zero(), F::zero()}; }
+    SV_HD bool is_inf() const { return zz.is_zero(); }
+
+    SV_HD static xyzz_t from_affine(const aff_t<F>& p) {
+        if (p.is_inf()) return inf();
+        return {p.x, p.y, F::one(), F::one()};
+    }
+    // doubling of an affine point (mdbl-2008-s-1), a = 0
+    SV_HD static xyzz_t dbl_affine(const aff_t<F>& p) {
+        F u = p.y.dbl();
+        F v = u.sqr();
+        F w = u * v;
+        F s = p.x * v;
+        F xx = p.x.sqr();
+        F m = xx.dbl() + xx;
+        xyzz_t r;
+        r.x = m.sqr() - s.dbl();
+        r.y = m * (s - r.x) - w * p.y;
+        r.zz = v;
+        r.zzz = w;
+        return r;
+    }
+    // dbl-2008-s-1, a = 0
+    SV_HD xyzz_t dbl() const {
+        if (is_inf()) return *this;
+        F u = y.dbl();
+        F v = u.sqr();
+        F w = u * v;
+        F s = x * v;
+        F xx = x.sqr();
+        F m = xx.dbl() + xx;
+        xyzz_t r;
+        r.x = m.sqr() - s.dbl();
+        r.y = m * (s - r.x) - w * y;
+        r.zz = v * zz;
+        r.zzz = w * zzz;
+        return r;
+    }
+    // this += p  (madd-2008-s); `negate` adds -p instead (signed-digit buckets)
+    SV_HD void add_affine(const aff_t<F>& p_in, bool negate = false) {
+        if (p_in.is_inf()) return;
+        aff_t<F> p = p_in;
+        if (negate) p.y = p.y.neg();
+        if (is_inf()) {
+            *this = {p.x, p.y, F::one(), F::one()};
+            return;
+        }
+        F u2 = p.x * zz;
+        F s2 = p.y * zzz;
+        F pp_ = u2 - x;  // P
+        F r = s2 - y;    // R
+        if (pp_.is_zero()) {
+            if (r.is_zero())
+                *this = dbl_affine(p);
+            else
+                *this = inf();
+            return;
+        }
+        F pp = pp_.sqr();
+        F ppp = pp_ * pp;
+        F q = x * pp;
+        F x3 = r.sqr() - ppp - q.dbl();
+        y = r * (q - x3) - y * ppp;
+        x = x3;
+        zz = zz * pp;
+        zzz = zzz * ppp;
+    }
+    // this += o  (add-2008-s)
+    SV_HD void add(const xyzz_t& o) {
+        if (o.is_inf()) return;
+        if (is_inf()) {
+            *this = o;
+            return;
+        }
+        F u1 = x * o.zz;
+        F u2 = o.x * zz;
+        F s1 = y * o.zzz;
+        F s2 = o.y * zzz;
+        F pp_ = u2 - u1;
+        F r = s2 - s1;
+        if (pp_.is_zero()) {
+            if (r.is_zero())
+                *this = dbl();
+            else
+                *this = inf();
+            return;
+        }
+        F pp = pp_.sqr();
+        F ppp = pp_ * pp;
+        F q = u1 * pp;
+        F x3 = r.sqr() - ppp - q.dbl();
+        y = r * (q - x3) - s1 * ppp;
+        x = x3;
+        zz = zz * o.zz * pp;
+        zzz = zzz * o.zzz * ppp;
+    }
+    // k * this for a small unsigned k (MSB-first double-and-add)
+    SV_HD xyzz_t mul_small(uint32_t k) const {
+        xyzz_t acc = inf();
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = acc.dbl();
+            if ((k >> bit) & 1) acc.add(*this);
+        }
+        return acc;
+    }
+    // Jacobian representative: with z = ZZZ/ZZ, take Z' = ZZZ = z^3: X' = x Z'^2 = X ZZ^2, Y' = y Z'^3 = Y ZZZ^2.
+    // Infinity maps to the reference's canonical Projective::zero() = (0, 1, 0) (projective.rs:49-54).
+    SV_HD jac_t<F> to_jacobian() const {
+        if (is_inf()) return {F::zero(), F::one(), F::zero()};
+        return {x * zz.sqr(), y * zzz.sqr(), zzz};
+    }
+};
+
+}  // namespace sv
+
+// ------------------------------------------------------------------------------------------
+// G1 memory images used by the MSM engine (internal Montgomery form, packed 48 B per coordinate)
+// ------------------------------------------------------------------------------------------
+namespace sv {
+struct alignas(16) g1_aff_mem_t {  // device-native base: 96 B, infinity = all zero
+    fq_mem_t x, y;
+};
+struct alignas(16) g1_xyzz_mem_t {  // bucket / partial sum: 192 B
+    fq_mem_t x, y, zz, zzz;
+};
+typedef aff_t<fq_t> g1_aff_t;
+typedef xyzz_t<fq_t> g1_xyzz_t;
+typedef jac_t<fq_t> g1_jac_t;
+
+SV_HD g1_aff_t g1_load_aff(const g1_aff_mem_t* p) { return {fq_t::load(&p->x), fq_t::load(&p->y)}; }
+SV_HD void g1_store_aff(g1_aff_mem_t* p, const g1_aff_t& a) {
+    a.x.store(&p->x);
+    a.y.store(&p->y);
+}
+SV_HD g1_xyzz_t g1_load_xyzz(const g1_xyzz_mem_t* p) {
+    return {fq_t::load(&p->x), fq_t::load(&p->y), fq_t::load(&p->zz), fq_t::load(&p->zzz)};
+}
+SV_HD void g1_store_xyzz(g1_xyzz_mem_t* p, const g1_xyzz_t& a) {
+    a.x.store(&p->x);
+    a.y.store(&p->y);
+    a.zz.store(&p->zz);
+    a.zzz.store(&p->zzz);
+}
+}  // namespace sv

@@ -1,0 +1,424 @@
+// msm.cuh - Pippenger variable-base MSM over BLS12-377 G1 for gfx950.
+//
+// Replaces (behaviour, not code): sppark's msm_t::invoke as called from
+// algorithms/cuda/cuda/snarkvm.cu:249-311, and the CPU algorithms VariableBase::msm /
+// batched::msm / standard::msm (algorithms/src/msm/variable_base/{mod,batched,standard}.rs).
+// Result = sum_i scalars[i] * bases[i] as a Jacobian point; the representative differs from the
+// reference's, the affine normalisation is identical (that is what the reference's tests compare,
+// variable_base/mod.rs:96-105,116-117).
+//
+// Pipeline (all on device, one stream; sizes for n = 2^24, c = 16):
+//   1 digits    scalar-read phase: each 32-byte scalar is read once (coalesced, staged through LDS) and
+//               recoded into W = ceil(254/c) signed c-bit digits with the bias trick
+//               (s' = s + sum_w 2^(c-1+cw); digit_w = ((s' >> cw) & (2^c-1)) - 2^(c-1)), written as u16
+//               [W][n].  HBM-bound: 32n B read + 2Wn B written.
+//   2 histogram per (chunk, window) workgroup: LDS histogram of 2^(c-1) bucket counters, no global atomics.
+//   3 scan      exclusive scan over [window][bucket][chunk] -> scatter offsets.
+//   4 scatter   per (chunk, window): LDS cursors; writes point index | sign<<31 grouped by bucket.
+//   5 accumulate  each bucket gets ceil(size/S) threads; a thread adds <= S points (gathered 96-byte
+//               affine bases, XYZZ mixed addition) and writes a partial sum.  Balanced for any scalar
+//               distribution; ALU-bound (~10 Fq multiplications per point).
+//   6 reduce    rounds of the same kernel over the partials (ceil(count/S2) threads per bucket) until one
+//               sum per bucket is left.
+//   7 bucket reduction  sum_b (b+1) B_b per window by chunked running sums, chunk offset applied with a
+//               small double-and-add; 8 window sum (LDS tree); 9 Horner across windows -> Jacobian.
+// Digit zero is skipped (batched.rs:350: bucket index wraps to u32::MAX and is ignored).
+#pragma once
+#include "ec.cuh"
+
+namespace sv {
+
+struct msm_plan_t {
+    size_t n;
+    int c, W;
+    uint32_t nb;       // buckets per window = 2^(c-1)
+    uint32_t nbt;      // W * nb
+    uint32_t chunk;    // scalars per histogram chunk
+    uint32_t nchunks;
+    uint32_t S, S2;    // points per accumulate thread; partials per reduce thread
+    uint32_t L;        // buckets per bucket-reduction thread
+    int rounds;        // reduce rounds
+    uint32_t bias[10]; // sum_w 2^(c-1+cw), 320-bit
+};
+
+static inline int msm_pick_c(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    int c = lg - 4;
+    if (c < 2) c = 2;
+    if (c > 16) c = 16;
+    return c;
+}
+static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0) {
+    msm_plan_t p;
+    p.n = n;
+    p.c = c_override ? c_override : msm_pick_c(n);
+    p.W = (254 + p.c - 1) / p.c;
+    p.nb = 1u << (p.c - 1);
+    p.nbt = (uint32_t)p.W * p.nb;
+    p.chunk = 1u << 18;
+    if (p.chunk > n) p.chunk = (uint32_t)(n ? n : 1);
+    p.nchunks = (uint32_t)((n + p.chunk - 1) / p.chunk);
+    p.S = 64;
+    p.S2 = 64;
+    p.L = p.nb < 16 ? p.nb : 16;
+    p.rounds = 0;
+    size_t m = (n + p.S - 1) / p.S;
+    while (m > 1) {
+        m = (m + p.S2 - 1) / p.S2;
+        p.rounds++;
+    }
+    for (int i = 0; i < 10; i++) p.bias[i] = 0;
+    for (int w = 0; w < p.W; w++) {
+        int bit = p.c - 1 + p.c * w;
+        p.bias[bit / 32] |= 1u << (bit % 32);  // bits are distinct: no carries while building the constant
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic exclusive scan (u32), tiles of 2048 per 256-thread block, recursive over block sums
+// ------------------------------------------------------------------------------------------
+static constexpr int SCAN_TILE = 2048;
+__global__ void scan_tile_kernel(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n) {
+    __shared__ uint32_t sh[256];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        v[i] = (base + i < n) ? in[base + i] : 0u;
+        s += v[i];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan of per-thread sums
+        uint32_t t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - s;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = sh[255];
+}
+__global__ void scan_add_kernel(uint32_t* out, const uint32_t* block_offsets, size_t n) {
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
+    const uint32_t add = block_offsets[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (base + i < n) out[base + i] += add;
+}
+static inline size_t scan_tmp_elems(size_t n) {
+    size_t tot = 0;
+    while (n > 1) {
+        n = (n + SCAN_TILE - 1) / SCAN_TILE;
+        tot += n + 1;
+        if (n == 1) break;
+    }
+    return tot + 8;
+}
+// out may alias in
+static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp) {
+    if (n == 0) return;
+    const size_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, tmp, n);
+    if (blocks > 1) {
+        exclusive_scan_u32(st, tmp, tmp, blocks, tmp + blocks + 1);
+        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, tmp, n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 0. base conversion: Rust `Affine` (x, y Montgomery R = 2^384, infinity flag; stride bytes) -> g1_aff_mem_t
+// ------------------------------------------------------------------------------------------
+__global__ void g1_convert_bases_kernel(const uint8_t* in, size_t stride, size_t n, g1_aff_mem_t* out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = (const uint32_t*)(in + i * stride);  // stride is a multiple of 8 (Rust layout)
+    uint32_t xw[12], yw[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        xw[k] = src[k];
+        yw[k] = src[12 + k];
+    }
+    const uint32_t inf = src[24] & 0xffu;
+    g1_aff_t a;
+    if (inf) {
+        a = g1_aff_t::inf();
+    } else {
+        a.x = fq_t::unpack(xw).from_mem_mont();
+        a.y = fq_t::unpack(yw).from_mem_mont();
+    }
+    g1_store_aff(&out[i], a);
+}
+
+// ------------------------------------------------------------------------------------------
+// 1. digits (the scalar-read phase)
+// ------------------------------------------------------------------------------------------
+struct msm_digit_params_t {
+    uint32_t bias[10];
+    int c, W;
+    size_t n;
+};
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
+                                                         msm_digit_params_t p) {
+    // 256 scalars per block iteration: coalesced 16-byte loads into LDS, then one scalar per thread
+    __shared__ uint4 stage[512];
+    const size_t nblk = (p.n + 255) / 256;
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const size_t first = blk * 256;
+        const size_t cnt = (p.n - first < 256) ? (p.n - first) : 256;
+        for (int k = threadIdx.x; k < 512; k += 256)
+            if ((size_t)(k >> 1) < cnt) stage[k] = scalars[first * 2 + k];
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const uint4 lo = stage[2 * threadIdx.x], hi = stage[2 * threadIdx.x + 1];
+            uint32_t s[11] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u, 0u, 0u};
+            uint64_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                carry += (uint64_t)s[k] + p.bias[k];
+                s[k] = (uint32_t)carry;
+                carry >>= 32;
+            }
+            const uint32_t mask = (1u << p.c) - 1;
+            const size_t i = first + threadIdx.x;
+            for (int w = 0; w < p.W; w++) {
+                const int bit = p.c * w, wi = bit >> 5, sh = bit & 31;
+                uint64_t two = (uint64_t)s[wi] | ((uint64_t)s[wi + 1] << 32);
+                digits[(size_t)w * p.n + i] = (uint16_t)((uint32_t)(two >> sh) & mask);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2./4. histogram and scatter, one workgroup per (chunk, window); LDS holds nb counters
+// ------------------------------------------------------------------------------------------
+struct msm_sort_params_t {
+    size_t n;
+    uint32_t chunk, nchunks, nb;
+    int c;
+};
+__global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts,
+                                                        msm_sort_params_t p) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t chunk = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)chunk * p.chunk;
+    const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
+    const int half = 1 << (p.c - 1);
+    const uint16_t* d = digits + (size_t)w * p.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int v = (int)d[i] - half;
+        if (v != 0) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x)
+        counts[((size_t)w * p.nb + b) * p.nchunks + chunk] = hist[b];
+}
+__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
+                                                           const uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ sorted, msm_sort_params_t p) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t chunk = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x)
+        cursor[b] = offsets[((size_t)w * p.nb + b) * p.nchunks + chunk];
+    __syncthreads();
+    const size_t lo = (size_t)chunk * p.chunk;
+    const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
+    const int half = 1 << (p.c - 1);
+    const uint16_t* d = digits + (size_t)w * p.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int v = (int)d[i] - half;
+        if (v != 0) {
+            const uint32_t pos = atomicAdd(&cursor[(v < 0 ? -v : v) - 1], 1u);
+            sorted[pos] = (uint32_t)i | (v < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+// boff[k] = first sorted position of bucket k (k = w*nb + b); boff[nbt] = number of sorted entries
+__global__ void msm_bucket_offsets_kernel(const uint32_t* offsets, const uint32_t* counts, uint32_t* boff, uint32_t nbt,
+                                          uint32_t nchunks) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nbt) boff[k] = offsets[(size_t)k * nchunks];
+    if (k == nbt) {
+        const size_t last = (size_t)nbt * nchunks - 1;
+        boff[nbt] = offsets[last] + counts[last];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 5./6. accumulate + reduce rounds
+// ------------------------------------------------------------------------------------------
+// cnt_out[k] = ceil(cnt_in[k] / S); level 0 takes its input counts from bucket offsets
+__global__ void msm_alloc_kernel(const uint32_t* boff, const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t nbt, uint32_t S) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nbt) return;
+    if (k == nbt) {
+        cnt_out[k] = 0;
+        return;
+    }
+    const uint32_t c = boff ? (boff[k + 1] - boff[k]) : cnt_in[k];
+    cnt_out[k] = (c + S - 1) / S;
+}
+// largest k in [0, nbt) with start[k] <= t   (start is non-decreasing, start[nbt] = total > t)
+__device__ __forceinline__ uint32_t find_bucket(const uint32_t* start, uint32_t nbt, uint32_t t) {
+    uint32_t lo = 0, hi = nbt;  // invariant: start[lo] <= t < start[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (start[mid] <= t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const g1_aff_mem_t* __restrict__ bases,
+                                                             const uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ boff,
+                                                             const uint32_t* __restrict__ start,
+                                                             g1_xyzz_mem_t* __restrict__ partial, uint32_t nbt, uint32_t S) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= start[nbt]) return;
+    const uint32_t k = find_bucket(start, nbt, t);
+    const uint32_t j = t - start[k];
+    const uint32_t lo = boff[k] + j * S;
+    uint32_t hi = lo + S;
+    if (hi > boff[k + 1]) hi = boff[k + 1];
+    g1_xyzz_t acc = g1_xyzz_t::inf();
+    for (uint32_t pos = lo; pos < hi; pos++) {
+        const uint32_t e = sorted[pos];
+        const g1_aff_t pt = g1_load_aff(&bases[e & 0x7fffffffu]);
+        acc.add_affine(pt, (e >> 31) != 0);
+    }
+    g1_store_xyzz(&partial[t], acc);
+}
+__global__ void __launch_bounds__(256) msm_reduce_kernel(const g1_xyzz_mem_t* __restrict__ in,
+                                                         const uint32_t* __restrict__ in_start,
+                                                         const uint32_t* __restrict__ in_cnt,
+                                                         const uint32_t* __restrict__ out_start,
+                                                         g1_xyzz_mem_t* __restrict__ out, uint32_t nbt, uint32_t S2) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out_start[nbt]) return;
+    const uint32_t k = find_bucket(out_start, nbt, t);
+    const uint32_t j = t - out_start[k];
+    const uint32_t lo = in_start[k] + j * S2;
+    uint32_t hi = lo + S2;
+    const uint32_t end = in_start[k] + in_cnt[k];
+    if (hi > end) hi = end;
+    g1_xyzz_t acc = g1_load_xyzz(&in[lo]);
+    for (uint32_t pos = lo + 1; pos < hi; pos++) acc.add(g1_load_xyzz(&in[pos]));
+    g1_store_xyzz(&out[t], acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// 7. bucket reduction: thread (w, j) covers buckets [jL, (j+1)L) of window w
+//    contribution = sum_l (l+1) B_(jL+l) + jL * sum_l B_(jL+l)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const g1_xyzz_mem_t* __restrict__ sums,
+                                                                const uint32_t* __restrict__ start,
+                                                                const uint32_t* __restrict__ cnt,
+                                                                g1_xyzz_mem_t* __restrict__ contrib, uint32_t nb,
+                                                                uint32_t L, uint32_t total_threads) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_threads) return;
+    const uint32_t J = nb / L;
+    const uint32_t w = t / J, j = t % J;
+    const uint32_t k0 = w * nb + j * L;
+    g1_xyzz_t run = g1_xyzz_t::inf(), acc = g1_xyzz_t::inf();
+    for (int l = (int)L - 1; l >= 0; l--) {
+        const uint32_t k = k0 + (uint32_t)l;
+        if (cnt[k]) run.add(g1_load_xyzz(&sums[start[k]]));
+        acc.add(run);
+    }
+    if (j) acc.add(run.mul_small(j * L));
+    g1_store_xyzz(&contrib[t], acc);
+}
+// 8. one block per window: tree sum of its J contributions
+__global__ void __launch_bounds__(256) msm_window_sum_kernel(const g1_xyzz_mem_t* __restrict__ contrib,
+                                                             g1_xyzz_mem_t* __restrict__ wsum, uint32_t J) {
+    __shared__ g1_xyzz_mem_t sh[256];
+    const uint32_t w = blockIdx.x;
+    g1_xyzz_t acc = g1_xyzz_t::inf();
+    for (uint32_t j = threadIdx.x; j < J; j += blockDim.x) acc.add(g1_load_xyzz(&contrib[(size_t)w * J + j]));
+    g1_store_xyzz(&sh[threadIdx.x], acc);
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            g1_xyzz_t a = g1_load_xyzz(&sh[threadIdx.x]);
+            a.add(g1_load_xyzz(&sh[threadIdx.x + off]));
+            g1_store_xyzz(&sh[threadIdx.x], a);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wsum[w] = sh[0];
+}
+// 9. Horner across windows (batched.rs:404-413) and conversion to the reference's Jacobian memory image
+struct alignas(16) g1_jac_out_t {
+    fq_mem_t x, y, z;
+};
+__global__ void msm_final_kernel(const g1_xyzz_mem_t* __restrict__ wsum, g1_jac_out_t* out, int W, int c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g1_xyzz_t total = g1_xyzz_t::inf();
+    for (int w = W - 1; w >= 0; w--) {
+        for (int d = 0; d < c; d++) total = total.dbl();
+        total.add(g1_load_xyzz(&wsum[w]));
+    }
+    const g1_jac_t j = total.to_jacobian();
+    j.x.to_mem_mont().store(&out->x);
+    j.y.to_mem_mont().store(&out->y);
+    j.z.to_mem_mont().store(&out->z);
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic base generation (benchmark / test utility): out[i] = (start + i) * G in the Rust layout
+// ------------------------------------------------------------------------------------------
+static constexpr int GEN_RUN = 32;
+__global__ void __launch_bounds__(256) g1_generate_bases_kernel(g1_aff_mem_t gen, uint64_t start, size_t n, uint8_t* out,
+                                                                size_t stride, g1_xyzz_mem_t* scratch_pts,
+                                                                fq_mem_t* scratch_prod) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t first = t * GEN_RUN;
+    if (first >= n) return;
+    const size_t cnt = (n - first < (size_t)GEN_RUN) ? (n - first) : (size_t)GEN_RUN;
+    const g1_aff_t g = g1_load_aff(&gen);
+    // (start + first) * G by double-and-add
+    const uint64_t k = start + first;
+    g1_xyzz_t cur = g1_xyzz_t::inf();
+    for (int bit = 63; bit >= 0; bit--) {
+        cur = cur.dbl();
+        if ((k >> bit) & 1) cur.add_affine(g);
+    }
+    // running addition; prefix products of zzz for one shared inversion (Montgomery's trick).
+    // Multiples of G below the group order are never infinity, so every zzz is invertible.
+    fq_t prod = fq_t::one();
+    for (size_t i = 0; i < cnt; i++) {
+        g1_store_xyzz(&scratch_pts[first + i], cur);
+        prod = prod * cur.zzz;
+        prod.store(&scratch_prod[first + i]);
+        cur.add_affine(g);
+    }
+    fq_t inv = prod.inverse();
+    for (size_t i = cnt; i-- > 0;) {
+        const g1_xyzz_t pt = g1_load_xyzz(&scratch_pts[first + i]);
+        const fq_t zzz_inv = (i == 0) ? inv : inv * fq_t::load(&scratch_prod[first + i - 1]);
+        inv = inv * pt.zzz;
+        const fq_t zz_inv = zzz_inv.sqr() * pt.zz.sqr();  // zz^3 = zzz^2  =>  1/zz = zz^2 / zzz^2
+        uint32_t w[26];
+        (pt.x * zz_inv).to_mem_mont().pack(w);
+        (pt.y * zzz_inv).to_mem_mont().pack(w + 12);
+        w[24] = 0;  // infinity = false + padding
+        w[25] = 0;
+        uint32_t* dst = (uint32_t*)(out + (first + i) * stride);
+        for (int q = 0; q < 26; q++) dst[q] = w[q];
+    }
+}
+
+}  // namespace sv

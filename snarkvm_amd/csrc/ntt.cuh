@@ -1,0 +1,385 @@
+// ntt.cuh - radix-2 NTT / iNTT over BLS12-377 Fr for gfx950.
+//
+// Replaces (behaviour, not code): sppark's NTT::Base / NTT_internal / bit_rev as called from
+// algorithms/cuda/cuda/snarkvm.cu:154-186 and polynomial.cuh:104-266, and the CPU transforms of
+// algorithms/src/fft/domain.rs:374-443 (in_order_fft / ifft / coset_ifft), :691-773 (io/oi helpers).
+//
+// Structure (MI355X-first): a 2^lg transform is split into at most three passes of radix <= 2^8
+// ("four-step" decomposition applied recursively).  One workgroup stages a [2^a rows] x [T columns]
+// tile of 32-byte elements in LDS (<= 64 KiB), runs the a radix-2 DIF stages there with __syncthreads
+// between stages, and writes the tile back:
+//   * non-last pass: in place (same addresses), each element multiplied by the inter-pass twiddle
+//     w_L^(inner*k) looked up from a two-level power table (2 x 4096 entries, L2-resident);
+//   * last pass: rows are contiguous; the output index is digit-reversed so the result lands in
+//     natural (NN) order.  This pass is out-of-place (another workgroup still needs the slots it
+//     would overwrite), hence the ping-pong with a scratch buffer in ntt_run().
+// Every pass reads and writes each element exactly once in >= 256-byte contiguous runs, so HBM traffic is
+// passes * 2 * 32 * n bytes (algorithmic minimum 2 * 32 * n: SURVEY.md 8d).  Twiddles are never
+// streamed from HBM: per-stage twiddles come from a 128-entry table of w_256 powers staged in LDS.
+//
+// Data stays in the reference's memory form (Montgomery, R = 2^256) throughout; see ff.cuh for why the
+// 29-bit-limb arithmetic needs no conversion on this (linear) path.
+#pragma once
+#include "ff.cuh"
+
+namespace sv {
+
+static constexpr int NTT_LG_MAX = 24;     // two-level tables cover exponents < 2^24
+static constexpr int NTT_TW_BITS = 12;    // w^e = hi[e >> 12] * lo[e & 4095]
+static constexpr int NTT_TW_SIZE = 1 << NTT_TW_BITS;
+static constexpr int NTT_MAX_RADIX_LG = 8;
+
+// order / direction / type enums: algorithms/cuda/src/lib.rs:22-40
+enum { NTT_NN = 0, NTT_NR = 1, NTT_RN = 2, NTT_RR = 3 };
+enum { NTT_FORWARD = 0, NTT_INVERSE = 1 };
+enum { NTT_STANDARD = 0, NTT_COSET = 1 };
+
+// Device-resident tables (internal Montgomery form, packed 32 B per entry).
+struct ntt_tables_t {
+    fr_mem_t* pow_lo[2];   // [dir][4096]  W^(+-i)          W = primitive 2^24-th root of unity
+    fr_mem_t* pow_hi[2];   // [dir][4096]  W^(+-4096 i)
+    fr_mem_t* local[2];    // [dir][128]   w_256^(+-i)
+    fr_mem_t* g_lo[2];     // [0]: g^i  [1]: g^-i          g = 22 (fr.rs:126-135)
+    fr_mem_t* g_hi[2];     //      g^(+-4096 i)
+    fr_mem_t* size_inv;    // [25]  (2^lg)^-1
+    fr_mem_t* consts;      // scratch for the set-up kernels
+};
+
+// TWO_ADIC_ROOT_OF_UNITY (fr.rs:115-120), memory form (a * 2^256), 32-bit words
+__device__ static const uint32_t FR_TWO_ADIC_ROOT_MEM[8] = {0xda3ad648u, 0xaf80da4du, 0xfc381dacu, 0x5e223adbu,
+                                                             0xb2f92525u, 0x03ba0666u, 0x3befb0ceu, 0x0f906c5bu};
+
+// consts[0] = W, [1] = W^-1, [2] = g, [3] = g^-1, then size_inv[0..24]
+__global__ void ntt_setup_consts(ntt_tables_t t) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t w8[8];
+    for (int i = 0; i < 8; i++) w8[i] = FR_TWO_ADIC_ROOT_MEM[i];
+    fr_t w = fr_t::unpack(w8).from_mem_mont();          // 2^47-th root, internal form
+    for (int i = 0; i < 47 - NTT_LG_MAX; i++) w = w.sqr();  // -> primitive 2^24-th root
+    fr_t g = fr_t::from_u32(22);
+    w.store(&t.consts[0]);
+    w.inverse().store(&t.consts[1]);
+    g.store(&t.consts[2]);
+    g.inverse().store(&t.consts[3]);
+    fr_t half = fr_t::from_u32(2).inverse();
+    fr_t cur = fr_t::one();
+    for (int lg = 0; lg <= NTT_LG_MAX; lg++) {
+        cur.store(&t.size_inv[lg]);
+        cur = cur * half;
+    }
+}
+// lo[i] = b^i, hi[i] = b^(4096 i) for the four bases; local[dir][i] = (W^+-1)^(65536 i)
+__global__ void ntt_fill_tables(ntt_tables_t t) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NTT_TW_SIZE) return;
+    for (int which = 0; which < 4; which++) {
+        fr_t b = fr_t::load(&t.consts[which]);
+        fr_mem_t* lo = which < 2 ? t.pow_lo[which] : t.g_lo[which - 2];
+        fr_mem_t* hi = which < 2 ? t.pow_hi[which] : t.g_hi[which - 2];
+        b.pow_u64((uint64_t)i).store(&lo[i]);
+        b.pow_u64((uint64_t)i << NTT_TW_BITS).store(&hi[i]);
+        if (which < 2 && i < 128) b.pow_u64((uint64_t)i << 16).store(&t.local[which][i]);
+    }
+}
+
+struct ntt_pass_t {
+    const fr_mem_t* in;
+    fr_mem_t* out;
+    int lg_n;        // transform size
+    int a;           // log2 radix of this pass
+    int s;           // log2 inner stride (non-last pass); 0 for the last pass
+    int lgT;         // log2 tile width
+    int last;        // 1: last pass
+    int a1;          // last pass: log2 size of the leading digit (tile dimension); 0 for a single-pass transform
+    int lg_mid;      // last pass: log2 size of the middle digit (three-pass transforms), else 0
+    int dir;         // NTT_FORWARD / NTT_INVERSE
+    int coset_pre;   // multiply input j by g^j        (forward coset, first pass)
+    int scale_post;  // last pass: 0 none, 1 * n^-1, 2 * g^-k n^-1   (inverse / coset inverse)
+    int tw_shift;    // non-last: twiddle exponent = (inner * k) << tw_shift
+};
+
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+__device__ __forceinline__ fr_t tw_lookup(const fr_mem_t* lo, const fr_mem_t* hi, uint32_t e) {
+    fr_t a = fr_t::load(&lo[e & (NTT_TW_SIZE - 1)]);
+    uint32_t h = e >> NTT_TW_BITS;
+    if (h == 0) return a;
+    return a * fr_t::load(&hi[h]);
+}
+
+// LDS tile: element e = rho * T + col, stored as two 16-byte planes (conflict-free b128 accesses).
+__global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_tables_t tb) {
+    extern __shared__ uint4 lds[];
+    const int R = 1 << p.a, T = 1 << p.lgT, E = R << p.lgT;
+    uint4* lo_plane = lds;
+    uint4* hi_plane = lds + E;
+    uint4* tw_plane = lds + 2 * E;  // 128 local twiddles, 2 x uint4 each
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t tile = blockIdx.x;
+
+    // ---- addressing
+    size_t in_base, in_rho_stride, in_col_stride;
+    size_t inner0 = 0;
+    size_t d1_0 = 0, mid = 0;
+    if (!p.last) {
+        const size_t tiles_per_outer = (size_t)1 << (p.s - p.lgT);
+        const size_t outer = tile / tiles_per_outer;
+        inner0 = (tile % tiles_per_outer) << p.lgT;
+        in_base = (outer << (p.a + p.s)) + inner0;
+        in_rho_stride = (size_t)1 << p.s;
+        in_col_stride = 1;
+    } else {
+        const size_t tiles_per_mid = (size_t)1 << (p.a1 - p.lgT);
+        mid = tile / tiles_per_mid;
+        d1_0 = (tile % tiles_per_mid) << p.lgT;
+        in_base = (d1_0 << (p.lg_n - p.a1)) + (mid << p.a);
+        in_rho_stride = 1;
+        in_col_stride = (size_t)1 << (p.lg_n - p.a1);
+    }
+
+    // ---- load (and optional coset pre-scale by g^j, j = natural input index)
+    for (int i = tid; i < 128; i += nthr) {
+        const uint4* src = (const uint4*)&tb.local[p.dir][i];
+        tw_plane[2 * i] = src[0];
+        tw_plane[2 * i + 1] = src[1];
+    }
+    for (int e = tid; e < E; e += nthr) {
+        int rho, col;
+        if (!p.last) {
+            rho = e >> p.lgT;
+            col = e & (T - 1);
+        } else {
+            col = e >> p.a;
+            rho = e & (R - 1);
+        }
+        const size_t g = in_base + rho * in_rho_stride + col * in_col_stride;
+        const uint4* src = (const uint4*)&p.in[g];
+        uint4 x0 = src[0], x1 = src[1];
+        if (p.coset_pre) {
+            uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            fr_t x = fr_t::unpack(w) * tw_lookup(tb.g_lo[0], tb.g_hi[0], (uint32_t)g);
+            x.pack(w);
+            x0 = make_uint4(w[0], w[1], w[2], w[3]);
+            x1 = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        const int le = rho * T + col;
+        lo_plane[le] = x0;
+        hi_plane[le] = x1;
+    }
+    __syncthreads();
+
+    // ---- a radix-2 DIF stages: (u, v) <- (u + v, (u - v) * w_R^(pos << st))
+    const int nb = E >> 1;
+    for (int st = 0; st < p.a; st++) {
+        const int lg_half = p.a - 1 - st;
+        for (int b = tid; b < nb; b += nthr) {
+            const int col = b & (T - 1);
+            const int q = b >> p.lgT;
+            const int pos = q & ((1 << lg_half) - 1);
+            const int i0 = ((q >> lg_half) << (lg_half + 1)) + pos;
+            const int e0 = i0 * T + col, e1 = e0 + (T << lg_half);
+            uint4 a0 = lo_plane[e0], a1 = hi_plane[e0], b0 = lo_plane[e1], b1 = hi_plane[e1];
+            uint32_t wu[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            uint32_t wv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            fr_t u = fr_t::unpack(wu), v = fr_t::unpack(wv);
+            fr_t sum = u + v, dif = u - v;
+            const int tw_idx = (pos << st) << (NTT_MAX_RADIX_LG - p.a);  // index into w_256 powers
+            if (tw_idx != 0) {
+                uint4 t0 = tw_plane[2 * tw_idx], t1 = tw_plane[2 * tw_idx + 1];
+                uint32_t ww[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                dif = dif * fr_t::unpack(ww);
+            }
+            sum.pack(wu);
+            dif.pack(wv);
+            lo_plane[e0] = make_uint4(wu[0], wu[1], wu[2], wu[3]);
+            hi_plane[e0] = make_uint4(wu[4], wu[5], wu[6], wu[7]);
+            lo_plane[e1] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            hi_plane[e1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store: row rho holds output digit k = bitrev_a(rho)
+    for (int e = tid; e < E; e += nthr) {
+        const int rho = e >> p.lgT, col = e & (T - 1);
+        const uint32_t k = bitrev32((uint32_t)rho, p.a);
+        uint4 x0 = lo_plane[e], x1 = hi_plane[e];
+        size_t g;
+        bool need_mul = false;
+        fr_t f;
+        if (!p.last) {
+            g = in_base + ((size_t)k << p.s) + col;
+            const uint32_t expo = (uint32_t)(((inner0 + col) * (size_t)k) << p.tw_shift);
+            if (expo != 0) {
+                f = tw_lookup(tb.pow_lo[p.dir], tb.pow_hi[p.dir], expo);
+                need_mul = true;
+            }
+        } else {
+            g = (d1_0 + col) + (((size_t)mid + ((size_t)k << p.lg_mid)) << p.a1);
+            if (p.scale_post == 1) {
+                f = fr_t::load(&tb.size_inv[p.lg_n]);
+                need_mul = true;
+            } else if (p.scale_post == 2) {
+                f = tw_lookup(tb.g_lo[1], tb.g_hi[1], (uint32_t)g) * fr_t::load(&tb.size_inv[p.lg_n]);
+                need_mul = true;
+            }
+        }
+        if (need_mul) {
+            uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            fr_t x = fr_t::unpack(w) * f;
+            x.pack(w);
+            x0 = make_uint4(w[0], w[1], w[2], w[3]);
+            x1 = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        uint4* dst = (uint4*)&p.out[g];
+        dst[0] = x0;
+        dst[1] = x1;
+    }
+}
+
+// out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.cuh:128,189; domain.rs:797-804 derange)
+__global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << lg_n)) return;
+    size_t r = lg_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - lg_n)) : 0;
+    const uint4* s = (const uint4*)&in[r];
+    uint4* d = (uint4*)&out[i];
+    d[0] = s[0];
+    d[1] = s[1];
+}
+// polynomial_inner_multiply (polynomial.cuh:36-45): out[i] = a[i] * b[i] (memory Montgomery form, R = 2^256).
+// mont261(x, y) = x y 2^-261 = (a b 2^256) 2^-5, so `fix` = 2^(5 + 261) mod r restores the form (see ff.cuh);
+// with fix_later the factor is left for the caller to fold into a later constant.
+__global__ void fr_pointwise_mul_kernel(fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, size_t n, int fix_now) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        fr_t x = fr_t::load(&a[i]) * fr_t::load(&b[i]);
+        if (fix_now) x = x.from_mem_mont();  // * 2^266 * 2^-261 = * 2^5
+        x.store(&out[i]);
+    }
+}
+// Fr::to_bigint (fp_256.rs:380-413) / from_bigint (fp_256.rs:362-377) over a vector: kzg10 convert_to_bigints
+__global__ void fr_to_bigint_kernel(fr_mem_t* out, const fr_mem_t* in, size_t n, int to_bigint) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        fr_t x = fr_t::load(&in[i]);
+        // memory Montgomery a*2^256 -> a : internal(x) = mem * 2^5 ... use explicit forms:
+        //   to_bigint:   a = mont261(mem, 2^261 * 2^-256 = 2^5)
+        //   from_bigint: a -> internal a*2^261 (times R2) -> memory a*2^256 (times INT2MEM)
+        if (to_bigint) {
+            fr_t c = fr_t::zero();
+            c.v[0] = 32;  // 2^5 as a plain integer
+            x = x * c;
+        } else {
+            x = x.int_to_mont().to_mem_mont();  // a -> a*2^261 -> a*2^256
+        }
+        x.store(&out[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side driver
+// ------------------------------------------------------------------------------------------
+struct ntt_plan_t {
+    int npass;
+    int a[3];
+};
+static inline ntt_plan_t ntt_make_plan(int lg) {
+    ntt_plan_t pl;
+    if (lg <= NTT_MAX_RADIX_LG) {
+        pl.npass = 1;
+        pl.a[0] = lg;
+        pl.a[1] = pl.a[2] = 0;
+    } else if (lg <= 2 * NTT_MAX_RADIX_LG) {
+        pl.npass = 2;
+        pl.a[0] = lg / 2;
+        pl.a[1] = lg - pl.a[0];
+        pl.a[2] = 0;
+    } else {
+        pl.npass = 3;
+        pl.a[0] = lg / 3;
+        pl.a[1] = (lg - pl.a[0]) / 2;
+        pl.a[2] = lg - pl.a[0] - pl.a[1];
+    }
+    return pl;
+}
+
+static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb) {
+    const size_t E = (size_t)1 << (p.a + p.lgT);
+    const size_t ntiles = ((size_t)1 << p.lg_n) / E;
+    int threads = (int)(E / 2);
+    if (threads < 64) threads = 64;
+    if (threads > 512) threads = 512;
+    const size_t shmem = (2 * E + 256) * sizeof(uint4);
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
+}
+
+// NN-order transform of 2^lg elements held in `data`; `scratch` is a second buffer of the same size.
+// The result is left in `data`.
+static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* data, fr_mem_t* scratch, int lg,
+                              int dir, int type) {
+    if (lg == 0) {
+        // size-1 transform: identity (coset shift g^0 = 1, n^-1 = 1)
+        return;
+    }
+    const ntt_plan_t pl = ntt_make_plan(lg);
+    const int scale_post = (dir == NTT_INVERSE) ? (type == NTT_COSET ? 2 : 1) : 0;
+    const int coset_pre = (dir == NTT_FORWARD && type == NTT_COSET) ? 1 : 0;
+    int consumed = 0;
+    for (int k = 0; k < pl.npass; k++) {
+        ntt_pass_t p;
+        p.lg_n = lg;
+        p.a = pl.a[k];
+        p.dir = dir;
+        p.coset_pre = (k == 0) ? coset_pre : 0;
+        p.last = (k == pl.npass - 1);
+        p.scale_post = p.last ? scale_post : 0;
+        p.a1 = p.lg_mid = p.s = p.tw_shift = 0;
+        if (!p.last) {
+            p.s = lg - consumed - p.a;
+            p.lgT = p.s < 3 ? p.s : 3;
+            p.tw_shift = NTT_LG_MAX - (p.a + p.s);
+        } else {
+            p.a1 = (pl.npass >= 2) ? pl.a[0] : 0;
+            p.lg_mid = (pl.npass == 3) ? pl.a[1] : 0;
+            p.lgT = p.a1 < 3 ? p.a1 : 3;
+        }
+        if (pl.npass == 1) {
+            p.in = data;
+            p.out = scratch;
+        } else if (k == 0) {
+            p.in = data;
+            p.out = scratch;
+        } else if (!p.last) {
+            p.in = scratch;
+            p.out = scratch;
+        } else {
+            p.in = scratch;
+            p.out = data;
+        }
+        ntt_launch_pass(st, p, tb);
+        consumed += p.a;
+    }
+    if (pl.npass == 1)
+        (void)hipMemcpyAsync(data, scratch, sizeof(fr_mem_t) << lg, hipMemcpyDeviceToDevice, st);
+}
+
+// Full FFI semantics (any order): bit-reversed inputs/outputs are handled with an explicit permutation pass.
+static inline void ntt_run(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* data, fr_mem_t* scratch, int lg, int order,
+                           int dir, int type) {
+    const size_t n = (size_t)1 << lg;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (order == NTT_RN || order == NTT_RR) {
+        hipLaunchKernelGGL(ntt_bitrev_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, lg);
+        (void)hipMemcpyAsync(data, scratch, sizeof(fr_mem_t) * n, hipMemcpyDeviceToDevice, st);
+    }
+    ntt_run_nn(st, tb, data, scratch, lg, dir, type);
+    if (order == NTT_NR || order == NTT_RR) {
+        hipLaunchKernelGGL(ntt_bitrev_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, lg);
+        (void)hipMemcpyAsync(data, scratch, sizeof(fr_mem_t) * n, hipMemcpyDeviceToDevice, st);
+    }
+}
+
+}  // namespace sv

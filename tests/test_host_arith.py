@@ -1,0 +1,111 @@
+"""The gfx950 device arithmetic (snarkvm_amd/csrc/ff.cuh, ec.cuh: 29-bit limbs) compiled for the host and
+executed on the CPU through the snarkvm_hip_selftest_* hooks, compared with the oracle.  No GPU needed."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu as oracle
+from oracle import pyref
+from snarkvm_amd import _lib, synthetic
+from tests import util
+
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inverse": 4, "neg": 5, "from_bigint": 6, "to_bigint": 7}
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def host_field(field, op, a, b=None):
+    L = _lib.lib()
+    nl = 4 if field == 0 else 6
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, nl)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, nl)
+    out = np.zeros_like(a)
+    rc = L.snarkvm_hip_selftest_field(ctypes.c_int(field), ctypes.c_int(OPS[op]), _p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0]))
+    assert rc == 0
+    return out
+
+
+def _rand_mont(field, n, seed):
+    mod = pyref.R_MOD if field == 0 else pyref.Q_MOD
+    nl = 4 if field == 0 else 6
+    rng = np.random.default_rng(seed)
+    vals = [int.from_bytes(rng.bytes(48), "little") % mod for _ in range(n)]
+    vals[:4] = [0, 1, mod - 1, mod - 2]
+    return np.array([pyref.to_limbs(v, nl) for v in vals], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_device_field_arithmetic_on_host_matches_oracle(field):
+    ofn = oracle.fr_op if field == 0 else oracle.fq_op
+    a = _rand_mont(field, 300, 10 + field)
+    b = _rand_mont(field, 300, 20 + field)[::-1].copy()
+    for op in ("add", "sub", "mul"):
+        assert np.array_equal(host_field(field, op, a, b), ofn(op, a, b)), op
+    assert np.array_equal(host_field(field, "sqr", a), ofn("sqr", a))
+    assert np.array_equal(host_field(field, "neg", a), ofn("neg", a))
+    assert np.array_equal(host_field(field, "from_bigint", a), ofn("from_bigint", a))
+    assert np.array_equal(host_field(field, "to_bigint", a), ofn("to_bigint", a))
+    nz = a[1:40]
+    assert np.array_equal(host_field(field, "inverse", nz), ofn("inverse", nz))
+
+
+def test_limb_tables_match_reference_constants(golden):
+    """Every 29-bit table in ff.cuh is re-derived from the reference's constants."""
+    src = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "ff.cuh")).read()
+
+    def table(struct, name):
+        body = src[src.index("struct " + struct):]
+        body = body[: body.index("\n};")]
+        m = re.search(r"uint32_t " + name + r"\[\d+\] = \{(.*?)\}", body, re.S)
+        vals = [int(x.rstrip("u"), 0) for x in re.findall(r"0x[0-9a-fA-F]+u?|\b\d+\b", m.group(1))]
+        return sum(v << (29 * i) for i, v in enumerate(vals))
+
+    for struct, key, nlimb, membits in (("FrP", "fr", 9, 256), ("FqP", "fq", 13, 384)):
+        mod = pyref.from_limbs(golden["constants"][key]["MODULUS"])
+        B = 29 * nlimb
+        assert table(struct, "MOD") == mod
+        assert table(struct, "ONE") == pow(2, B, mod)
+        assert table(struct, "R2") == pow(2, 2 * B, mod)
+        assert table(struct, "MEM2INT") == pow(2, 2 * B - membits, mod)
+        assert table(struct, "INT2MEM") == pow(2, membits, mod)
+        assert pyref.from_limbs(golden["constants"][key]["R"]) == pow(2, membits, mod)
+    # two-adic root and generator constants used by ntt.cuh / api.hip
+    ntt = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "ntt.cuh")).read()
+    m = re.search(r"FR_TWO_ADIC_ROOT_MEM\[8\] = \{(.*?)\}", ntt, re.S)
+    words = [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
+    assert sum(w << (32 * i) for i, w in enumerate(words)) == pyref.from_limbs(golden["constants"]["fr"]["TWO_ADIC_ROOT_OF_UNITY"])
+    api = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "api.hip")).read()
+    for name, key in (("G1_GEN_X", "GENERATOR_X_MONT"), ("G1_GEN_Y", "GENERATOR_Y_MONT")):
+        m = re.search(name + r"\[6\] = \{(.*?)\}", api, re.S)
+        assert [int(x) for x in re.findall(r"(\d+)ull", m.group(1))] == golden["constants"]["g1"][key]
+    m = re.search(r"FQ_R\[6\] = \{(.*?)\}", api, re.S)
+    assert [int(x) for x in re.findall(r"(\d+)ull", m.group(1))] == golden["constants"]["fq"]["R"]
+
+
+def test_device_point_arithmetic_on_host(golden):
+    """xyzz mixed add / add / double incl. exceptional cases, via a naive double-and-add MSM on the host."""
+    L = _lib.lib()
+    pts = util.srs_points_ints(golden["srs_g1"], 12)
+    pts = pts + [pts[2], pyref.g1_neg(pts[4]), None, pts[0]]
+    r = pyref.R_MOD
+    scal = [int(v) % r for v in synthetic.splitmix64(5, len(pts))]
+    scal[0] = 0
+    scal[1] = 1
+    scal[3] = r - 1
+    scal[12] = scal[2]  # duplicate base with the same scalar: P + P
+    scal[13] = scal[4]  # P and -P with the same scalar: P + (-P)
+    aff = util.g1_affine_from_ints(pts)
+    sc = util.ints_to_fr(scal)
+    out = np.zeros(1, dtype=oracle.G1_PROJECTIVE)
+    rc = L.snarkvm_hip_selftest_g1_msm_naive(_p(aff), ctypes.c_size_t(len(pts)), ctypes.c_size_t(104), _p(sc), _p(out))
+    assert rc == 0
+    got = util.g1_affine_to_ints(oracle.g1_to_affine(out))[0]
+    assert got == pyref.msm_naive(pts, scal)
+    # all-zero scalars -> Projective::zero() = (0, 1, 0)
+    rc = L.snarkvm_hip_selftest_g1_msm_naive(_p(aff), ctypes.c_size_t(len(pts)), ctypes.c_size_t(104), _p(np.zeros_like(sc)), _p(out))
+    assert pyref.from_limbs(out["z"][0]) == 0 and pyref.from_limbs(out["y"][0]) == pyref.FQ_MONT_R

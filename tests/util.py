@@ -5,7 +5,7 @@ import numpy as np
 
 from oracle import pyref
 from oracle import cpu as oracle
-from snarkvm_amd.types import G1_AFFINE, G1_PROJECTIVE, G2_AFFINE
+from snarkvm_amd.layout import G1_AFFINE, G1_PROJECTIVE, G2_AFFINE
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
