@@ -44,6 +44,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing - build it with `python -m snarkvm_amd.build` (hipcc, gfx950). "
                 "snarkvm_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.
+        # If torch is installed, load it first so that this library binds to the runtime that is already in the
+        # process (same SONAME); two runtimes in one process leave the second one without visible GPUs.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
                    "snarkvm_hip_register_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_fr_mul_device",

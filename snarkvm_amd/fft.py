@@ -1,0 +1,79 @@
+"""`EvaluationDomain<Fr>` and `PolyMultiplier` (algorithms/src/fft/domain.rs:83-221, fft/polynomial/multiplier.rs:70-134)
+over the gfx950 NTT.  Vectors are (n, 4) u64 arrays of Montgomery limbs (the Rust `Vec<Fr>` memory image)."""
+import numpy as np
+
+from . import plugin
+from .layout import NTTDirection, NTTInputOutputOrder, NTTType
+
+FR_TWO_ADICITY = 47  # curves/src/bls12_377/fr.rs:109
+
+
+class EvaluationDomain:
+    def __init__(self, size, log_size_of_group):
+        self.size = size
+        self.log_size_of_group = log_size_of_group
+
+    @classmethod
+    def new(cls, num_coeffs):
+        """domain.rs:118-147: size = next_power_of_two(num_coeffs); None if the field has no such subgroup."""
+        size = 1
+        while size < num_coeffs:
+            size <<= 1
+        lg = size.bit_length() - 1
+        if lg > FR_TWO_ADICITY:
+            return None
+        return cls(size, lg)
+
+    def _resized(self, v):
+        """domain.rs:171,187,218: `coeffs.resize(self.size(), zero)` - zero-pad or truncate."""
+        v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((self.size, 4), dtype=np.uint64)
+        k = min(self.size, v.shape[0])
+        out[:k] = v[:k]
+        return out
+
+    def _run(self, v, direction, kind):
+        x = self._resized(v)
+        plugin.NTT(self.size, x, NTTInputOutputOrder.NN, direction, kind)
+        return x
+
+    def fft(self, coeffs):  # domain.rs:162-174
+        return self._run(coeffs, NTTDirection.Forward, NTTType.Standard)
+
+    def ifft(self, evals):  # domain.rs:177-192
+        return self._run(evals, NTTDirection.Inverse, NTTType.Standard)
+
+    def coset_fft(self, coeffs):  # domain.rs:195-207
+        return self._run(coeffs, NTTDirection.Forward, NTTType.Coset)
+
+    def coset_ifft(self, evals):  # domain.rs:210-221
+        return self._run(evals, NTTDirection.Inverse, NTTType.Coset)
+
+
+class PolyMultiplier:
+    """multiplier.rs:27-134: collect coefficient-form polynomials and evaluation-form vectors, multiply."""
+
+    def __init__(self):
+        self.polynomials = []
+        self.evaluations = []
+
+    def add_polynomial(self, coeffs, label=""):
+        self.polynomials.append((label, np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)))
+
+    def add_evaluation(self, evals, label=""):
+        self.evaluations.append((label, np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)))
+
+    def multiply(self):
+        """Returns the coefficient vector with trailing zeros trimmed (DensePolynomial::from_coefficients_vec,
+        dense.rs:76-86), or None when an evaluation vector lives on a different domain (multiplier.rs:76-77)."""
+        if not self.polynomials and not self.evaluations:
+            return np.zeros((0, 4), dtype=np.uint64)  # the zero polynomial
+        degree = sum(max(p.shape[0], 1) for _, p in self.polynomials)  # sum(deg + 1) for trimmed inputs
+        domain = EvaluationDomain.new(degree)
+        if domain is None:
+            return None
+        if any(e.shape[0] != domain.size for _, e in self.evaluations):
+            return None
+        res = plugin.polymul(domain.size, [p for _, p in self.polynomials], [e for _, e in self.evaluations])
+        nz = np.nonzero(res.any(axis=1))[0]
+        return res[: (nz[-1] + 1 if nz.size else 0)]

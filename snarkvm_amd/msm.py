@@ -1,0 +1,65 @@
+"""`VariableBase::msm` for G1 (algorithms/src/msm/variable_base/mod.rs:28-49), bound to the gfx950 backend.
+
+The reference dispatches G1 MSMs with more than 1024 scalars to the accelerator and silently falls back to
+`batched::msm` otherwise / on error.  This package *is* the accelerator side: every size goes to the device
+(the reference's own GPU test drives the FFI from 2^2, mod.rs:109-119) and errors are raised, never masked by
+a CPU path.  `RegisteredBases` is the extension for SRS vectors that stay resident in HBM."""
+import ctypes
+
+import numpy as np
+
+from . import _lib, plugin
+from .layout import G1_AFFINE, G1_PROJECTIVE
+
+
+class VariableBase:
+    @staticmethod
+    def msm(bases, scalars):
+        """bases: G1_AFFINE array; scalars: (n,4) u64 canonical integers (`Fr::to_bigint`).  Returns a
+        G1_PROJECTIVE record (Jacobian; compare after to_affine, like mod.rs:116-117)."""
+        return plugin.msm(bases, scalars)
+
+
+class RegisteredBases:
+    """Device-resident base vector (snarkvm_hip_register_bases)."""
+
+    def __init__(self, bases=None, device_ptr=None, npoints=None):
+        L = _lib.lib()
+        self._h = ctypes.c_void_p()
+        if device_ptr is not None:
+            self.n = int(npoints)
+            err = L.snarkvm_hip_register_bases(ctypes.byref(self._h), ctypes.c_void_p(device_ptr), ctypes.c_size_t(self.n),
+                                               ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(1))
+        else:
+            bases = np.ascontiguousarray(bases, dtype=G1_AFFINE).reshape(-1)
+            self.n = bases.shape[0]
+            err = L.snarkvm_hip_register_bases(ctypes.byref(self._h), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(self.n),
+                                               ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0))
+        _lib.check(err)
+
+    def msm(self, scalars=None, offset=0, device_ptr=None, npoints=None, window_bits=0):
+        """sum_i scalars[i] * bases[offset + i]; scalars either a host (n,4) u64 array or a device pointer."""
+        L = _lib.lib()
+        out = np.zeros(1, dtype=G1_PROJECTIVE)
+        if device_ptr is not None:
+            n = int(npoints)
+            err = L.snarkvm_hip_msm_registered(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(offset), ctypes.c_size_t(n),
+                                               ctypes.c_void_p(device_ptr), ctypes.c_int(1), ctypes.c_int(window_bits))
+        else:
+            scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+            n = scalars.shape[0]
+            err = L.snarkvm_hip_msm_registered(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(offset), ctypes.c_size_t(n),
+                                               ctypes.c_void_p(scalars.ctypes.data), ctypes.c_int(0), ctypes.c_int(window_bits))
+        _lib.check(err)
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().snarkvm_hip_free_bases(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,259 @@
+"""Parity of the HIP path (through the C ABI) against the oracle, on a real MI355X.  Bit-exact: NTT outputs are
+compared limb for limb (unique Montgomery representation), MSM outputs after affine normalisation (x, y, infinity),
+exactly like the reference's own GPU-vs-CPU tests (fft/domain.rs:1140-1218, msm/variable_base/mod.rs:109-119)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import cpu as oracle
+from oracle import pyref
+from snarkvm_amd import _lib, fft, plugin, synthetic
+from snarkvm_amd.layout import G1_AFFINE, G1_PROJECTIVE, NTTDirection, NTTInputOutputOrder, NTTType
+from snarkvm_amd.msm import RegisteredBases, VariableBase
+from tests import util
+from tests.test_host_arith import OPS, _rand_mont
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+# ------------------------------------------------------------------------------------------ field arithmetic
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_ops_on_device(field):
+    L = _lib.lib()
+    ofn = oracle.fr_op if field == 0 else oracle.fq_op
+    a = _rand_mont(field, 1000, 30 + field)
+    b = _rand_mont(field, 1000, 40 + field)[::-1].copy()
+    for op in ("add", "sub", "mul", "sqr", "neg", "from_bigint", "to_bigint", "inverse"):
+        aa = a[1:200] if op == "inverse" else a
+        bb = b[1:200] if op == "inverse" else b
+        out = np.zeros_like(aa)
+        _lib.check(L.snarkvm_hip_devtest_field(ctypes.c_int(field), ctypes.c_int(OPS[op]), _p(aa), _p(bb), _p(out), ctypes.c_size_t(aa.shape[0])))
+        want = ofn(op, aa, bb) if op in ("add", "sub", "mul") else ofn(op, aa)
+        assert np.array_equal(out, want), (field, op)
+
+
+# ------------------------------------------------------------------------------------------ NTT
+def _fr_vec(n, seed):
+    return oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, seed))
+
+
+@pytest.mark.parametrize("lg", list(range(0, 20)))
+def test_ntt_nn_all_transforms_vs_oracle(lg):
+    """test_fft_correctness_cuda (domain.rs:1140-1218): lg 2..19, forward / inverse / coset, NN order."""
+    n = 1 << lg
+    x = _fr_vec(n, 100 + lg)
+    for d in (NTTDirection.Forward, NTTDirection.Inverse):
+        for t in (NTTType.Standard, NTTType.Coset):
+            got = x.copy()
+            plugin.NTT(n, got, NTTInputOutputOrder.NN, d, t)
+            assert np.array_equal(got, oracle.ntt(x, oracle.ORDER_NN, d, t)), (lg, d, t)
+
+
+@pytest.mark.parametrize("lg", [3, 8, 9, 13, 17])
+def test_ntt_all_orders(lg):
+    n = 1 << lg
+    x = _fr_vec(n, 200 + lg)
+    for order in (NTTInputOutputOrder.NR, NTTInputOutputOrder.RN, NTTInputOutputOrder.RR):
+        for d in (NTTDirection.Forward, NTTDirection.Inverse):
+            got = x.copy()
+            plugin.NTT(n, got, order, d, NTTType.Standard)
+            assert np.array_equal(got, oracle.ntt(x, order, d, oracle.STANDARD)), (lg, order, d)
+
+
+@pytest.mark.parametrize("lg", [20, 22])
+def test_ntt_large_vs_oracle(lg):
+    n = 1 << lg
+    x = _fr_vec(n, 300 + lg)
+    got = x.copy()
+    plugin.NTT(n, got, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Standard)
+    assert np.array_equal(got, oracle.ntt(x))
+    plugin.NTT(n, got, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Standard)
+    assert np.array_equal(got, x)
+
+
+def test_ntt_2_24_properties():
+    """BASELINE size: round trip, coset round trip and one spot value by Horner (size-independent properties)."""
+    lg = 24
+    n = 1 << lg
+    x = _fr_vec(n, 324)
+    y = x.copy()
+    plugin.NTT(n, y, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Standard)
+    # X[0] = sum of inputs, X[n/2] = alternating sum
+    ints = None
+    s = oracle.fr_op("add", x[0::2], x[1::2])
+    while s.shape[0] > 1:
+        s = oracle.fr_op("add", s[0::2], s[1::2])
+    assert np.array_equal(y[0], s[0])
+    z = y.copy()
+    plugin.NTT(n, z, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Standard)
+    assert np.array_equal(z, x)
+    plugin.NTT(n, z, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Coset)
+    plugin.NTT(n, z, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Coset)
+    assert np.array_equal(z, x)
+
+
+def test_ntt_rejects_oversized_domain():
+    with pytest.raises(_lib.HipError):
+        _lib.check(_lib.lib().snarkvm_ntt(None, ctypes.c_uint32(25), 0, 0, 0))
+
+
+def test_kat_intt8_and_domain_wrappers(golden):
+    evals = [1, 2, 8, 4, 32, 2, 128, 0]
+    z_lde = [int(v) for v in golden["varuna"]["polynomials"]["z_lde"]]
+    dom = fft.EvaluationDomain.new(8)
+    got = dom.ifft(util.ints_to_fr_mont(evals))
+    assert util.fr_mont_to_ints(got) == z_lde
+    # resize semantics: truncation and zero padding (domain.rs:171)
+    short = util.ints_to_fr_mont([5, 7, 11])
+    assert np.array_equal(dom.fft(short), oracle.ntt(np.vstack([short, np.zeros((5, 4), dtype=np.uint64)])))
+    assert fft.EvaluationDomain.new(0).size == 1 and fft.EvaluationDomain.new(1 << 48) is None
+
+
+def test_polymul_vs_oracle(golden):
+    rng = np.random.default_rng(7)
+    for lens in [(3, 5), (17, 40), (64, 64), (1000, 900, 100), (5000, 3000)]:
+        polys = [_fr_vec(k, 400 + k) for k in lens]
+        lg = 0
+        while (1 << lg) < sum(lens):
+            lg += 1
+        got = plugin.polymul(1 << lg, polys, [])
+        assert np.array_equal(got, oracle.polymul(lg, polys)), lens
+    # coefficient + evaluation form, and the single-evaluation corner case (snarkvm.cu:203-208)
+    polys = [_fr_vec(100, 1), _fr_vec(120, 2)]
+    ev = [_fr_vec(256, 3)]
+    assert np.array_equal(plugin.polymul(256, polys, ev), oracle.polymul(8, polys, ev))
+    assert np.array_equal(plugin.polymul(256, [], ev), oracle.polymul(8, [], ev))
+    # KAT-polymul16 through PolyMultiplier (trim of trailing zeros)
+    pa = oracle.ntt(util.ints_to_fr_mont([2, 2, 2, 2, 2, 8, 32, 0]), direction=oracle.INVERSE)
+    pb = oracle.ntt(util.ints_to_fr_mont([4, 4, 4, 4, 4, 4, 4, 0]), direction=oracle.INVERSE)
+    pm = fft.PolyMultiplier()
+    pm.add_polynomial(pa)
+    pm.add_polynomial(pb)
+    res = pm.multiply()
+    want = oracle.polymul(4, [pa, pb])
+    assert np.array_equal(res, want[: res.shape[0]]) and not want[res.shape[0] :].any()
+
+
+# ------------------------------------------------------------------------------------------ MSM
+def _srs(golden, n):
+    pts = util.srs_points_ints(golden["srs_g1"])
+    aff = util.g1_affine_from_ints(pts)
+    reps = (n + len(pts) - 1) // len(pts)
+    return np.tile(aff, reps)[:n].copy()  # tiled like the reference benches (benches/msm/variable_base.rs:29-32)
+
+
+def _check(bases, scalars, got):
+    want = oracle.g1_to_affine(oracle.g1_msm(bases, scalars, oracle.MSM_BATCHED))
+    assert util.affine_equal(oracle.g1_to_affine(got), want)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 10, 14, 15, 31, 32, 50, 100, 500, 1000, 1024, 1025, 4096])
+def test_msm_small_sizes_vs_oracle(golden, n):
+    bases = _srs(golden, n)
+    sc = synthetic.random_fr_integers(n, 500 + n)
+    _check(bases, sc, VariableBase.msm(bases, sc))
+
+
+@pytest.mark.parametrize("lg", [14, 16, 18])
+def test_msm_pow2_vs_oracle(golden, lg):
+    """test_msm_cuda (variable_base/mod.rs:109-119) sizes and the 2^16 plumbing config of BASELINE.json."""
+    n = 1 << lg
+    g = util.g1_generator_affine()
+    bases = oracle.g1_gen_bases(g, 1, n)
+    sc = synthetic.random_fr_integers(n, synthetic.SEED_MSM_2_16)
+    _check(bases, sc, VariableBase.msm(bases, sc))
+
+
+def test_msm_unequal_lengths(golden):
+    bases = _srs(golden, 1024)
+    sc = synthetic.random_fr_integers(924, 9)
+    got = VariableBase.msm(bases, sc)
+    _check(bases[:924], sc, got)
+
+
+def test_msm_edge_cases(golden):
+    pts = util.srs_points_ints(golden["srs_g1"], 64)
+    r = pyref.R_MOD
+    pts = pts[:40] + [pts[3]] * 8 + [pyref.g1_neg(pts[5])] * 4 + [None] * 4 + pts[40:48]
+    scal = [0, 1, r - 1, 2, 1, 1, r - 1, 0] + [int(v) % r for v in synthetic.splitmix64(3, 56)]
+    scal[40:48] = [scal[3]] * 8
+    scal[48:52] = [scal[5]] * 4
+    bases = util.g1_affine_from_ints(pts)
+    sc = util.ints_to_fr(scal)
+    got = util.g1_affine_to_ints(oracle.g1_to_affine(VariableBase.msm(bases, sc)))[0]
+    assert got == pyref.msm_naive(pts, scal)
+    # all-zero scalars and the empty MSM -> infinity, affine (0, 1, inf)
+    for b_, s_ in ((bases, np.zeros((64, 4), dtype=np.uint64)), (bases, np.zeros((0, 4), dtype=np.uint64))):
+        z = oracle.g1_to_affine(VariableBase.msm(b_, s_))
+        assert z["infinity"][0] == 1
+    # all scalars equal (one bucket per window takes every point) and all scalars == r - 1
+    n = 3000
+    bases = _srs(golden, n)
+    for v in (12345678901234567890123, r - 1, 1, 2**252):
+        sc = util.ints_to_fr([v] * n)
+        _check(bases, sc, VariableBase.msm(bases, sc))
+
+
+def test_msm_witness_like_distribution(golden):
+    n = 1 << 15
+    bases = oracle.g1_gen_bases(util.g1_generator_affine(), 7, n)
+    sc = synthetic.witness_like_scalars(n, 77)
+    _check(bases, sc, VariableBase.msm(bases, sc))
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_msm_every_window_size(golden, c):
+    n = 2000
+    bases = _srs(golden, n)
+    sc = synthetic.random_fr_integers(n, 600 + c)
+    rb = RegisteredBases(bases)
+    _check(bases, sc, rb.msm(sc, window_bits=c))
+    # sub-range of the registered vector (KZG degree-bounded commitments use a base offset, kzg10/mod.rs:124-129)
+    _check(bases[100:1100], sc[:1000], rb.msm(sc[:1000], offset=100, window_bits=c))
+    rb.close()
+
+
+def _device_bases(n, start=1):
+    import torch
+
+    buf = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(start), ctypes.c_size_t(n)))
+    return buf
+
+
+def test_generated_bases_match_oracle():
+    n = 5000
+    buf = _device_bases(n, start=3)
+    got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=G1_AFFINE)
+    want = oracle.g1_gen_bases(util.g1_generator_affine(), 3, n)
+    assert util.affine_equal(got, want)
+
+
+@pytest.mark.parametrize("lg", [20, 24])
+def test_msm_full_size_closed_form(lg):
+    """BASELINE sizes.  bases_i = (i+1) G, so sum_i s_i bases_i = (sum_i s_i (i+1) mod r) G: an O(n) closed form
+    that needs no CPU MSM.  Scalars and bases are device-resident (registered)."""
+    import torch
+
+    n = 1 << lg
+    buf = _device_bases(n, start=1)
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n)
+    sc = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    got = rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
+    k = util.weighted_sum_mod_r(sc, start=1)
+    want = oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), util.limbs(k, 4)))
+    assert util.affine_equal(oracle.g1_to_affine(got), want)
+    if lg == 20:
+        # the same vectors through the plain FFI (host pointers, bases converted per call) and the CPU oracle
+        host_bases = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=G1_AFFINE)
+        assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(host_bases, sc)), want)
+        assert util.affine_equal(oracle.g1_to_affine(oracle.g1_msm(host_bases, sc, oracle.MSM_BATCHED)), want)
+    rb.close()

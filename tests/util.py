@@ -108,3 +108,21 @@ def affine_equal(a, b):
 
 def g1_generator_affine():
     return g1_affine_from_ints([pyref.G1_GEN])
+
+
+def weighted_sum_mod_r(scalars, start=1):
+    """sum_i (start + i) * scalars[i] mod r for an (n,4) u64 array, vectorised (16-bit pieces, chunked)."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = s.shape[0]
+    total = 0
+    CH = 1 << 18
+    for lo in range(0, n, CH):
+        hi = min(n, lo + CH)
+        wgt = np.arange(start + lo, start + hi, dtype=np.uint64)
+        for limb in range(4):
+            col = s[lo:hi, limb]
+            for piece in range(4):
+                part = (col >> np.uint64(16 * piece)) & np.uint64(0xFFFF)
+                # weights < 2^26, pieces < 2^16, chunk 2^18 -> sums < 2^60
+                total += int(np.sum(part * wgt, dtype=np.uint64)) << (64 * limb + 16 * piece)
+    return total % pyref.R_MOD
