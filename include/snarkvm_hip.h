@@ -88,6 +88,13 @@ void snarkvm_hip_free_bases(snarkvm_hip_bases_t *handle);
 RustError snarkvm_hip_msm_registered(void *out, const snarkvm_hip_bases_t *handle, size_t offset, size_t npoints,
                                      const void *scalars, int scalars_on_device, int window_bits);
 
+/* G2 variable-base MSM (the reference routes G2 through its CPU `standard::msm`,
+ * msm/variable_base/{mod.rs:45-47,standard.rs:79-105}; north_star asks for it on the device).
+ * `points_with_infinity` is a Rust `[G2Affine]` (x, y in Fq2 = 96 B each, infinity flag; stride 200 B);
+ * `out` is a G2Projective (Jacobian, 288 B). */
+RustError snarkvm_hip_msm_g2(void *out, const void *points_with_infinity, size_t npoints, const void *scalars,
+                             size_t ffi_affine_sz);
+
 /* Fr vector helpers on device memory: out[i] = a[i] * b[i] (polynomial_inner_multiply,
  * polynomial.cuh:36-45); Fr::to_bigint / from_bigint over a vector (kzg10/mod.rs:469-474). */
 RustError snarkvm_hip_fr_mul_device(void *d_out, const void *d_a, const void *d_b, size_t n);

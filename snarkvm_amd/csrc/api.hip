@@ -169,25 +169,28 @@ struct snarkvm_hip_bases {
 // ------------------------------------------------------------------------------------------------
 // MSM driver
 // ------------------------------------------------------------------------------------------------
+static const uint64_t FQ_R[6] = {202099033278250856ull,  5854854902718660529ull, 11492539364873682930ull,
+                                 8885205928937022213ull, 5545221690922665192ull, 39800542322357402ull};  // fq.rs:134-141
+// Projective::zero() = (0, 1, 0) in Montgomery form (projective.rs:49-54); Fq2 one = (R, 0)
+template <class F>
 static void write_infinity(void* out) {
-    // Projective::zero() = (0, 1, 0) in Montgomery form (projective.rs:49-54)
-    static const uint64_t FQ_R[6] = {202099033278250856ull,  5854854902718660529ull, 11492539364873682930ull,
-                                     8885205928937022213ull, 5545221690922665192ull, 39800542322357402ull};  // fq.rs:134-141
-    uint64_t* o = (uint64_t*)out;
-    memset(o, 0, 144);
-    memcpy(o + 6, FQ_R, 48);
+    const size_t fb = sizeof(typename F::mem_t);
+    memset(out, 0, 3 * fb);
+    memcpy((uint8_t*)out + fb, FQ_R, 48);
 }
 
 // d_bases: converted device bases; d_scalars: device scalars (32 B each); result written to host `out` (144 B)
-static void msm_run(context_t& c, const g1_aff_mem_t* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits) {
+template <class F>
+static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits) {
     if (n == 0) {
-        write_infinity(out);
+        write_infinity<F>(out);
         return;
     }
     if (n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: npoints must be < 2^31", __LINE__};
     const msm_plan_t pl = msm_make_plan(n, window_bits);
     if ((size_t)pl.W * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: W * npoints must be < 2^32", __LINE__};
     hipStream_t st = c.stream;
+    constexpr unsigned WS_THREADS = sizeof(xyzz_mem_t<F>) > 192 ? 128 : 256;  // window-sum LDS tile <= 48 KiB
     const size_t E_max = (size_t)pl.W * n;
     const uint32_t nbt = pl.nbt;
 
@@ -206,12 +209,12 @@ static void msm_run(context_t& c, const g1_aff_mem_t* d_bases, const uint4* d_sc
     const size_t slack = (size_t)nbt / 32 + 64;
     const size_t T0_max = E_max / pl.S + nbt + 1 + slack;
     const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
-    c.part_a.ensure(T0_max * sizeof(g1_xyzz_mem_t));
-    c.part_b.ensure(T1_max * sizeof(g1_xyzz_mem_t));
+    c.part_a.ensure(T0_max * sizeof(xyzz_mem_t<F>));
+    c.part_b.ensure(T1_max * sizeof(xyzz_mem_t<F>));
     const uint32_t J = pl.nb / pl.L;
-    c.contrib.ensure((size_t)pl.W * J * sizeof(g1_xyzz_mem_t));
-    c.wsum.ensure((size_t)pl.W * sizeof(g1_xyzz_mem_t));
-    c.result.ensure(sizeof(g1_jac_out_t));
+    c.contrib.ensure((size_t)pl.W * J * sizeof(xyzz_mem_t<F>));
+    c.wsum.ensure((size_t)pl.W * sizeof(xyzz_mem_t<F>));
+    c.result.ensure(sizeof(jac_mem_t<F>));
 
     // 1. digits
     c.phase_begin("msm_digits");
@@ -251,21 +254,21 @@ static void msm_run(context_t& c, const g1_aff_mem_t* d_bases, const uint4* d_sc
     hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.boff.as<uint32_t>(), (const uint32_t*)nullptr,
                        c.cnt_a.as<uint32_t>(), nbt, pl.S);
     exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases, c.sorted.as<uint32_t>(),
-                       c.boff.as<uint32_t>(), c.start_a.as<uint32_t>(), c.part_a.as<g1_xyzz_mem_t>(), nbt, pl.S);
+    hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases, c.sorted.as<uint32_t>(),
+                       c.boff.as<uint32_t>(), c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S);
     c.phase_end();
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
     c.phase_begin("msm_reduce_partials");
     uint32_t *cnt_in = c.cnt_a.as<uint32_t>(), *cnt_out = c.cnt_b.as<uint32_t>();
     uint32_t *start_in = c.start_a.as<uint32_t>(), *start_out = c.start_b.as<uint32_t>();
-    g1_xyzz_mem_t *pin = c.part_a.as<g1_xyzz_mem_t>(), *pout = c.part_b.as<g1_xyzz_mem_t>();
+    xyzz_mem_t<F> *pin = c.part_a.as<xyzz_mem_t<F>>(), *pout = c.part_b.as<xyzz_mem_t<F>>();
     size_t T_in_max = T0_max;
     for (int r = 0; r < pl.rounds; r++) {
         size_t T_out_max = T_in_max / pl.S2 + nbt + 1;
         if (T_out_max > T1_max) T_out_max = T1_max;  // both ping-pong buffers hold >= T1_max partials
         hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)nullptr, cnt_in, cnt_out, nbt, pl.S2);
         exclusive_scan_u32(st, cnt_out, start_out, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3((unsigned)((T_out_max + 255) / 256)), dim3(256), 0, st, pin, start_in, cnt_in, start_out, pout,
+        hipLaunchKernelGGL((msm_reduce_kernel<F>), dim3((unsigned)((T_out_max + 255) / 256)), dim3(256), 0, st, pin, start_in, cnt_in, start_out, pout,
                            nbt, pl.S2);
         std::swap(cnt_in, cnt_out);
         std::swap(start_in, start_out);
@@ -276,22 +279,46 @@ static void msm_run(context_t& c, const g1_aff_mem_t* d_bases, const uint4* d_sc
     // 7.-9. bucket reduction, window sums, Horner
     c.phase_begin("msm_bucket_reduce");
     const uint32_t total_threads = (uint32_t)pl.W * J;
-    hipLaunchKernelGGL(msm_bucket_reduce_kernel, dim3((total_threads + 255) / 256), dim3(256), 0, st, pin, start_in, cnt_in,
-                       c.contrib.as<g1_xyzz_mem_t>(), pl.nb, pl.L, total_threads);
-    hipLaunchKernelGGL(msm_window_sum_kernel, dim3(pl.W), dim3(256), 0, st, c.contrib.as<g1_xyzz_mem_t>(), c.wsum.as<g1_xyzz_mem_t>(), J);
+    hipLaunchKernelGGL((msm_bucket_reduce_kernel<F>), dim3((total_threads + 255) / 256), dim3(256), 0, st, pin, start_in, cnt_in,
+                       c.contrib.as<xyzz_mem_t<F>>(), pl.nb, pl.L, total_threads);
+    hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(pl.W), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, c.contrib.as<xyzz_mem_t<F>>(), c.wsum.as<xyzz_mem_t<F>>(), J);
     c.phase_end();
     c.phase_begin("msm_final_horner");
-    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, c.wsum.as<g1_xyzz_mem_t>(), c.result.as<g1_jac_out_t>(), pl.W, pl.c);
+    hipLaunchKernelGGL((msm_final_kernel<F>), dim3(1), dim3(64), 0, st, c.wsum.as<xyzz_mem_t<F>>(), c.result.as<jac_mem_t<F>>(), pl.W, pl.c);
     c.phase_end();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(g1_jac_out_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(jac_mem_t<F>), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 }
 
-static void convert_bases(context_t& c, const uint8_t* d_in, size_t stride, size_t n, g1_aff_mem_t* d_out) {
+template <class F>
+static void convert_bases(context_t& c, const uint8_t* d_in, size_t stride, size_t n, aff_mem_t<F>* d_out) {
     if (!n) return;
-    hipLaunchKernelGGL(g1_convert_bases_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_in, stride, n, d_out);
+    hipLaunchKernelGGL((convert_bases_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_in, stride, n, d_out);
     HIP_TRY(hipGetLastError());
+}
+
+// Plain FFI MSM (host pointers): stage, convert, run.  G1: F = fq_t (stride >= 104), G2: F = fq2_t (stride >= 200).
+template <class F>
+static void msm_host(context_t& c, void* out, const void* points, size_t npoints, const void* scalars, size_t stride) {
+    if (npoints == 0) {
+        write_infinity<F>(out);
+        return;
+    }
+    const size_t min_stride = 2 * sizeof(typename F::mem_t) + 8;
+    if (stride < min_stride || (stride & 7)) throw hip_failure{hipErrorInvalidValue, "msm: bad ffi_affine_sz for this curve", __LINE__};
+    const size_t aff_bytes = (npoints * sizeof(aff_mem_t<F>) + 255) & ~(size_t)255;
+    c.bases_tmp.ensure(aff_bytes + npoints * stride);
+    c.scalars_tmp.ensure(npoints * 32);
+    uint8_t* raw = c.bases_tmp.as<uint8_t>() + aff_bytes;
+    c.phase_begin("msm_h2d");
+    HIP_TRY(hipMemcpyAsync(raw, points, npoints * stride, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, c.stream));
+    c.phase_end();
+    c.phase_begin("msm_convert_bases");
+    convert_bases<F>(c, raw, stride, npoints, c.bases_tmp.as<aff_mem_t<F>>());
+    c.phase_end();
+    msm_run<F>(c, c.bases_tmp.as<aff_mem_t<F>>(), c.scalars_tmp.as<uint4>(), npoints, out, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -465,23 +492,12 @@ RustError snarkvm_polymul(void* out, size_t pcount, const void* polynomials, con
 // ---- MSM ---------------------------------------------------------------------------------------
 RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
     API_BEGIN
-    if (npoints == 0) {
-        write_infinity(out);
-    } else {
-        if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "msm: ffi_affine_sz must be >= 104 and 8-byte aligned", __LINE__};
-        const size_t aff_bytes = (npoints * sizeof(g1_aff_mem_t) + 255) & ~(size_t)255;
-        g_ctx.bases_tmp.ensure(aff_bytes + npoints * ffi_affine_sz);
-        g_ctx.scalars_tmp.ensure(npoints * 32);
-        uint8_t* raw = g_ctx.bases_tmp.as<uint8_t>() + aff_bytes;
-        g_ctx.phase_begin("msm_h2d");
-        HIP_TRY(hipMemcpyAsync(raw, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
-        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, g_ctx.stream));
-        g_ctx.phase_end();
-        g_ctx.phase_begin("msm_convert_bases");
-        convert_bases(g_ctx, raw, ffi_affine_sz, npoints, g_ctx.bases_tmp.as<g1_aff_mem_t>());
-        g_ctx.phase_end();
-        msm_run(g_ctx, g_ctx.bases_tmp.as<g1_aff_mem_t>(), g_ctx.scalars_tmp.as<uint4>(), npoints, out, 0);
-    }
+    msm_host<fq_t>(g_ctx, out, points, npoints, scalars, ffi_affine_sz);
+    API_END
+}
+RustError snarkvm_hip_msm_g2(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
+    API_BEGIN
+    msm_host<fq2_t>(g_ctx, out, points, npoints, scalars, ffi_affine_sz);
     API_END
 }
 
@@ -499,7 +515,7 @@ RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* p
             HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
             src = g_ctx.bases_tmp.as<uint8_t>();
         }
-        convert_bases(g_ctx, src, ffi_affine_sz, npoints, h->d);
+        convert_bases<fq_t>(g_ctx, src, ffi_affine_sz, npoints, h->d);
         HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     }
     *handle = h;
@@ -524,7 +540,7 @@ RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, si
         g_ctx.phase_end();
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
-    msm_run(g_ctx, h->d + offset, d_sc, npoints, out, window_bits);
+    msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits);
     API_END
 }
 

@@ -149,31 +149,51 @@ struct xyzz_t {
 }  // namespace sv
 
 // ------------------------------------------------------------------------------------------
-// G1 memory images used by the MSM engine (internal Montgomery form, packed 48 B per coordinate)
+// Memory images used by the MSM engine (internal Montgomery form, packed words per coordinate)
 // ------------------------------------------------------------------------------------------
 namespace sv {
-struct alignas(16) g1_aff_mem_t {  // device-native base: 96 B, infinity = all zero
-    fq_mem_t x, y;
+template <class F>
+struct alignas(16) aff_mem_t {  // device-native base (G1: 96 B, G2: 192 B); infinity = all zero
+    typename F::mem_t x, y;
 };
-struct alignas(16) g1_xyzz_mem_t {  // bucket / partial sum: 192 B
-    fq_mem_t x, y, zz, zzz;
+template <class F>
+struct alignas(16) xyzz_mem_t {  // bucket / partial sum (G1: 192 B, G2: 384 B)
+    typename F::mem_t x, y, zz, zzz;
 };
-typedef aff_t<fq_t> g1_aff_t;
-typedef xyzz_t<fq_t> g1_xyzz_t;
-typedef jac_t<fq_t> g1_jac_t;
-
-SV_HD g1_aff_t g1_load_aff(const g1_aff_mem_t* p) { return {fq_t::load(&p->x), fq_t::load(&p->y)}; }
-SV_HD void g1_store_aff(g1_aff_mem_t* p, const g1_aff_t& a) {
+template <class F>
+struct alignas(16) jac_mem_t {  // the reference's Projective memory image (G1: 144 B, G2: 288 B)
+    typename F::mem_t x, y, z;
+};
+template <class F>
+SV_HD aff_t<F> load_aff(const aff_mem_t<F>* p) {
+    return {F::load(&p->x), F::load(&p->y)};
+}
+template <class F>
+SV_HD void store_aff(aff_mem_t<F>* p, const aff_t<F>& a) {
     a.x.store(&p->x);
     a.y.store(&p->y);
 }
-SV_HD g1_xyzz_t g1_load_xyzz(const g1_xyzz_mem_t* p) {
-    return {fq_t::load(&p->x), fq_t::load(&p->y), fq_t::load(&p->zz), fq_t::load(&p->zzz)};
+template <class F>
+SV_HD xyzz_t<F> load_xyzz(const xyzz_mem_t<F>* p) {
+    return {F::load(&p->x), F::load(&p->y), F::load(&p->zz), F::load(&p->zzz)};
 }
-SV_HD void g1_store_xyzz(g1_xyzz_mem_t* p, const g1_xyzz_t& a) {
+template <class F>
+SV_HD void store_xyzz(xyzz_mem_t<F>* p, const xyzz_t<F>& a) {
     a.x.store(&p->x);
     a.y.store(&p->y);
     a.zz.store(&p->zz);
     a.zzz.store(&p->zzz);
 }
+
+typedef aff_mem_t<fq_t> g1_aff_mem_t;
+typedef xyzz_mem_t<fq_t> g1_xyzz_mem_t;
+typedef aff_t<fq_t> g1_aff_t;
+typedef xyzz_t<fq_t> g1_xyzz_t;
+typedef jac_t<fq_t> g1_jac_t;
+typedef jac_mem_t<fq_t> g1_jac_out_t;
+static_assert(sizeof(g1_aff_mem_t) == 96 && sizeof(g1_xyzz_mem_t) == 192 && sizeof(g1_jac_out_t) == 144, "G1 images");
+static_assert(sizeof(jac_mem_t<fq2_t>) == 288, "G2Projective image");
+SV_HD g1_aff_t g1_load_aff(const g1_aff_mem_t* p) { return load_aff<fq_t>(p); }
+SV_HD g1_xyzz_t g1_load_xyzz(const g1_xyzz_mem_t* p) { return load_xyzz<fq_t>(p); }
+SV_HD void g1_store_xyzz(g1_xyzz_mem_t* p, const g1_xyzz_t& a) { store_xyzz<fq_t>(p, a); }
 }  // namespace sv

@@ -72,6 +72,12 @@ struct FqP {  // base field q, 377 bits (fq.rs:111-150)
                                              0x133d256fu, 0x05fbe934u, 0x08d6661eu};  // 2^384 mod q
 };
 
+// memory image of a field element as the Rust side sees it (little-endian 32-bit words)
+template <int W>
+struct alignas(16) mem_words_t {
+    uint32_t w[W];
+};
+
 // ------------------------------------------------------------------------------------------
 // Fp<P>: N limbs of 29 bits, canonical, internal Montgomery form a * 2^(29N)
 // ------------------------------------------------------------------------------------------
@@ -79,6 +85,8 @@ template <class P>
 struct Fp {
     static constexpr int N = P::N;
     static constexpr int WORDS = P::WORDS;
+    static constexpr int MEM_WORDS = P::WORDS;
+    typedef mem_words_t<P::WORDS> mem_t;
     uint32_t v[N];
 
     SV_HD static Fp zero() {
@@ -269,6 +277,10 @@ struct Fp {
         return r;
     }
 
+    // raw words of the reference's Montgomery memory form <-> internal form
+    SV_HD static Fp from_raw_words(const uint32_t* w) { return unpack(w).from_mem_mont(); }
+    SV_HD void to_raw_words(uint32_t* w) const { to_mem_mont().pack(w); }
+
     // ---- conversions between representations
     // canonical integer -> internal Montgomery, and back
     SV_HD Fp int_to_mont() const { return *this * from_table(P::R2); }
@@ -317,14 +329,59 @@ struct Fp {
 
 typedef Fp<FrP> fr_t;
 typedef Fp<FqP> fq_t;
-
-// memory images (what the Rust side sees)
-struct alignas(16) fr_mem_t {
-    uint32_t w[8];
-};
-struct alignas(16) fq_mem_t {
-    uint32_t w[12];
-};
+typedef fr_t::mem_t fr_mem_t;
+typedef fq_t::mem_t fq_mem_t;
 static_assert(sizeof(fr_mem_t) == 32 && sizeof(fq_mem_t) == 48, "field element sizes must match the Rust layout");
+
+// ------------------------------------------------------------------------------------------
+// Fq2 = Fq[u] / (u^2 + 5)   (fields/src/fp2.rs:57-60, curves/src/bls12_377/fq2.rs:58-69: NONRESIDUE = -5)
+// Same interface as Fp so that ec.cuh / msm.cuh work for G2.
+// ------------------------------------------------------------------------------------------
+struct fq2_t {
+    fq_t c0, c1;
+    static constexpr int MEM_WORDS = 24;
+    struct alignas(16) mem_t {
+        fq_mem_t c0, c1;
+    };
+    SV_HD static fq2_t zero() { return {fq_t::zero(), fq_t::zero()}; }
+    SV_HD static fq2_t one() { return {fq_t::one(), fq_t::zero()}; }
+    SV_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    SV_HD bool operator==(const fq2_t& b) const { return c0 == b.c0 && c1 == b.c1; }
+    SV_HD bool operator!=(const fq2_t& b) const { return !(*this == b); }
+    SV_HD fq2_t operator+(const fq2_t& b) const { return {c0 + b.c0, c1 + b.c1}; }
+    SV_HD fq2_t operator-(const fq2_t& b) const { return {c0 - b.c0, c1 - b.c1}; }
+    SV_HD fq2_t neg() const { return {c0.neg(), c1.neg()}; }
+    SV_HD fq2_t dbl() const { return {c0.dbl(), c1.dbl()}; }
+    SV_HD static fq_t mul5(const fq_t& x) {
+        fq_t x4 = x.dbl().dbl();
+        return x4 + x;
+    }
+    // fp2.rs:404-410: c0 = a0 b0 + nr a1 b1, c1 = a0 b1 + a1 b0   (nr = -5)
+    SV_HD fq2_t operator*(const fq2_t& b) const {
+        fq_t v0 = c0 * b.c0, v1 = c1 * b.c1;
+        fq_t s = (c0 + c1) * (b.c0 + b.c1);  // Karatsuba cross term
+        return {v0 - mul5(v1), s - v0 - v1};
+    }
+    // fp2.rs:149-165 (same value)
+    SV_HD fq2_t sqr() const {
+        fq_t a = c0.sqr(), b = c1.sqr(), m = c0 * c1;
+        return {a - mul5(b), m.dbl()};
+    }
+    SV_HD static fq2_t load(const void* p) {
+        const uint8_t* q = (const uint8_t*)p;
+        return {fq_t::load(q), fq_t::load(q + 48)};
+    }
+    SV_HD void store(void* p) const {
+        uint8_t* q = (uint8_t*)p;
+        c0.store(q);
+        c1.store(q + 48);
+    }
+    SV_HD static fq2_t from_raw_words(const uint32_t* w) { return {fq_t::from_raw_words(w), fq_t::from_raw_words(w + 12)}; }
+    SV_HD void to_raw_words(uint32_t* w) const {
+        c0.to_raw_words(w);
+        c1.to_raw_words(w + 12);
+    }
+};
+static_assert(sizeof(fq2_t::mem_t) == 96, "Fq2 memory image");
 
 }  // namespace sv

@@ -135,25 +135,27 @@ static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32
 // ------------------------------------------------------------------------------------------
 // 0. base conversion: Rust `Affine` (x, y Montgomery R = 2^384, infinity flag; stride bytes) -> g1_aff_mem_t
 // ------------------------------------------------------------------------------------------
-__global__ void g1_convert_bases_kernel(const uint8_t* in, size_t stride, size_t n, g1_aff_mem_t* out) {
+template <class F>
+__global__ void convert_bases_kernel(const uint8_t* in, size_t stride, size_t n, aff_mem_t<F>* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = (const uint32_t*)(in + i * stride);  // stride is a multiple of 8 (Rust layout)
-    uint32_t xw[12], yw[12];
+    constexpr int MW = F::MEM_WORDS;
+    uint32_t xw[MW], yw[MW];
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
+    for (int k = 0; k < MW; k++) {
         xw[k] = src[k];
-        yw[k] = src[12 + k];
+        yw[k] = src[MW + k];
     }
-    const uint32_t inf = src[24] & 0xffu;
-    g1_aff_t a;
+    const uint32_t inf = src[2 * MW] & 0xffu;
+    aff_t<F> a;
     if (inf) {
-        a = g1_aff_t::inf();
+        a = aff_t<F>::inf();
     } else {
-        a.x = fq_t::unpack(xw).from_mem_mont();
-        a.y = fq_t::unpack(yw).from_mem_mont();
+        a.x = F::from_raw_words(xw);
+        a.y = F::from_raw_words(yw);
     }
-    g1_store_aff(&out[i], a);
+    store_aff<F>(&out[i], a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,11 +282,12 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* start, uint32_t 
     }
     return lo;
 }
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const g1_aff_mem_t* __restrict__ bases,
+template <class F>
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const aff_mem_t<F>* __restrict__ bases,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ boff,
                                                              const uint32_t* __restrict__ start,
-                                                             g1_xyzz_mem_t* __restrict__ partial, uint32_t nbt, uint32_t S) {
+                                                             xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= start[nbt]) return;
     const uint32_t k = find_bucket(start, nbt, t);
@@ -292,19 +295,20 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const g1_aff_mem_t*
     const uint32_t lo = boff[k] + j * S;
     uint32_t hi = lo + S;
     if (hi > boff[k + 1]) hi = boff[k + 1];
-    g1_xyzz_t acc = g1_xyzz_t::inf();
+    xyzz_t<F> acc = xyzz_t<F>::inf();
     for (uint32_t pos = lo; pos < hi; pos++) {
         const uint32_t e = sorted[pos];
-        const g1_aff_t pt = g1_load_aff(&bases[e & 0x7fffffffu]);
+        const aff_t<F> pt = load_aff<F>(&bases[e & 0x7fffffffu]);
         acc.add_affine(pt, (e >> 31) != 0);
     }
-    g1_store_xyzz(&partial[t], acc);
+    store_xyzz<F>(&partial[t], acc);
 }
-__global__ void __launch_bounds__(256) msm_reduce_kernel(const g1_xyzz_mem_t* __restrict__ in,
+template <class F>
+__global__ void __launch_bounds__(256) msm_reduce_kernel(const xyzz_mem_t<F>* __restrict__ in,
                                                          const uint32_t* __restrict__ in_start,
                                                          const uint32_t* __restrict__ in_cnt,
                                                          const uint32_t* __restrict__ out_start,
-                                                         g1_xyzz_mem_t* __restrict__ out, uint32_t nbt, uint32_t S2) {
+                                                         xyzz_mem_t<F>* __restrict__ out, uint32_t nbt, uint32_t S2) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= out_start[nbt]) return;
     const uint32_t k = find_bucket(out_start, nbt, t);
@@ -313,68 +317,73 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const g1_xyzz_mem_t* __
     uint32_t hi = lo + S2;
     const uint32_t end = in_start[k] + in_cnt[k];
     if (hi > end) hi = end;
-    g1_xyzz_t acc = g1_load_xyzz(&in[lo]);
-    for (uint32_t pos = lo + 1; pos < hi; pos++) acc.add(g1_load_xyzz(&in[pos]));
-    g1_store_xyzz(&out[t], acc);
+    xyzz_t<F> acc = load_xyzz<F>(&in[lo]);
+    for (uint32_t pos = lo + 1; pos < hi; pos++) acc.add(load_xyzz<F>(&in[pos]));
+    store_xyzz<F>(&out[t], acc);
 }
 
 // ------------------------------------------------------------------------------------------
 // 7. bucket reduction: thread (w, j) covers buckets [jL, (j+1)L) of window w
 //    contribution = sum_l (l+1) B_(jL+l) + jL * sum_l B_(jL+l)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const g1_xyzz_mem_t* __restrict__ sums,
+template <class F>
+__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const xyzz_mem_t<F>* __restrict__ sums,
                                                                 const uint32_t* __restrict__ start,
                                                                 const uint32_t* __restrict__ cnt,
-                                                                g1_xyzz_mem_t* __restrict__ contrib, uint32_t nb,
+                                                                xyzz_mem_t<F>* __restrict__ contrib, uint32_t nb,
                                                                 uint32_t L, uint32_t total_threads) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_threads) return;
     const uint32_t J = nb / L;
     const uint32_t w = t / J, j = t % J;
     const uint32_t k0 = w * nb + j * L;
-    g1_xyzz_t run = g1_xyzz_t::inf(), acc = g1_xyzz_t::inf();
+    xyzz_t<F> run = xyzz_t<F>::inf(), acc = xyzz_t<F>::inf();
     for (int l = (int)L - 1; l >= 0; l--) {
         const uint32_t k = k0 + (uint32_t)l;
-        if (cnt[k]) run.add(g1_load_xyzz(&sums[start[k]]));
+        if (cnt[k]) run.add(load_xyzz<F>(&sums[start[k]]));
         acc.add(run);
     }
     if (j) acc.add(run.mul_small(j * L));
-    g1_store_xyzz(&contrib[t], acc);
+    store_xyzz<F>(&contrib[t], acc);
 }
 // 8. one block per window: tree sum of its J contributions
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const g1_xyzz_mem_t* __restrict__ contrib,
-                                                             g1_xyzz_mem_t* __restrict__ wsum, uint32_t J) {
-    __shared__ g1_xyzz_mem_t sh[256];
+template <class F>
+__global__ void __launch_bounds__(256) msm_window_sum_kernel(const xyzz_mem_t<F>* __restrict__ contrib,
+                                                             xyzz_mem_t<F>* __restrict__ wsum, uint32_t J) {
+    // 256 partial sums staged in LDS (G1: 48 KiB; G2 uses 128 threads)
+    extern __shared__ uint4 sh_raw[];
+    xyzz_mem_t<F>* sh = (xyzz_mem_t<F>*)sh_raw;
     const uint32_t w = blockIdx.x;
-    g1_xyzz_t acc = g1_xyzz_t::inf();
-    for (uint32_t j = threadIdx.x; j < J; j += blockDim.x) acc.add(g1_load_xyzz(&contrib[(size_t)w * J + j]));
-    g1_store_xyzz(&sh[threadIdx.x], acc);
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    for (uint32_t j = threadIdx.x; j < J; j += blockDim.x) acc.add(load_xyzz<F>(&contrib[(size_t)w * J + j]));
+    store_xyzz<F>(&sh[threadIdx.x], acc);
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = (int)blockDim.x / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
-            g1_xyzz_t a = g1_load_xyzz(&sh[threadIdx.x]);
-            a.add(g1_load_xyzz(&sh[threadIdx.x + off]));
-            g1_store_xyzz(&sh[threadIdx.x], a);
+            xyzz_t<F> a = load_xyzz<F>(&sh[threadIdx.x]);
+            a.add(load_xyzz<F>(&sh[threadIdx.x + off]));
+            store_xyzz<F>(&sh[threadIdx.x], a);
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) wsum[w] = sh[0];
 }
 // 9. Horner across windows (batched.rs:404-413) and conversion to the reference's Jacobian memory image
-struct alignas(16) g1_jac_out_t {
-    fq_mem_t x, y, z;
-};
-__global__ void msm_final_kernel(const g1_xyzz_mem_t* __restrict__ wsum, g1_jac_out_t* out, int W, int c) {
+template <class F>
+__global__ void msm_final_kernel(const xyzz_mem_t<F>* __restrict__ wsum, jac_mem_t<F>* out, int W, int c) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    g1_xyzz_t total = g1_xyzz_t::inf();
+    xyzz_t<F> total = xyzz_t<F>::inf();
     for (int w = W - 1; w >= 0; w--) {
         for (int d = 0; d < c; d++) total = total.dbl();
-        total.add(g1_load_xyzz(&wsum[w]));
+        total.add(load_xyzz<F>(&wsum[w]));
     }
-    const g1_jac_t j = total.to_jacobian();
-    j.x.to_mem_mont().store(&out->x);
-    j.y.to_mem_mont().store(&out->y);
-    j.z.to_mem_mont().store(&out->z);
+    const jac_t<F> j = total.to_jacobian();
+    uint32_t w[3 * F::MEM_WORDS];
+    j.x.to_raw_words(w);
+    j.y.to_raw_words(w + F::MEM_WORDS);
+    j.z.to_raw_words(w + 2 * F::MEM_WORDS);
+    uint32_t* o = (uint32_t*)out;
+    for (int i = 0; i < 3 * F::MEM_WORDS; i++) o[i] = w[i];
 }
 
 // ------------------------------------------------------------------------------------------
