@@ -88,6 +88,18 @@ void snarkvm_hip_free_bases(snarkvm_hip_bases_t *handle);
 RustError snarkvm_hip_msm_registered(void *out, const snarkvm_hip_bases_t *handle, size_t offset, size_t npoints,
                                      const void *scalars, int scalars_on_device, int window_bits);
 
+/* KZG10-shaped MSM over registered bases: sum over two base ranges [off0, off0+n0) and [off1, off1+n1) with
+ * n0 + n1 consecutive scalars - the plaintext MSM and the hiding MSM of KZG10::commit
+ * (polycommit/kzg10/mod.rs:119,149) in one launch.  scalars_montgomery = 1 fuses `convert_to_bigints`
+ * (kzg10/mod.rs:469-474: Fr::to_bigint per coefficient) into the scalar-read phase. */
+RustError snarkvm_hip_msm_registered_ex(void *out, const snarkvm_hip_bases_t *handle, size_t off0, size_t n0,
+                                        size_t off1, size_t n1, const void *scalars, int scalars_on_device,
+                                        int scalars_montgomery, int window_bits);
+
+/* `From<Projective> for Affine` (curves/src/templates/short_weierstrass_jacobian/affine.rs:331-353) for n
+ * G1Projective (144 B) -> G1Affine (104 B), host buffers. */
+RustError snarkvm_hip_g1_to_affine(void *out_affine, const void *in_projective, size_t n);
+
 /* G2 variable-base MSM (the reference routes G2 through its CPU `standard::msm`,
  * msm/variable_base/{mod.rs:45-47,standard.rs:79-105}; north_star asks for it on the device).
  * `points_with_infinity` is a Rust `[G2Affine]` (x, y in Fq2 = 96 B each, infinity flag; stride 200 B);

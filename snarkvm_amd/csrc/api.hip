@@ -181,7 +181,9 @@ static void write_infinity(void* out) {
 
 // d_bases: converted device bases; d_scalars: device scalars (32 B each); result written to host `out` (144 B)
 template <class F>
-static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits) {
+static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
+                    const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0) {
+    if (n0 > n) n0 = n;
     if (n == 0) {
         write_infinity<F>(out);
         return;
@@ -224,6 +226,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
         dp.c = pl.c;
         dp.W = pl.W;
         dp.n = n;
+        dp.montgomery = scalars_montgomery;
         size_t blocks = (n + 255) / 256;
         if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
@@ -254,8 +257,16 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.boff.as<uint32_t>(), (const uint32_t*)nullptr,
                        c.cnt_a.as<uint32_t>(), nbt, pl.S);
     exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-    hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases, c.sorted.as<uint32_t>(),
-                       c.boff.as<uint32_t>(), c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S);
+    {
+        static const int acc_waves = getenv("SNARKVM_HIP_ACC_WAVES") ? atoi(getenv("SNARKVM_HIP_ACC_WAVES")) : 3;
+        const dim3 grid((unsigned)((T0_max + 255) / 256));
+        if (acc_waves >= 4 && sizeof(typename F::mem_t) == 48)
+            hipLaunchKernelGGL((msm_accumulate_kernel<F, 4>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), c.boff.as<uint32_t>(),
+                               c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S);
+        else
+            hipLaunchKernelGGL((msm_accumulate_kernel<F, 1>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), c.boff.as<uint32_t>(),
+                               c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S);
+    }
     c.phase_end();
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
     c.phase_begin("msm_reduce_partials");
@@ -541,6 +552,40 @@ RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, si
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
     msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits);
+    API_END
+}
+
+RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h, size_t off0, size_t n0, size_t off1, size_t n1,
+                                        const void* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    API_BEGIN
+    if (!h || off0 + n0 > h->n || off1 + n1 > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: range exceeds the registered bases", __LINE__};
+    if (window_bits && (window_bits < 2 || window_bits > 16)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: window_bits must be 0 or 2..16", __LINE__};
+    const size_t n = n0 + n1;
+    const uint4* d_sc = (const uint4*)scalars;
+    if (!scalars_on_device && n) {
+        g_ctx.scalars_tmp.ensure(n * 32);
+        g_ctx.phase_begin("msm_h2d");
+        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+        g_ctx.phase_end();
+        d_sc = g_ctx.scalars_tmp.as<uint4>();
+    }
+    msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery);
+    API_END
+}
+RustError snarkvm_hip_g1_to_affine(void* out_affine, const void* in_projective, size_t n) {
+    API_BEGIN
+    if (n) {
+        dev_buf din, dout;
+        din.ensure(n * 144);
+        dout.ensure(n * 104);
+        HIP_TRY(hipMemcpyAsync(din.p, in_projective, n * 144, hipMemcpyHostToDevice, g_ctx.stream));
+        hipLaunchKernelGGL(g1_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, din.as<uint32_t>(), dout.as<uint32_t>(), n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_affine, dout.p, n * 104, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        (void)hipFree(din.p);
+        (void)hipFree(dout.p);
+    }
     API_END
 }
 

@@ -165,6 +165,7 @@ struct msm_digit_params_t {
     uint32_t bias[10];
     int c, W;
     size_t n;
+    int montgomery;  // scalars are Fr elements in Montgomery form: fuse Fr::to_bigint (kzg10/mod.rs:469-474) into the read
 };
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
                                                          msm_digit_params_t p) {
@@ -180,6 +181,12 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict
         if (threadIdx.x < cnt) {
             const uint4 lo = stage[2 * threadIdx.x], hi = stage[2 * threadIdx.x + 1];
             uint32_t s[11] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u, 0u, 0u};
+            if (p.montgomery) {
+                // a*2^256 read as internal a*2^-5 (see ff.cuh): one Montgomery product by the integer 2^5 gives a
+                fr_t c32 = fr_t::zero();
+                c32.v[0] = 32;
+                (fr_t::unpack(s) * c32).pack(s);
+            }
             uint64_t carry = 0;
 #pragma unroll
             for (int k = 0; k < 10; k++) {
@@ -282,8 +289,11 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* start, uint32_t 
     }
     return lo;
 }
-template <class F>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const aff_mem_t<F>* __restrict__ bases,
+// MINW = minimum waves per SIMD requested from the register allocator (G1: 4 -> <= 128 VGPRs with a few
+// spills vs 3 -> 165 VGPRs; one wave alone issues only every ~5 ticks, see profiles/r01_microbench_*).
+template <class F, int MINW>
+__global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem_t<F>* __restrict__ bases,
+                                                                   const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ boff,
                                                              const uint32_t* __restrict__ start,
@@ -298,7 +308,8 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const aff_mem_t<F>*
     xyzz_t<F> acc = xyzz_t<F>::inf();
     for (uint32_t pos = lo; pos < hi; pos++) {
         const uint32_t e = sorted[pos];
-        const aff_t<F> pt = load_aff<F>(&bases[e & 0x7fffffffu]);
+        const uint32_t idx = e & 0x7fffffffu;  // scalar index; bases come in up to two segments
+        const aff_t<F> pt = load_aff<F>(idx < n0 ? &bases[idx] : &bases1[idx - n0]);
         acc.add_affine(pt, (e >> 31) != 0);
     }
     store_xyzz<F>(&partial[t], acc);
@@ -384,6 +395,32 @@ __global__ void msm_final_kernel(const xyzz_mem_t<F>* __restrict__ wsum, jac_mem
     j.z.to_raw_words(w + 2 * F::MEM_WORDS);
     uint32_t* o = (uint32_t*)out;
     for (int i = 0; i < 3 * F::MEM_WORDS; i++) o[i] = w[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Projective -> Affine (affine.rs:331-353 `From<Projective> for Affine`; batch form projective.rs:172-219)
+// in: Jacobian memory images (144 B), out: Rust G1Affine (104 B).  One Fermat inversion per point.
+// ------------------------------------------------------------------------------------------
+__global__ void g1_to_affine_kernel(const uint32_t* in, uint32_t* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = in + 36 * i;
+    uint32_t* dst = out + 26 * i;
+    const fq_t z = fq_t::from_raw_words(src + 24);
+    if (z.is_zero()) {  // Affine::zero() = (0, 1, infinity) (affine.rs:55-60)
+        for (int k = 0; k < 12; k++) dst[k] = 0;
+        fq_t::one().to_raw_words(dst + 12);
+        dst[24] = 1;
+        dst[25] = 0;
+        return;
+    }
+    const fq_t x = fq_t::from_raw_words(src), y = fq_t::from_raw_words(src + 12);
+    const fq_t zi = z.inverse();
+    const fq_t zi2 = zi.sqr();
+    (x * zi2).to_raw_words(dst);
+    (y * (zi2 * zi)).to_raw_words(dst + 12);
+    dst[24] = 0;
+    dst[25] = 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -63,3 +63,20 @@ class RegisteredBases:
             self.close()
         except Exception:
             pass
+
+
+def msm_g2(bases, scalars):
+    """G2 variable-base MSM on the device (extension: the reference sends G2 to its CPU `standard::msm`,
+    variable_base/mod.rs:45-47).  bases: G2_AFFINE array (200 B stride); returns a G2_PROJECTIVE record."""
+    from .layout import G2_AFFINE, G2_PROJECTIVE
+
+    bases = np.ascontiguousarray(bases, dtype=G2_AFFINE).reshape(-1)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = scalars.shape[0]
+    if n > bases.shape[0]:
+        raise ValueError(f"length mismatch {bases.shape[0]} points < {n} scalars")
+    out = np.zeros(1, dtype=G2_PROJECTIVE)
+    err = _lib.lib().snarkvm_hip_msm_g2(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(n),
+                                        ctypes.c_void_p(scalars.ctypes.data), ctypes.c_size_t(G2_AFFINE.itemsize))
+    _lib.check(err)
+    return out

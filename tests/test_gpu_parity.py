@@ -257,3 +257,65 @@ def test_msm_full_size_closed_form(lg):
         assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(host_bases, sc)), want)
         assert util.affine_equal(oracle.g1_to_affine(oracle.g1_msm(host_bases, sc, oracle.MSM_BATCHED)), want)
     rb.close()
+
+
+# ------------------------------------------------------------------------------------------ G2
+def _g2_bases(golden, n):
+    from oracle import cpu as o
+
+    g2 = golden["constants"]["g2"]
+    gen = np.zeros(1, dtype=o.G2_AFFINE)
+    gen["x"] = g2["G2_GENERATOR_X_C0_MONT"] + g2["G2_GENERATOR_X_C1_MONT"]
+    gen["y"] = g2["G2_GENERATOR_Y_C0_MONT"] + g2["G2_GENERATOR_Y_C1_MONT"]
+    proj = np.zeros(n, dtype=o.G2_PROJECTIVE)
+    for i in range(n):
+        proj[i] = o.g2_mul(gen, util.limbs(3 * i + 1, 4))[0]
+    return o.g2_to_affine(proj)
+
+
+@pytest.mark.parametrize("n", [1, 7, 33, 100, 1000, 5000])
+def test_g2_msm_vs_oracle_standard_msm(golden, n):
+    """G2 goes through `standard::msm` in the reference (variable_base/mod.rs:45-47, standard.rs:79-105)."""
+    from snarkvm_amd.msm import msm_g2
+
+    bases = _g2_bases(golden, n)
+    sc = synthetic.random_fr_integers(n, 800 + n)
+    if n >= 33:
+        sc[1] = 0
+        sc[2] = [1, 0, 0, 0]  # scalar == 1 takes the dedicated branch of standard.rs:48-53
+        bases[5] = bases[4]  # duplicate base
+        bases[6]["infinity"] = 1
+    got = oracle.g2_to_affine(msm_g2(bases, sc))
+    want = oracle.g2_to_affine(oracle.g2_msm(bases, sc, oracle.MSM_STANDARD))
+    assert got.tobytes() == want.tobytes()
+
+
+# ------------------------------------------------------------------------------------------ KZG10 commit
+def test_kzg10_commit_matches_reference_formula(golden):
+    """KZG10::commit (polycommit/kzg10/mod.rs:98-156) = msm(powers[lz..], to_bigint(coeffs[lz..])) + msm(gamma powers,
+    to_bigint(blinding)); checked against the oracle's CPU MSMs + projective addition, after to_affine."""
+    from snarkvm_amd import kzg10
+
+    n = 3000
+    powers_g = _srs(golden, n)                                   # real SRS powers of beta (tiled)
+    gamma_g = oracle.g1_gen_bases(util.g1_generator_affine(), 11, 8)  # stand-in for powers_of_beta_times_gamma_g
+    pw = kzg10.Powers(powers_g, gamma_g)
+    coeffs = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 4242))
+    coeffs[:37] = 0                                              # leading zeros are skipped (mod.rs:455-467)
+    coeffs[100] = 0
+    blind = oracle.fr_op("from_bigint", synthetic.random_fr_integers(3, 99))
+    for hiding in (None, 2):
+        comm, rand = kzg10.KZG10.commit(pw, coeffs, hiding, (lambda k: blind[:k]) if hiding is not None else None)
+        want = oracle.g1_msm(powers_g[37:], oracle.fr_op("to_bigint", coeffs[37:]), oracle.MSM_BATCHED)
+        if hiding is not None:
+            assert rand.blinding_polynomial.shape[0] == hiding + 1
+            want = oracle.g1_add(want, oracle.g1_msm(gamma_g, oracle.fr_op("to_bigint", blind[: hiding + 1]), oracle.MSM_BATCHED))
+        assert util.affine_equal(oracle.g1_to_affine(comm), oracle.g1_to_affine(want))
+        # device-side `From<Projective> for Affine` agrees with the oracle's normalisation
+        assert util.affine_equal(kzg10.to_affine(comm), oracle.g1_to_affine(want))
+    # zero polynomial and too-large degree
+    z, _ = kzg10.KZG10.commit(pw, np.zeros((0, 4), dtype=np.uint64))
+    assert kzg10.to_affine(z)["infinity"][0] == 1
+    with pytest.raises(kzg10.PCError):
+        kzg10.KZG10.commit(pw, np.zeros((n + 1, 4), dtype=np.uint64) + 1)
+    pw.close()
