@@ -201,7 +201,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     c.counts.ensure(ncounts * 4);
     c.offsets.ensure(ncounts * 4);
     c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
-    c.sorted.ensure(E_max * 4);
+    c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * 4);
     c.boff.ensure(((size_t)nbt + 1) * 4);
     c.cnt_a.ensure(((size_t)nbt + 1) * 4);
     c.cnt_b.ensure(((size_t)nbt + 1) * 4);
@@ -232,7 +232,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
     }
     c.phase_end();
-    // 2.-4. counting sort by (window, bucket)
+    // 2.-4. counting sort by (window, bucket), chunk-major layout
     msm_sort_params_t sp;
     sp.n = n;
     sp.chunk = pl.chunk;
@@ -240,32 +240,34 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     sp.nb = pl.nb;
     sp.c = pl.c;
     const size_t lds = (size_t)pl.nb * 4;
+    uint32_t* rank = c.counts.as<uint32_t>();      // counts, turned into ranks in place
+    uint32_t* loc_off = c.offsets.as<uint32_t>();  // offset of each bucket inside its (window, chunk) region
+    uint32_t* bsize = c.boff.as<uint32_t>();       // bucket sizes
     c.phase_begin("msm_histogram");
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), c.counts.as<uint32_t>(), sp);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), rank, sp);
     c.phase_end();
-    c.phase_begin("msm_scan");
-    exclusive_scan_u32(st, c.counts.as<uint32_t>(), c.offsets.as<uint32_t>(), ncounts, c.scan_tmp.as<uint32_t>());
-    hipLaunchKernelGGL(msm_bucket_offsets_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.offsets.as<uint32_t>(),
-                       c.counts.as<uint32_t>(), c.boff.as<uint32_t>(), nbt, pl.nchunks);
+    c.phase_begin("msm_bucket_rank");
+    hipLaunchKernelGGL(msm_bucket_rank_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, rank, bsize, pl.nb, pl.nchunks, nbt);
     c.phase_end();
     c.phase_begin("msm_scatter");
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), c.offsets.as<uint32_t>(),
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds + 4096, st, c.digits.as<uint16_t>(), rank, bsize, loc_off,
                        c.sorted.as<uint32_t>(), sp);
     c.phase_end();
     // 5. accumulate
     c.phase_begin("msm_accumulate");
-    hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.boff.as<uint32_t>(), (const uint32_t*)nullptr,
-                       c.cnt_a.as<uint32_t>(), nbt, pl.S);
+    hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
     exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
     {
         static const int acc_waves = getenv("SNARKVM_HIP_ACC_WAVES") ? atoi(getenv("SNARKVM_HIP_ACC_WAVES")) : 3;
         const dim3 grid((unsigned)((T0_max + 255) / 256));
         if (acc_waves >= 4 && sizeof(typename F::mem_t) == 48)
-            hipLaunchKernelGGL((msm_accumulate_kernel<F, 4>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), c.boff.as<uint32_t>(),
-                               c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S);
+            hipLaunchKernelGGL((msm_accumulate_kernel<F, 4>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
+                               c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
+                               pl.nb, pl.nchunks, pl.chunk);
         else
-            hipLaunchKernelGGL((msm_accumulate_kernel<F, 1>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), c.boff.as<uint32_t>(),
-                               c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S);
+            hipLaunchKernelGGL((msm_accumulate_kernel<F, 1>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
+                               c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
+                               pl.nb, pl.nchunks, pl.chunk);
     }
     c.phase_end();
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
@@ -277,7 +279,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     for (int r = 0; r < pl.rounds; r++) {
         size_t T_out_max = T_in_max / pl.S2 + nbt + 1;
         if (T_out_max > T1_max) T_out_max = T1_max;  // both ping-pong buffers hold >= T1_max partials
-        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)nullptr, cnt_in, cnt_out, nbt, pl.S2);
+        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, cnt_in, cnt_out, nbt, pl.S2);
         exclusive_scan_u32(st, cnt_out, start_out, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
         hipLaunchKernelGGL((msm_reduce_kernel<F>), dim3((unsigned)((T_out_max + 255) / 256)), dim3(256), 0, st, pin, start_in, cnt_in, start_out, pout,
                            nbt, pl.S2);

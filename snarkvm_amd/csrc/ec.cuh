@@ -27,6 +27,22 @@ struct aff_t {
 template <class F>
 struct jac_t {
     F x, y, z;
+    SV_HD bool is_inf() const { return z.is_zero(); }
+    // projective.rs:302-339 (double_in_place, a == 0 branch): 2M + 5S, the cheapest doubling for long chains
+    SV_HD jac_t dbl() const {
+        if (is_inf()) return *this;
+        F a = x.sqr();
+        F b = y.sqr();
+        F c = b.sqr();
+        F d = ((x + b).sqr() - a - c).dbl();
+        F e = a.dbl() + a;
+        F f = e.sqr();
+        jac_t r;
+        r.z = (y * z).dbl();
+        r.x = f - d.dbl();
+        r.y = e * (d - r.x) - c.dbl().dbl().dbl();
+        return r;
+    }
 };
 
 template <class F>
@@ -143,6 +159,12 @@ struct xyzz_t {
     SV_HD jac_t<F> to_jacobian() const {
         if (is_inf()) return {F::zero(), F::one(), F::zero()};
         return {x * zz.sqr(), y * zzz.sqr(), zzz};
+    }
+    // Jacobian (X, Y, Z) -> XYZZ: zz = Z^2, zzz = Z^3
+    SV_HD static xyzz_t from_jacobian(const jac_t<F>& j) {
+        if (j.is_inf()) return inf();
+        F zz = j.z.sqr();
+        return {j.x, j.y, zz, zz * j.z};
     }
 };
 

@@ -13,8 +13,9 @@
 //               (s' = s + sum_w 2^(c-1+cw); digit_w = ((s' >> cw) & (2^c-1)) - 2^(c-1)), written as u16
 //               [W][n].  HBM-bound: 32n B read + 2Wn B written.
 //   2 histogram per (chunk, window) workgroup: LDS histogram of 2^(c-1) bucket counters, no global atomics.
-//   3 scan      exclusive scan over [window][bucket][chunk] -> scatter offsets.
-//   4 scatter   per (chunk, window): LDS cursors; writes point index | sign<<31 grouped by bucket.
+//   3 rank      per bucket: exclusive prefix of its counts over the chunks (-> rank of each chunk's run) + size.
+//   4 scatter   per (chunk, window): LDS scan + cursors; writes point index | sign<<31 grouped by bucket into the
+//               workgroup's private region (chunk-major layout: a bucket's entries are nchunks short runs).
 //   5 accumulate  each bucket gets ceil(size/S) threads; a thread adds <= S points (gathered 96-byte
 //               affine bases, XYZZ mixed addition) and writes a partial sum.  Balanced for any scalar
 //               distribution; ALU-bound (~10 Fq multiplications per point).
@@ -214,6 +215,27 @@ struct msm_sort_params_t {
     uint32_t chunk, nchunks, nb;
     int c;
 };
+// Visit the digits of scalars [lo, hi) of one window; 8 digits per 16-byte load when the rows are 16-byte aligned.
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ d, size_t n, size_t lo, size_t hi, Fn fn) {
+    if ((n & 7) == 0 && (lo & 7) == 0 && ((hi - lo) & 7) == 0) {
+        const uint4* d4 = (const uint4*)(d + lo);
+        const size_t nvec = (hi - lo) >> 3;
+        for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+            const uint4 q = d4[v];
+            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+            const size_t i = lo + (v << 3);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                fn(wds[k] & 0xffffu, i + 2 * k);
+                fn(wds[k] >> 16, i + 2 * k + 1);
+            }
+        }
+    } else {
+        for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) fn((uint32_t)d[i], i);
+    }
+}
+// counts[w][chunk][b] (contiguous per workgroup: no write amplification)
 __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts,
                                                         msm_sort_params_t p) {
     extern __shared__ uint32_t hist[];
@@ -223,59 +245,95 @@ __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restri
     const size_t lo = (size_t)chunk * p.chunk;
     const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
     const int half = 1 << (p.c - 1);
-    const uint16_t* d = digits + (size_t)w * p.n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int v = (int)d[i] - half;
+    for_each_digit(digits + (size_t)w * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
+        const int v = (int)u - half;
         if (v != 0) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
+    });
+    __syncthreads();
+    uint32_t* dst = counts + ((size_t)w * p.nchunks + chunk) * p.nb;
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) dst[b] = hist[b];
+}
+// Per bucket k = (w, b): turn the per-chunk counts into ranks (exclusive prefix over chunks, in place) and the
+// bucket size.  Threads adjacent in b -> coalesced.
+__global__ void msm_bucket_rank_kernel(uint32_t* __restrict__ counts_to_rank, uint32_t* __restrict__ size, uint32_t nb,
+                                       uint32_t nchunks, uint32_t nbt) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nbt) return;
+    if (k == nbt) {
+        size[k] = 0;
+        return;
+    }
+    const uint32_t w = k / nb, b = k - w * nb;
+    uint32_t run = 0;
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        const size_t idx = ((size_t)w * nchunks + ch) * nb + b;
+        const uint32_t c = counts_to_rank[idx];
+        counts_to_rank[idx] = run;
+        run += c;
+    }
+    size[k] = run;
+}
+// Scatter into the workgroup's PRIVATE region sorted[(w*nchunks + chunk)*chunk ...], grouped by bucket:
+// all partial-line writes of a region come from one workgroup, so they merge in its L2 (the bucket-major layout
+// measured 8x write amplification, profiles/r01_rocprofv3_pmc_hbm_bytes.txt).  loc_off[w][chunk][b] = offset of
+// bucket b inside the region.
+__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
+                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ size,
+                                                           uint32_t* __restrict__ loc_off, uint32_t* __restrict__ sorted,
+                                                           msm_sort_params_t p) {
+    extern __shared__ uint32_t cursor[];  // nb counters followed by 1024 scan slots
+    uint32_t* part = cursor + p.nb;
+    const uint32_t chunk = blockIdx.x, w = blockIdx.y;
+    const size_t row = ((size_t)w * p.nchunks + chunk) * p.nb;
+    // this chunk's count per bucket = next rank - rank
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) {
+        const uint32_t nxt = (chunk + 1 < p.nchunks) ? rank[row + p.nb + b] : size[(size_t)w * p.nb + b];
+        cursor[b] = nxt - rank[row + b];
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x)
-        counts[((size_t)w * p.nb + b) * p.nchunks + chunk] = hist[b];
-}
-__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
-                                                           const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ sorted, msm_sort_params_t p) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t chunk = blockIdx.x, w = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x)
-        cursor[b] = offsets[((size_t)w * p.nb + b) * p.nchunks + chunk];
+    // exclusive scan over the nb counters: per-thread segments + Hillis-Steele over the 1024 segment sums
+    const uint32_t seg = (p.nb + blockDim.x - 1) / blockDim.x;
+    const uint32_t b0 = threadIdx.x * seg;
+    uint32_t s = 0;
+    for (uint32_t b = b0; b < b0 + seg && b < p.nb; b++) s += cursor[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+        const uint32_t t = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t b = b0; b < b0 + seg && b < p.nb; b++) {
+        const uint32_t c = cursor[b];
+        cursor[b] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) loc_off[row + b] = cursor[b];
     __syncthreads();
     const size_t lo = (size_t)chunk * p.chunk;
     const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
     const int half = 1 << (p.c - 1);
-    const uint16_t* d = digits + (size_t)w * p.n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int v = (int)d[i] - half;
+    uint32_t* region = sorted + ((size_t)w * p.nchunks + chunk) * p.chunk;
+    for_each_digit(digits + (size_t)w * p.n, p.n, lo, hi, [&](uint32_t u, size_t i) {
+        const int v = (int)u - half;
         if (v != 0) {
             const uint32_t pos = atomicAdd(&cursor[(v < 0 ? -v : v) - 1], 1u);
-            sorted[pos] = (uint32_t)i | (v < 0 ? 0x80000000u : 0u);
+            region[pos] = (uint32_t)i | (v < 0 ? 0x80000000u : 0u);
         }
-    }
-}
-// boff[k] = first sorted position of bucket k (k = w*nb + b); boff[nbt] = number of sorted entries
-__global__ void msm_bucket_offsets_kernel(const uint32_t* offsets, const uint32_t* counts, uint32_t* boff, uint32_t nbt,
-                                          uint32_t nchunks) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nbt) boff[k] = offsets[(size_t)k * nchunks];
-    if (k == nbt) {
-        const size_t last = (size_t)nbt * nchunks - 1;
-        boff[nbt] = offsets[last] + counts[last];
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------
 // 5./6. accumulate + reduce rounds
 // ------------------------------------------------------------------------------------------
-// cnt_out[k] = ceil(cnt_in[k] / S); level 0 takes its input counts from bucket offsets
-__global__ void msm_alloc_kernel(const uint32_t* boff, const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t nbt, uint32_t S) {
+// cnt_out[k] = ceil(cnt_in[k] / S)   (level 0: cnt_in = bucket sizes)
+__global__ void msm_alloc_kernel(const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t nbt, uint32_t S) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > nbt) return;
-    if (k == nbt) {
-        cnt_out[k] = 0;
-        return;
-    }
-    const uint32_t c = boff ? (boff[k + 1] - boff[k]) : cnt_in[k];
-    cnt_out[k] = (c + S - 1) / S;
+    cnt_out[k] = (k == nbt) ? 0u : (cnt_in[k] + S - 1) / S;
 }
 // largest k in [0, nbt) with start[k] <= t   (start is non-decreasing, start[nbt] = total > t)
 __device__ __forceinline__ uint32_t find_bucket(const uint32_t* start, uint32_t nbt, uint32_t t) {
@@ -294,20 +352,44 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* start, uint32_t 
 template <class F, int MINW>
 __global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem_t<F>* __restrict__ bases,
                                                                    const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
-                                                             const uint32_t* __restrict__ sorted,
-                                                             const uint32_t* __restrict__ boff,
-                                                             const uint32_t* __restrict__ start,
-                                                             xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S) {
+                                                                   const uint32_t* __restrict__ sorted,
+                                                                   const uint32_t* __restrict__ rank,
+                                                                   const uint32_t* __restrict__ loc_off,
+                                                                   const uint32_t* __restrict__ size,
+                                                                   const uint32_t* __restrict__ start,
+                                                                   xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S,
+                                                                   uint32_t nb, uint32_t nchunks, uint32_t chunk) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= start[nbt]) return;
     const uint32_t k = find_bucket(start, nbt, t);
     const uint32_t j = t - start[k];
-    const uint32_t lo = boff[k] + j * S;
-    uint32_t hi = lo + S;
-    if (hi > boff[k + 1]) hi = boff[k + 1];
+    const uint32_t w = k / nb, b = k - w * nb;
+    const uint32_t sz = size[k];
+    uint32_t r = j * S;  // rank range [r, r1) inside bucket k
+    uint32_t r1 = r + S;
+    if (r1 > sz) r1 = sz;
+    // the bucket's entries live in nchunks runs: run ch covers ranks [rank[w][ch][b], rank[w][ch+1][b])
+    const size_t col = (size_t)w * nchunks * nb + b;
+    uint32_t lo = 0, hi = nchunks;  // largest ch with rank(ch) <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rank[col + (size_t)mid * nb] <= r)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    uint32_t ch = lo;
+    uint32_t re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
+    size_t phys = ((size_t)w * nchunks + ch) * chunk + loc_off[col + (size_t)ch * nb] + (r - rank[col + (size_t)ch * nb]);
     xyzz_t<F> acc = xyzz_t<F>::inf();
-    for (uint32_t pos = lo; pos < hi; pos++) {
-        const uint32_t e = sorted[pos];
+    while (r < r1) {
+        while (r == re) {  // run exhausted: next non-empty run (ranks are contiguous across runs)
+            ch++;
+            re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
+            phys = ((size_t)w * nchunks + ch) * chunk + loc_off[col + (size_t)ch * nb];
+        }
+        const uint32_t e = sorted[phys++];
+        r++;
         const uint32_t idx = e & 0x7fffffffu;  // scalar index; bases come in up to two segments
         const aff_t<F> pt = load_aff<F>(idx < n0 ? &bases[idx] : &bases1[idx - n0]);
         acc.add_affine(pt, (e >> 31) != 0);
@@ -383,12 +465,14 @@ __global__ void __launch_bounds__(256) msm_window_sum_kernel(const xyzz_mem_t<F>
 template <class F>
 __global__ void msm_final_kernel(const xyzz_mem_t<F>* __restrict__ wsum, jac_mem_t<F>* out, int W, int c) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    xyzz_t<F> total = xyzz_t<F>::inf();
+    // total = total * 2^c + S_w: the c doublings run in Jacobian coordinates (2M + 5S each)
+    jac_t<F> j = {F::zero(), F::one(), F::zero()};
     for (int w = W - 1; w >= 0; w--) {
-        for (int d = 0; d < c; d++) total = total.dbl();
+        for (int d = 0; d < c; d++) j = j.dbl();
+        xyzz_t<F> total = xyzz_t<F>::from_jacobian(j);
         total.add(load_xyzz<F>(&wsum[w]));
+        j = total.to_jacobian();
     }
-    const jac_t<F> j = total.to_jacobian();
     uint32_t w[3 * F::MEM_WORDS];
     j.x.to_raw_words(w);
     j.y.to_raw_words(w + F::MEM_WORDS);
