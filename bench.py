@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--lg-ntt", type=int, default=24)
     ap.add_argument("--ntt-steps", type=int, default=10)
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--tables", type=int, default=4, help="precomputed 2^(256/tables*j) multiples of the registered bases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lg-msm", type=int, default=18)
     ap.add_argument("--cpu-lg-ntt", type=int, default=22)
@@ -68,7 +69,7 @@ def main():
     bases_dev = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     _lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(bases_dev.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(n)))
-    rb = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n)
+    rb = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=args.tables)
     del bases_dev
     scalars = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE + rank)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).cuda()
@@ -166,7 +167,8 @@ def main():
     if rank == 0:
         acc_ms = phase_ms.get("msm_accumulate", 0.0)
         dig_ms = phase_ms.get("msm_digits", 0.0)
-        W = (254 + (args.window_bits or 16) - 1) // (args.window_bits or 16)
+        cbits = args.window_bits or 16
+        W = (256 // cbits) if args.tables > 1 else (254 + cbits - 1) // cbits  # digit rows per scalar
         out = {
             "metric": "BLS12-377 G1 MSM scalar-point pairs/sec (+ Fr NTT elements/sec in ntt_*)",
             "value": pairs_per_s,
@@ -182,7 +184,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"G1 Pippenger MSM 2^{args.lg_msm} (BASELINE.json configs[1]), bases (i+1)G registered in HBM, "
                                    f"uniform scalars in HBM; independent instance per GPU",
-                       "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto"},
+                       "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables},
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
             "ntt_ms_per_transform": ntt_dt / args.ntt_steps * 1e3,

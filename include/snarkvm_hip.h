@@ -80,6 +80,12 @@ RustError snarkvm_hip_ntt_device(void *d_inout, uint32_t lg_domain_size, int ntt
 typedef struct snarkvm_hip_bases snarkvm_hip_bases_t;
 RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t **handle, const void *points, size_t npoints,
                                      size_t ffi_affine_sz, int on_device);
+/* Same, additionally precomputing `tables` (1, 2, 4, 8 or 16) multiples 2^(256/tables * j) * P_i of every base
+ * (one-time cost; tables x 96 B per point of HBM).  An MSM over such a handle needs only 256/(tables*c) bucket
+ * windows: the serial Horner tail and the bucket reduction shrink by `tables` while the result stays the same
+ * group element. */
+RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t **handle, const void *points, size_t npoints,
+                                            size_t ffi_affine_sz, int on_device, int tables);
 void snarkvm_hip_free_bases(snarkvm_hip_bases_t *handle);
 
 /* MSM over registered bases [offset, offset + npoints).  `scalars` in host (scalars_on_device = 0) or

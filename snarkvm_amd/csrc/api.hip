@@ -118,6 +118,7 @@ struct context_t {
         tb.size_inv = take(32);
         tb.consts = take(8);
         HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         hipLaunchKernelGGL(ntt_setup_consts, dim3(1), dim3(64), 0, stream, tb);
@@ -162,8 +163,9 @@ struct context_t {
 static context_t g_ctx;
 
 struct snarkvm_hip_bases {
-    g1_aff_mem_t* d = nullptr;
+    g1_aff_mem_t* d = nullptr;  // tables * n entries: table j at d + j * n holds 2^(256 / tables * j) * P_i
     size_t n = 0;
+    int tables = 1;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -182,18 +184,20 @@ static void write_infinity(void* out) {
 // d_bases: converted device bases; d_scalars: device scalars (32 B each); result written to host `out` (144 B)
 template <class F>
 static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
-                    const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0) {
+                    const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
+                    size_t table_stride = 0) {
     if (n0 > n) n0 = n;
     if (n == 0) {
         write_infinity<F>(out);
         return;
     }
     if (n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: npoints must be < 2^31", __LINE__};
-    const msm_plan_t pl = msm_make_plan(n, window_bits);
-    if ((size_t)pl.W * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: W * npoints must be < 2^32", __LINE__};
+    const msm_plan_t pl = msm_make_plan(n, window_bits, tables);
+    if ((size_t)pl.Wd * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: windows * npoints must be < 2^32", __LINE__};
+    if ((size_t)pl.J * n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: tables * npoints must be < 2^31", __LINE__};
     hipStream_t st = c.stream;
     constexpr unsigned WS_THREADS = sizeof(xyzz_mem_t<F>) > 192 ? 128 : 256;  // window-sum LDS tile <= 48 KiB
-    const size_t E_max = (size_t)pl.W * n;
+    const size_t E_max = (size_t)pl.Wd * n;
     const uint32_t nbt = pl.nbt;
 
     c.digits.ensure(E_max * sizeof(uint16_t));
@@ -201,7 +205,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     c.counts.ensure(ncounts * 4);
     c.offsets.ensure(ncounts * 4);
     c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
-    c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * 4);
+    c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * pl.J * 4);
     c.boff.ensure(((size_t)nbt + 1) * 4);
     c.cnt_a.ensure(((size_t)nbt + 1) * 4);
     c.cnt_b.ensure(((size_t)nbt + 1) * 4);
@@ -224,7 +228,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
         msm_digit_params_t dp;
         memcpy(dp.bias, pl.bias, sizeof dp.bias);
         dp.c = pl.c;
-        dp.W = pl.W;
+        dp.W = pl.Wd;
         dp.n = n;
         dp.montgomery = scalars_montgomery;
         size_t blocks = (n + 255) / 256;
@@ -239,6 +243,8 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     sp.nchunks = pl.nchunks;
     sp.nb = pl.nb;
     sp.c = pl.c;
+    sp.W = pl.W;
+    sp.J = pl.J;
     const size_t lds = (size_t)pl.nb * 4;
     uint32_t* rank = c.counts.as<uint32_t>();      // counts, turned into ranks in place
     uint32_t* loc_off = c.offsets.as<uint32_t>();  // offset of each bucket inside its (window, chunk) region
@@ -263,11 +269,11 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
         if (acc_waves >= 4 && sizeof(typename F::mem_t) == 48)
             hipLaunchKernelGGL((msm_accumulate_kernel<F, 4>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
                                c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
-                               pl.nb, pl.nchunks, pl.chunk);
+                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride);
         else
             hipLaunchKernelGGL((msm_accumulate_kernel<F, 1>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
                                c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
-                               pl.nb, pl.nchunks, pl.chunk);
+                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride);
     }
     c.phase_end();
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
@@ -372,6 +378,15 @@ SV_HD void field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out)
         case 5: r = x.neg(); break;
         case 6: r = F::unpack(a).int_to_mont(); break;                  // from_bigint: integer -> Montgomery
         case 7: (x.mont_to_int()).pack(out); return;                    // to_bigint: Montgomery -> integer
+        case 8: {  // lazy-arithmetic chain used by the NTT butterflies (Fr only): ((a + b) - b + 2r) * b == a * b
+            if (F::N != 9) { r = x * y; break; }
+            uint32_t kp[F::N];
+            F::mod_shl(kp, 1);
+            F t = F::add_lazy(x, y);         // < 2r
+            t = F::sub_lazy(t, y, kp);       // < 4r
+            r = t.mul_lazy(y).reduce_lazy();
+            break;
+        }
         default: r = F::zero();
     }
     r.to_mem_mont().pack(out);
@@ -510,18 +525,24 @@ RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void*
 }
 RustError snarkvm_hip_msm_g2(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
     API_BEGIN
+#ifdef SV_NO_G2  // development builds only (python -m snarkvm_amd.build --fast): skips the Fq2 kernel instantiations
+    throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
+#else
     msm_host<fq2_t>(g_ctx, out, points, npoints, scalars, ffi_affine_sz);
+#endif
     API_END
 }
 
-RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
-    API_BEGIN
+static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables) {
     if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
     if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
+    if (tables != 1 && tables != 2 && tables != 4 && tables != 8 && tables != 16)
+        throw hip_failure{hipErrorInvalidValue, "register_bases: tables must be 1, 2, 4, 8 or 16", __LINE__};
     snarkvm_hip_bases* h = new snarkvm_hip_bases();
     h->n = npoints;
+    h->tables = tables;
     if (npoints) {
-        HIP_TRY(hipMalloc((void**)&h->d, npoints * sizeof(g1_aff_mem_t)));
+        HIP_TRY(hipMalloc((void**)&h->d, (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
         const uint8_t* src = (const uint8_t*)points;
         if (!on_device) {
             g_ctx.bases_tmp.ensure(npoints * ffi_affine_sz);
@@ -529,9 +550,23 @@ RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* p
             src = g_ctx.bases_tmp.as<uint8_t>();
         }
         convert_bases<fq_t>(g_ctx, src, ffi_affine_sz, npoints, h->d);
+        for (int j = 1; j < tables; j++)
+            hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, g_ctx.stream,
+                               h->d + (size_t)(j - 1) * npoints, h->d + (size_t)j * npoints, npoints, 256 / tables);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     }
     *handle = h;
+}
+RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
+    API_BEGIN
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, 1);
+    API_END
+}
+RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
+                                            int tables) {
+    API_BEGIN
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables);
     API_END
 }
 void snarkvm_hip_free_bases(snarkvm_hip_bases_t* h) {
@@ -553,7 +588,7 @@ RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, si
         g_ctx.phase_end();
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
-    msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits);
+    msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits, nullptr, ~(size_t)0, 0, h->tables, h->n);
     API_END
 }
 
@@ -571,7 +606,7 @@ RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h,
         g_ctx.phase_end();
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
-    msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery);
+    msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery, h->tables, h->n);
     API_END
 }
 RustError snarkvm_hip_g1_to_affine(void* out_affine, const void* in_projective, size_t n) {

@@ -281,6 +281,69 @@ struct Fp {
     SV_HD static Fp from_raw_words(const uint32_t* w) { return unpack(w).from_mem_mont(); }
     SV_HD void to_raw_words(uint32_t* w) const { to_mem_mont().pack(w); }
 
+    // ---- lazy arithmetic (NTT butterflies).  Valid only for a field with spare bits in 29N (Fr: 261 - 253 = 8):
+    // operands are arbitrary integers < 2^(29N) with normalised limbs, results likewise; nothing is reduced mod p
+    // until reduce_lazy().  Bounds are tracked by the caller (ntt.cuh).
+    SV_HD static Fp add_lazy(const Fp& a, const Fp& b) {  // a + b  (must stay < 2^(29N))
+        Fp r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint32_t t = a.v[i] + b.v[i] + c;
+            r.v[i] = (i == N - 1) ? t : (t & LIMB_MASK);
+            c = t >> 29;
+        }
+        return r;
+    }
+    SV_HD static Fp sub_lazy(const Fp& a, const Fp& b, const uint32_t* kp) {  // a - b + kp, kp = k*p >= b
+        Fp r;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int32_t x = (int32_t)(a.v[i] - b.v[i] + kp[i]) + c;
+            r.v[i] = (i == N - 1) ? (uint32_t)x : ((uint32_t)x & LIMB_MASK);
+            c = x >> 29;
+        }
+        return r;
+    }
+    // kp = 2^s * p as normalised limbs (s < 29, 2^s * p < 2^(29N)); s is wave-uniform, so this is scalar-unit work
+    SV_HD static void mod_shl(uint32_t* kp, int s) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t below = (i > 0) ? (P::MOD[i > 0 ? i - 1 : 0] >> (29 - s)) : 0u;
+            kp[i] = ((P::MOD[i] << s) | below) & LIMB_MASK;
+        }
+    }
+    // Montgomery product without the final conditional subtraction: for a < 2^(29N), b < p the result is < 2p
+    SV_HD Fp mul_lazy(const Fp& b) const {
+        uint32_t m[N];
+        Fp r;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < N) acc += (uint64_t)v[i] * b.v[j];
+            }
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 1 && j < N && i < k) acc += (uint64_t)m[i] * P::MOD[j];
+            }
+            if (k < N) {
+                m[k] = (0u - (uint32_t)acc) & LIMB_MASK;
+                acc += m[k];
+            } else {
+                r.v[k - N] = (k == 2 * N - 1) ? (uint32_t)acc : ((uint32_t)acc & LIMB_MASK);
+            }
+            acc >>= 29;
+        }
+        return r;
+    }
+    // value < 2p with normalised limbs -> canonical
+    SV_HD Fp reduce_lazy() const { return cond_sub(v); }
+
     // ---- conversions between representations
     // canonical integer -> internal Montgomery, and back
     SV_HD Fp int_to_mont() const { return *this * from_table(P::R2); }

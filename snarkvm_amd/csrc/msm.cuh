@@ -31,7 +31,10 @@ namespace sv {
 
 struct msm_plan_t {
     size_t n;
-    int c, W;
+    int c;             // window width (bits)
+    int W;             // bucket windows (Horner chain = c * (W - 1) doublings)
+    int J;             // precomputed base tables: table j holds 2^(c*W*j) * P, so digit row j*W + w lands in window w
+    int Wd;            // digit rows per scalar = W * J
     uint32_t nb;       // buckets per window = 2^(c-1)
     uint32_t nbt;      // W * nb
     uint32_t chunk;    // scalars per histogram chunk
@@ -50,27 +53,41 @@ static inline int msm_pick_c(size_t n) {
     if (c > 16) c = 16;
     return c;
 }
-static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0) {
+// tables == 1: W = ceil(254 / c) windows.  tables == J > 1 (registered bases with precomputed 2^(256/J * j) multiples):
+// the 256 scalar bits split into J parts of 256/J bits; c must divide the part width.
+static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables = 1) {
     msm_plan_t p;
     p.n = n;
-    p.c = c_override ? c_override : msm_pick_c(n);
-    p.W = (254 + p.c - 1) / p.c;
+    p.J = tables < 1 ? 1 : tables;
+    if (p.J == 1) {
+        p.c = c_override ? c_override : msm_pick_c(n);
+        p.W = (254 + p.c - 1) / p.c;
+    } else {
+        const int part = 256 / p.J;
+        p.c = c_override ? c_override : (n >= 4096 ? 16 : 8);
+        if (p.c > part) p.c = part;
+        while (part % p.c) p.c--;  // largest divisor of the part width not above the request
+        p.W = part / p.c;
+    }
+    p.Wd = p.W * p.J;
     p.nb = 1u << (p.c - 1);
     p.nbt = (uint32_t)p.W * p.nb;
-    p.chunk = 1u << 18;
+    // scalars per (chunk, window) workgroup: keep ~2^18 entries per private scatter region whatever the table count
+    p.chunk = (1u << 18) / (uint32_t)p.J;
+    p.chunk &= ~7u;  // multiple of 8: 16-byte digit loads
     if (p.chunk > n) p.chunk = (uint32_t)(n ? n : 1);
     p.nchunks = (uint32_t)((n + p.chunk - 1) / p.chunk);
     p.S = 64;
     p.S2 = 64;
     p.L = p.nb < 16 ? p.nb : 16;
     p.rounds = 0;
-    size_t m = (n + p.S - 1) / p.S;
+    size_t m = ((size_t)p.J * n + p.S - 1) / p.S;
     while (m > 1) {
         m = (m + p.S2 - 1) / p.S2;
         p.rounds++;
     }
     for (int i = 0; i < 10; i++) p.bias[i] = 0;
-    for (int w = 0; w < p.W; w++) {
+    for (int w = 0; w < p.Wd; w++) {
         int bit = p.c - 1 + p.c * w;
         p.bias[bit / 32] |= 1u << (bit % 32);  // bits are distinct: no carries while building the constant
     }
@@ -214,6 +231,7 @@ struct msm_sort_params_t {
     size_t n;
     uint32_t chunk, nchunks, nb;
     int c;
+    int W, J;  // bucket windows and base tables: digit row j*W + w feeds window w with base table j
 };
 // Visit the digits of scalars [lo, hi) of one window; 8 digits per 16-byte load when the rows are 16-byte aligned.
 template <class Fn>
@@ -245,10 +263,11 @@ __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restri
     const size_t lo = (size_t)chunk * p.chunk;
     const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
     const int half = 1 << (p.c - 1);
-    for_each_digit(digits + (size_t)w * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
-        const int v = (int)u - half;
-        if (v != 0) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
-    });
+    for (int j = 0; j < p.J; j++)
+        for_each_digit(digits + (size_t)(j * p.W + w) * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
+            const int v = (int)u - half;
+            if (v != 0) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
+        });
     __syncthreads();
     uint32_t* dst = counts + ((size_t)w * p.nchunks + chunk) * p.nb;
     for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) dst[b] = hist[b];
@@ -316,14 +335,41 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
     const size_t lo = (size_t)chunk * p.chunk;
     const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
     const int half = 1 << (p.c - 1);
-    uint32_t* region = sorted + ((size_t)w * p.nchunks + chunk) * p.chunk;
-    for_each_digit(digits + (size_t)w * p.n, p.n, lo, hi, [&](uint32_t u, size_t i) {
-        const int v = (int)u - half;
-        if (v != 0) {
-            const uint32_t pos = atomicAdd(&cursor[(v < 0 ? -v : v) - 1], 1u);
-            region[pos] = (uint32_t)i | (v < 0 ? 0x80000000u : 0u);
+    uint32_t* region = sorted + ((size_t)w * p.nchunks + chunk) * p.chunk * p.J;
+    const bool vec = (p.n & 7) == 0 && (lo & 7) == 0 && ((hi - lo) & 7) == 0;
+    for (int j = 0; j < p.J; j++) {
+        const uint32_t voff = (uint32_t)((size_t)j * p.n);  // virtual index = table * n + scalar index
+        const uint16_t* d = digits + (size_t)(j * p.W + w) * p.n;
+        if (vec) {
+            // 8 digits per 16-byte load; all 8 LDS cursor atomics are issued before the first dependent store
+            const uint4* d4 = (const uint4*)(d + lo);
+            const size_t nvec = (hi - lo) >> 3;
+            for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+                const uint4 q = d4[v];
+                const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+                const uint32_t i0 = (uint32_t)(lo + (v << 3));
+                uint32_t pos[8], val[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t u = (k & 1) ? (wds[k >> 1] >> 16) : (wds[k >> 1] & 0xffffu);
+                    const int dv = (int)u - half;
+                    val[k] = (voff + i0 + k) | (dv < 0 ? 0x80000000u : 0u);
+                    pos[k] = dv != 0 ? atomicAdd(&cursor[(dv < 0 ? -dv : dv) - 1], 1u) : 0xffffffffu;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (pos[k] != 0xffffffffu) region[pos[k]] = val[k];
+            }
+        } else {
+            for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const int dv = (int)d[i] - half;
+                if (dv != 0) {
+                    const uint32_t pos = atomicAdd(&cursor[(dv < 0 ? -dv : dv) - 1], 1u);
+                    region[pos] = (voff + (uint32_t)i) | (dv < 0 ? 0x80000000u : 0u);
+                }
+            }
         }
-    });
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -358,12 +404,14 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem
                                                                    const uint32_t* __restrict__ size,
                                                                    const uint32_t* __restrict__ start,
                                                                    xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S,
-                                                                   uint32_t nb, uint32_t nchunks, uint32_t chunk) {
+                                                                   uint32_t nb, uint32_t nchunks, uint32_t chunk, uint32_t n,
+                                                                   size_t table_stride) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= start[nbt]) return;
     const uint32_t k = find_bucket(start, nbt, t);
     const uint32_t j = t - start[k];
     const uint32_t w = k / nb, b = k - w * nb;
+    const size_t chunk_stride = chunk;  // entries reserved per (window, chunk) region (chunk * tables)
     const uint32_t sz = size[k];
     uint32_t r = j * S;  // rank range [r, r1) inside bucket k
     uint32_t r1 = r + S;
@@ -380,18 +428,21 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem
     }
     uint32_t ch = lo;
     uint32_t re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
-    size_t phys = ((size_t)w * nchunks + ch) * chunk + loc_off[col + (size_t)ch * nb] + (r - rank[col + (size_t)ch * nb]);
+    size_t phys = ((size_t)w * nchunks + ch) * chunk_stride + loc_off[col + (size_t)ch * nb] + (r - rank[col + (size_t)ch * nb]);
     xyzz_t<F> acc = xyzz_t<F>::inf();
     while (r < r1) {
         while (r == re) {  // run exhausted: next non-empty run (ranks are contiguous across runs)
             ch++;
             re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
-            phys = ((size_t)w * nchunks + ch) * chunk + loc_off[col + (size_t)ch * nb];
+            phys = ((size_t)w * nchunks + ch) * chunk_stride + loc_off[col + (size_t)ch * nb];
         }
         const uint32_t e = sorted[phys++];
         r++;
-        const uint32_t idx = e & 0x7fffffffu;  // scalar index; bases come in up to two segments
-        const aff_t<F> pt = load_aff<F>(idx < n0 ? &bases[idx] : &bases1[idx - n0]);
+        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
+        const uint32_t tbl = v / n;
+        const uint32_t idx = v - tbl * n;    // bases come in up to two segments
+        const aff_mem_t<F>* src = (idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride;
+        const aff_t<F> pt = load_aff<F>(src);
         acc.add_affine(pt, (e >> 31) != 0);
     }
     store_xyzz<F>(&partial[t], acc);
@@ -479,6 +530,30 @@ __global__ void msm_final_kernel(const xyzz_mem_t<F>* __restrict__ wsum, jac_mem
     j.z.to_raw_words(w + 2 * F::MEM_WORDS);
     uint32_t* o = (uint32_t*)out;
     for (int i = 0; i < 3 * F::MEM_WORDS; i++) o[i] = w[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Base tables for registered (static) bases: next[i] = 2^shift * prev[i], affine.  Lets one bucket window serve
+// `tables` digit rows, which cuts the serial Horner chain and the bucket reduction by `tables`.
+// ------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) precompute_table_kernel(const aff_mem_t<F>* __restrict__ prev, aff_mem_t<F>* __restrict__ next,
+                                                               size_t n, int shift) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const aff_t<F> p = load_aff<F>(&prev[i]);
+    aff_t<F> q = aff_t<F>::inf();
+    if (!p.is_inf()) {
+        jac_t<F> j = {p.x, p.y, F::one()};
+        for (int d = 0; d < shift; d++) j = j.dbl();
+        if (!j.is_inf()) {
+            const F zi = j.z.inverse();
+            const F zi2 = zi.sqr();
+            q.x = j.x * zi2;
+            q.y = j.y * (zi2 * zi);
+        }
+    }
+    store_aff<F>(&next[i], q);
 }
 
 // ------------------------------------------------------------------------------------------

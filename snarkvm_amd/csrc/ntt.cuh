@@ -237,6 +237,198 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_tables_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// v2 pass kernel: radix-4 butterflies in registers + lazy reduction.
+//   * two DIF stages per LDS round trip (a = 8: 4 groups, 3 round trips instead of 8), the first group reads
+//     straight from global memory and the last one writes straight back;
+//   * the tile lives in LDS as 9 planes of 29-bit limbs (no pack / unpack between stages);
+//   * butterflies use lazy arithmetic (ff.cuh): sums are only carry-normalised, differences add 2^s * r, products
+//     skip the conditional subtraction.  Bound: entering local stage s every value is < 2^s * r (inputs canonical),
+//     so after a <= 8 stages values are < 256 r < 2^261 (9 limbs).  The closing multiplication (inter-pass twiddle,
+//     1/n scaling, or the constant one) brings the value below 2r and one conditional subtraction makes it
+//     canonical again before it is stored.
+// ------------------------------------------------------------------------------------------
+struct ntt_lds_t {
+    uint32_t* data;  // 9 planes of E limbs
+    uint32_t* tw;    // 9 planes of 128 limbs (w_256 powers, internal form)
+    int E;
+    __device__ __forceinline__ fr_t get(int e) const {
+        fr_t x;
+#pragma unroll
+        for (int l = 0; l < 9; l++) x.v[l] = data[l * E + e];
+        return x;
+    }
+    __device__ __forceinline__ void put(int e, const fr_t& x) const {
+#pragma unroll
+        for (int l = 0; l < 9; l++) data[l * E + e] = x.v[l];
+    }
+    __device__ __forceinline__ fr_t twiddle(int idx) const {
+        fr_t x;
+#pragma unroll
+        for (int l = 0; l < 9; l++) x.v[l] = tw[l * 128 + idx];
+        return x;
+    }
+};
+
+// One DIF stage inside a register group: x[lo_m], x[lo_m | bit] -> (u + v, (u - v + 2^s r) * w)
+__device__ __forceinline__ void lazy_butterfly(fr_t& u, fr_t& v, int s, int tw_idx, const ntt_lds_t& L) {
+    uint32_t kp[9];
+    fr_t::mod_shl(kp, s);  // 2^s * r
+    const fr_t sum = fr_t::add_lazy(u, v);
+    fr_t dif = fr_t::sub_lazy(u, v, kp);
+    if (tw_idx != 0) dif = dif.mul_lazy(L.twiddle(tw_idx));
+    u = sum;
+    v = dif;
+}
+
+__device__ __forceinline__ fr_t load_fr_global(const fr_mem_t* p) {
+    const uint4* src = (const uint4*)p;
+    const uint4 x0 = src[0], x1 = src[1];
+    const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    return fr_t::unpack(w);
+}
+__device__ __forceinline__ void store_fr_global(fr_mem_t* p, const fr_t& x) {
+    uint32_t w[8];
+    x.pack(w);
+    uint4* dst = (uint4*)p;
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// K stages (1 or 2) on the 2^K rows {base_row + m * row_step}; s = index of the first of them within the pass.
+template <int K>
+__device__ __forceinline__ void dif_group(fr_t* x, int s, int a, int lo, const ntt_lds_t& L) {
+    // rows of the group differ in the K bits just below bit (a - s); `lo` = the row bits below them
+    const int lo_bits = a - s - K;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        const int bit = 1 << (K - 1 - t);  // group-local index bit paired at stage s + t
+#pragma unroll
+        for (int m = 0; m < (1 << K); m++) {
+            if (m & bit) continue;
+            // pos = row mod half, half = 2^(a - 1 - (s + t)): the group-local bits below `bit`, then `lo`
+            const int pos = ((m & (bit - 1)) << lo_bits) | lo;
+            const int tw_idx = (pos << (s + t)) << (NTT_MAX_RADIX_LG - a);
+            lazy_butterfly(x[m], x[m | bit], s + t, tw_idx, L);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tables_t tb) {
+    extern __shared__ uint32_t lds32[];
+    const int R = 1 << p.a, T = 1 << p.lgT, E = R << p.lgT;
+    ntt_lds_t L;
+    L.data = lds32;
+    L.tw = lds32 + 9 * E;
+    L.E = E;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t tile = blockIdx.x;
+
+    // ---- addressing (as in v1)
+    size_t in_base, in_rho_stride, in_col_stride;
+    size_t inner0 = 0, d1_0 = 0, mid = 0;
+    if (!p.last) {
+        const size_t tiles_per_outer = (size_t)1 << (p.s - p.lgT);
+        const size_t outer = tile / tiles_per_outer;
+        inner0 = (tile % tiles_per_outer) << p.lgT;
+        in_base = (outer << (p.a + p.s)) + inner0;
+        in_rho_stride = (size_t)1 << p.s;
+        in_col_stride = 1;
+    } else {
+        const size_t tiles_per_mid = (size_t)1 << (p.a1 - p.lgT);
+        mid = tile / tiles_per_mid;
+        d1_0 = (tile % tiles_per_mid) << p.lgT;
+        in_base = (d1_0 << (p.lg_n - p.a1)) + (mid << p.a);
+        in_rho_stride = 1;
+        in_col_stride = (size_t)1 << (p.lg_n - p.a1);
+    }
+    // local twiddles -> LDS planes
+    for (int i = tid; i < 128; i += nthr) {
+        const fr_t w = fr_t::load(&tb.local[p.dir][i]);
+#pragma unroll
+        for (int l = 0; l < 9; l++) L.tw[l * 128 + i] = w.v[l];
+    }
+    __syncthreads();
+
+    // ---- stage groups: pairs of stages, a single stage first when a is odd
+    int s = 0;
+    bool first = true;
+    while (s < p.a) {
+        const int K = ((p.a - s) & 1) ? 1 : 2;
+        const bool last_group = (s + K == p.a);
+        const int lo_bits = p.a - s - K;
+        const int ngroups = E >> K;
+        for (int gi = tid; gi < ngroups; gi += nthr) {
+            // non-last passes keep `col` fastest (coalesced rows of T elements); the last pass keeps the row fastest
+            int col, q;
+            if (!p.last || !first) {
+                col = gi & (T - 1);
+                q = gi >> p.lgT;
+            } else {
+                q = gi & ((R >> K) - 1);
+                col = gi >> (p.a - K);
+            }
+            const int lo = q & ((1 << lo_bits) - 1);
+            const int hi = q >> lo_bits;
+            const int row0 = (hi << (p.a - s)) | lo;
+            const int row_step = 1 << lo_bits;
+            fr_t x[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (m >= (1 << K)) break;
+                const int row = row0 + m * row_step;
+                if (first) {
+                    const size_t g = in_base + row * in_rho_stride + col * in_col_stride;
+                    x[m] = load_fr_global(&p.in[g]);
+                    if (p.coset_pre) x[m] = x[m] * tw_lookup(tb.g_lo[0], tb.g_hi[0], (uint32_t)g);
+                } else {
+                    x[m] = L.get(row * T + col);
+                }
+            }
+            if (K == 2)
+                dif_group<2>(x, s, p.a, lo, L);
+            else
+                dif_group<1>(x, s, p.a, lo, L);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (m >= (1 << K)) break;
+                const int row = row0 + m * row_step;
+                if (!last_group) {
+                    L.put(row * T + col, x[m]);
+                    continue;
+                }
+                // ---- closing multiplication + store; row `row` holds output digit k = bitrev_a(row)
+                const uint32_t k = bitrev32((uint32_t)row, p.a);
+                size_t g;
+                fr_t y;
+                if (!p.last) {
+                    g = in_base + ((size_t)k << p.s) + col;
+                    const uint32_t expo = (uint32_t)(((inner0 + col) * (size_t)k) << p.tw_shift);
+                    y = x[m].mul_lazy(fr_t::load(&tb.pow_lo[p.dir][expo & (NTT_TW_SIZE - 1)]));
+                    const uint32_t h = expo >> NTT_TW_BITS;
+                    if (h) y = y.mul_lazy(fr_t::load(&tb.pow_hi[p.dir][h]));
+                } else {
+                    g = (d1_0 + col) + (((size_t)mid + ((size_t)k << p.lg_mid)) << p.a1);
+                    if (p.scale_post == 0) {
+                        y = x[m].mul_lazy(fr_t::one());
+                    } else {
+                        y = x[m].mul_lazy(fr_t::load(&tb.size_inv[p.lg_n]));
+                        if (p.scale_post == 2) {
+                            y = y.mul_lazy(fr_t::load(&tb.g_lo[1][(uint32_t)g & (NTT_TW_SIZE - 1)]));
+                            const uint32_t h = (uint32_t)g >> NTT_TW_BITS;
+                            if (h) y = y.mul_lazy(fr_t::load(&tb.g_hi[1][h]));
+                        }
+                    }
+                }
+                store_fr_global(&p.out[g], y.reduce_lazy());
+            }
+        }
+        __syncthreads();
+        s += K;
+        first = false;
+    }
+}
+
 // out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.cuh:128,189; domain.rs:797-804 derange)
 __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -309,11 +501,20 @@ static inline ntt_plan_t ntt_make_plan(int lg) {
 static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb) {
     const size_t E = (size_t)1 << (p.a + p.lgT);
     const size_t ntiles = ((size_t)1 << p.lg_n) / E;
-    int threads = (int)(E / 2);
-    if (threads < 64) threads = 64;
-    if (threads > 512) threads = 512;
-    const size_t shmem = (2 * E + 256) * sizeof(uint4);
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
+    static const int use_v1 = getenv("SNARKVM_HIP_NTT_V1") ? atoi(getenv("SNARKVM_HIP_NTT_V1")) : 0;
+    if (use_v1) {
+        int threads = (int)(E / 2);
+        if (threads < 64) threads = 64;
+        if (threads > 512) threads = 512;
+        const size_t shmem = (2 * E + 256) * sizeof(uint4);
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
+    } else {
+        int threads = (int)(E / 4);  // one radix-4 group per thread
+        if (threads < 64) threads = 64;
+        if (threads > 512) threads = 512;
+        const size_t shmem = (9 * E + 9 * 128) * sizeof(uint32_t);
+        hipLaunchKernelGGL(ntt_pass_kernel_v2, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
+    }
 }
 
 // NN-order transform of 2^lg elements held in `data`; `scratch` is a second buffer of the same size.

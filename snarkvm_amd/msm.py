@@ -23,18 +23,20 @@ class VariableBase:
 class RegisteredBases:
     """Device-resident base vector (snarkvm_hip_register_bases)."""
 
-    def __init__(self, bases=None, device_ptr=None, npoints=None):
+    def __init__(self, bases=None, device_ptr=None, npoints=None, tables=1):
+        """tables > 1 precomputes 2^(256/tables * j) * P_i (j < tables) once, shrinking the serial tail of every MSM."""
         L = _lib.lib()
         self._h = ctypes.c_void_p()
+        self.tables = int(tables)
         if device_ptr is not None:
             self.n = int(npoints)
-            err = L.snarkvm_hip_register_bases(ctypes.byref(self._h), ctypes.c_void_p(device_ptr), ctypes.c_size_t(self.n),
-                                               ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(1))
+            err = L.snarkvm_hip_register_bases_tables(ctypes.byref(self._h), ctypes.c_void_p(device_ptr), ctypes.c_size_t(self.n),
+                                                      ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(1), ctypes.c_int(self.tables))
         else:
             bases = np.ascontiguousarray(bases, dtype=G1_AFFINE).reshape(-1)
             self.n = bases.shape[0]
-            err = L.snarkvm_hip_register_bases(ctypes.byref(self._h), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(self.n),
-                                               ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0))
+            err = L.snarkvm_hip_register_bases_tables(ctypes.byref(self._h), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(self.n),
+                                                      ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0), ctypes.c_int(self.tables))
         _lib.check(err)
 
     def msm(self, scalars=None, offset=0, device_ptr=None, npoints=None, window_bits=0):

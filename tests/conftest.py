@@ -26,3 +26,17 @@ def golden():
     with open(os.path.join(here, "beta_h_g2.bin"), "rb") as f:
         beta_h = f.read()
     return {"constants": consts, "varuna": varuna, "srs_g1": srs, "beta_h_g2": beta_h}
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The CPU oracle parallelises with OpenMP; on a many-core GPU host (256 hardware threads) the fork/join cost of
+    hundreds of tiny parallel regions dominates small transforms, so the checker is capped at 16 threads."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    try:
+        from oracle import cpu as oracle
+
+        oracle.set_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
+    yield

@@ -218,6 +218,21 @@ def test_msm_every_window_size(golden, c):
     rb.close()
 
 
+@pytest.mark.parametrize("tables", [2, 4, 8, 16])
+def test_msm_precomputed_tables(golden, tables):
+    """Registered bases with 2^(256/tables * j) multiples: same group element, shorter serial tail."""
+    n = 5000
+    bases = _srs(golden, n)
+    bases[17]["infinity"] = 1
+    sc = synthetic.random_fr_integers(n, 700 + tables)
+    sc[:3] = util.ints_to_fr([0, 1, pyref.R_MOD - 1])
+    rb = RegisteredBases(bases, tables=tables)
+    _check(bases, sc, rb.msm(sc))
+    _check(bases[40:140], sc[:100], rb.msm(sc[:100], offset=40))      # small n -> c = 8
+    _check(bases, sc, rb.msm(sc, window_bits=4))
+    rb.close()
+
+
 def _device_bases(n, start=1):
     import torch
 
@@ -243,7 +258,7 @@ def test_msm_full_size_closed_form(lg):
 
     n = 1 << lg
     buf = _device_bases(n, start=1)
-    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n)
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=4 if lg == 24 else 1)
     sc = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE)
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()

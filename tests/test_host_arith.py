@@ -12,7 +12,7 @@ from oracle import pyref
 from snarkvm_amd import _lib, synthetic
 from tests import util
 
-OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inverse": 4, "neg": 5, "from_bigint": 6, "to_bigint": 7}
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inverse": 4, "neg": 5, "from_bigint": 6, "to_bigint": 7, "lazy_chain": 8}
 
 
 def _p(a):
@@ -52,6 +52,8 @@ def test_device_field_arithmetic_on_host_matches_oracle(field):
     assert np.array_equal(host_field(field, "to_bigint", a), ofn("to_bigint", a))
     nz = a[1:40]
     assert np.array_equal(host_field(field, "inverse", nz), ofn("inverse", nz))
+    if field == 0:  # lazy add / sub / mul + final reduction (NTT butterflies) == plain product
+        assert np.array_equal(host_field(field, "lazy_chain", a, b), ofn("mul", a, b))
 
 
 def test_limb_tables_match_reference_constants(golden):
@@ -109,3 +111,9 @@ def test_device_point_arithmetic_on_host(golden):
     # all-zero scalars -> Projective::zero() = (0, 1, 0)
     rc = L.snarkvm_hip_selftest_g1_msm_naive(_p(aff), ctypes.c_size_t(len(pts)), ctypes.c_size_t(104), _p(np.zeros_like(sc)), _p(out))
     assert pyref.from_limbs(out["z"][0]) == 0 and pyref.from_limbs(out["y"][0]) == pyref.FQ_MONT_R
+
+
+def test_ntt_lazy_bound():
+    """Lazy butterflies keep values below 2^s * r entering local stage s; 8 stages need 256 r < 2^261 (9 x 29 bits)."""
+    assert 256 * pyref.R_MOD < 1 << 261
+    assert (pyref.R_MOD << 8) >> (29 * 8) < 1 << 29  # top limb of 2^8 r stays a 29-bit limb
