@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--ntt-steps", type=int, default=10)
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--tables", type=int, default=4, help="precomputed 2^(256/tables*j) multiples of the registered bases")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="issue the K steps one synchronous MSM at a time instead of one pipelined batch of K independent MSMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lg-msm", type=int, default=18)
     ap.add_argument("--cpu-lg-ntt", type=int, default=22)
@@ -80,8 +82,13 @@ def main():
         rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
+    if args.no_pipeline:
+        for _ in range(args.steps):
+            res = rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
+    else:
+        # K independent MSM instances (a batch of commitments) pipelined over the backend's HIP streams: the
+        # latency-bound tail of one instance overlaps the accumulation of the next.  Every step does the full work.
+        res = rb.msm_batch(device_ptrs=[d_scalars.data_ptr()] * args.steps, npoints=[n] * args.steps, window_bits=args.window_bits)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -184,7 +191,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"G1 Pippenger MSM 2^{args.lg_msm} (BASELINE.json configs[1]), bases (i+1)G registered in HBM, "
                                    f"uniform scalars in HBM; independent instance per GPU",
-                       "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables},
+                       "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables,
+                       "pipelined_batch": not args.no_pipeline},
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
             "ntt_ms_per_transform": ntt_dt / args.ntt_steps * 1e3,

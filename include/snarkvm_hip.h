@@ -102,6 +102,15 @@ RustError snarkvm_hip_msm_registered_ex(void *out, const snarkvm_hip_bases_t *ha
                                         size_t off1, size_t n1, const void *scalars, int scalars_on_device,
                                         int scalars_montgomery, int window_bits);
 
+/* A batch of independent MSMs over one registered base vector (the commitments of a batch of proofs,
+ * polycommit/sonic_pc/mod.rs:186-245 fans these out over a CPU pool).  Instance k covers bases
+ * [offsets[k], offsets[k] + npoints[k]) with the scalar vector scalars[k]; results are written to
+ * outs + 144 * k.  Instances are pipelined over several HIP streams so that the latency-bound tail of one MSM
+ * overlaps the accumulation of the next. */
+RustError snarkvm_hip_msm_registered_batch(void *outs, const snarkvm_hip_bases_t *handle, size_t count,
+                                           const size_t *offsets, const size_t *npoints, const void *const *scalars,
+                                           int scalars_on_device, int scalars_montgomery, int window_bits);
+
 /* `From<Projective> for Affine` (curves/src/templates/short_weierstrass_jacobian/affine.rs:331-353) for n
  * G1Projective (144 B) -> G1Affine (104 B), host buffers. */
 RustError snarkvm_hip_g1_to_affine(void *out_affine, const void *in_projective, size_t n);

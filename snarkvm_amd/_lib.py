@@ -14,7 +14,7 @@ SYMBOLS = [
     "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm",
     "snarkvm_hip_device_count", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
     "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_free_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2",
-    "snarkvm_hip_msm_registered_ex", "snarkvm_hip_g1_to_affine",
+    "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_g1_to_affine",
     "snarkvm_hip_fr_mul_device", "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize",
@@ -54,7 +54,7 @@ def lib():
             pass
         L = ctypes.CDLL(LIB_PATH)
         err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
-                   "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
+                   "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
                    "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device", "snarkvm_hip_synchronize",
                    "snarkvm_hip_devtest_field"]
         for name in err_fns:

@@ -67,6 +67,11 @@ struct dev_buf {
     }
 };
 
+struct msm_ws_t {
+    hipStream_t stream = nullptr;
+    dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, contrib, wsum, result;
+};
+
 struct phase_rec {
     const char* name;
     hipEvent_t e0, e1;
@@ -82,9 +87,13 @@ struct context_t {
     dev_buf tables_mem;
     // NTT staging
     dev_buf ntt_data, ntt_scratch, ntt_acc;
-    // MSM workspace
-    dev_buf bases_tmp, scalars_tmp, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b,
-        part_a, part_b, contrib, wsum, result, gen_pts, gen_prod;
+    // MSM workspaces: lane 0 runs on the main stream; lanes 1.. are used by the batch API so that the latency-bound
+    // tail of one MSM (bucket reduction, Horner) overlaps the throughput-bound accumulation of the next
+    static constexpr int LANES = 3;
+    msm_ws_t lane[LANES];
+    dev_buf bases_tmp, scalars_tmp, gen_pts, gen_prod;
+    void* batch_pinned = nullptr;
+    size_t batch_pinned_cap = 0;
     // profiling
     bool profiling = false;
     std::vector<phase_rec> phases;
@@ -98,6 +107,8 @@ struct context_t {
         if (e != hipSuccess || ndev == 0) throw hip_failure{e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount (no MI355X visible)", __LINE__};
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        lane[0].stream = stream;
+        for (int l = 1; l < LANES; l++) HIP_TRY(hipStreamCreateWithFlags(&lane[l].stream, hipStreamNonBlocking));
         // tables: 4 x (lo + hi) x 4096 + 2 x 128 + 25 + 4, 32 B each
         const size_t entries = 8 * NTT_TW_SIZE + 256 + 32 + 8;
         tables_mem.ensure(entries * sizeof(fr_mem_t));
@@ -183,9 +194,13 @@ static void write_infinity(void* out) {
 
 // d_bases: converted device bases; d_scalars: device scalars (32 B each); result written to host `out` (144 B)
 template <class F>
-static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
+static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
                     const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
-                    size_t table_stride = 0) {
+                    size_t table_stride = 0, int lane_idx = 0, bool sync = true) {
+    msm_ws_t& c = ctx.lane[lane_idx];
+    // per-phase HIP events only on the synchronous single-MSM path (lane 0)
+    auto phase_begin = [&](const char* name) { if (lane_idx == 0 && sync) ctx.phase_begin(name); };
+    auto phase_end = [&]() { if (lane_idx == 0 && sync) ctx.phase_end(); };
     if (n0 > n) n0 = n;
     if (n == 0) {
         write_infinity<F>(out);
@@ -223,7 +238,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     c.result.ensure(sizeof(jac_mem_t<F>));
 
     // 1. digits
-    c.phase_begin("msm_digits");
+    phase_begin("msm_digits");
     {
         msm_digit_params_t dp;
         memcpy(dp.bias, pl.bias, sizeof dp.bias);
@@ -235,7 +250,7 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
         if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
     }
-    c.phase_end();
+    phase_end();
     // 2.-4. counting sort by (window, bucket), chunk-major layout
     msm_sort_params_t sp;
     sp.n = n;
@@ -249,18 +264,18 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
     uint32_t* rank = c.counts.as<uint32_t>();      // counts, turned into ranks in place
     uint32_t* loc_off = c.offsets.as<uint32_t>();  // offset of each bucket inside its (window, chunk) region
     uint32_t* bsize = c.boff.as<uint32_t>();       // bucket sizes
-    c.phase_begin("msm_histogram");
+    phase_begin("msm_histogram");
     hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), rank, sp);
-    c.phase_end();
-    c.phase_begin("msm_bucket_rank");
+    phase_end();
+    phase_begin("msm_bucket_rank");
     hipLaunchKernelGGL(msm_bucket_rank_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, rank, bsize, pl.nb, pl.nchunks, nbt);
-    c.phase_end();
-    c.phase_begin("msm_scatter");
+    phase_end();
+    phase_begin("msm_scatter");
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds + 4096, st, c.digits.as<uint16_t>(), rank, bsize, loc_off,
                        c.sorted.as<uint32_t>(), sp);
-    c.phase_end();
+    phase_end();
     // 5. accumulate
-    c.phase_begin("msm_accumulate");
+    phase_begin("msm_accumulate");
     hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
     exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
     {
@@ -275,9 +290,9 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
                                c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
                                pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride);
     }
-    c.phase_end();
+    phase_end();
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
-    c.phase_begin("msm_reduce_partials");
+    phase_begin("msm_reduce_partials");
     uint32_t *cnt_in = c.cnt_a.as<uint32_t>(), *cnt_out = c.cnt_b.as<uint32_t>();
     uint32_t *start_in = c.start_a.as<uint32_t>(), *start_out = c.start_b.as<uint32_t>();
     xyzz_mem_t<F> *pin = c.part_a.as<xyzz_mem_t<F>>(), *pout = c.part_b.as<xyzz_mem_t<F>>();
@@ -294,20 +309,20 @@ static void msm_run(context_t& c, const aff_mem_t<F>* d_bases, const uint4* d_sc
         std::swap(pin, pout);
         T_in_max = T_out_max;
     }
-    c.phase_end();
+    phase_end();
     // 7.-9. bucket reduction, window sums, Horner
-    c.phase_begin("msm_bucket_reduce");
+    phase_begin("msm_bucket_reduce");
     const uint32_t total_threads = (uint32_t)pl.W * J;
     hipLaunchKernelGGL((msm_bucket_reduce_kernel<F>), dim3((total_threads + 255) / 256), dim3(256), 0, st, pin, start_in, cnt_in,
                        c.contrib.as<xyzz_mem_t<F>>(), pl.nb, pl.L, total_threads);
     hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(pl.W), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, c.contrib.as<xyzz_mem_t<F>>(), c.wsum.as<xyzz_mem_t<F>>(), J);
-    c.phase_end();
-    c.phase_begin("msm_final_horner");
+    phase_end();
+    phase_begin("msm_final_horner");
     hipLaunchKernelGGL((msm_final_kernel<F>), dim3(1), dim3(64), 0, st, c.wsum.as<xyzz_mem_t<F>>(), c.result.as<jac_mem_t<F>>(), pl.W, pl.c);
-    c.phase_end();
+    phase_end();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(jac_mem_t<F>), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(jac_mem_t<F>), hipMemcpyDeviceToHost, st));  // `out` is pinned when !sync
+    if (sync) HIP_TRY(hipStreamSynchronize(st));
 }
 
 template <class F>
@@ -607,6 +622,37 @@ RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h,
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
     msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery, h->tables, h->n);
+    API_END
+}
+RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t* h, size_t count, const size_t* offsets, const size_t* npoints,
+                                           const void* const* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    API_BEGIN
+    if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null handle", __LINE__};
+    if (window_bits && (window_bits < 2 || window_bits > 16)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: window_bits must be 0 or 2..16", __LINE__};
+    if (count * 144 > g_ctx.batch_pinned_cap) {
+        if (g_ctx.batch_pinned) HIP_TRY(hipHostFree(g_ctx.batch_pinned));
+        g_ctx.batch_pinned = nullptr;
+        g_ctx.batch_pinned_cap = 0;
+        HIP_TRY(hipHostMalloc(&g_ctx.batch_pinned, count * 144 + 144, hipHostMallocDefault));
+        g_ctx.batch_pinned_cap = count * 144 + 144;
+    }
+    uint8_t* stage = (uint8_t*)g_ctx.batch_pinned;
+    for (size_t k = 0; k < count; k++) {
+        if (offsets[k] + npoints[k] > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
+        const int lane = (int)(k % context_t::LANES);
+        msm_ws_t& ws = g_ctx.lane[lane];
+        const uint4* d_sc = (const uint4*)scalars[k];
+        if (!scalars_on_device && npoints[k]) {
+            // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
+            ws.scalars.ensure(npoints[k] * 32);
+            HIP_TRY(hipMemcpyAsync(ws.scalars.p, scalars[k], npoints[k] * 32, hipMemcpyHostToDevice, ws.stream));
+            d_sc = ws.scalars.as<uint4>();
+        }
+        msm_run<fq_t>(g_ctx, h->d + offsets[k], d_sc, npoints[k], stage + 144 * k, window_bits, nullptr, ~(size_t)0, scalars_montgomery, h->tables,
+                      h->n, lane, false);
+    }
+    for (int l = 0; l < context_t::LANES; l++) HIP_TRY(hipStreamSynchronize(g_ctx.lane[l].stream));
+    memcpy(outs, stage, count * 144);
     API_END
 }
 RustError snarkvm_hip_g1_to_affine(void* out_affine, const void* in_projective, size_t n) {

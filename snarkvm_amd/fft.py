@@ -77,3 +77,29 @@ class PolyMultiplier:
         res = plugin.polymul(domain.size, [p for _, p in self.polynomials], [e for _, e in self.evaluations])
         nz = np.nonzero(res.any(axis=1))[0]
         return res[: (nz[-1] + 1 if nz.size else 0)]
+
+
+class Evaluations:
+    """fft/evaluations.rs:28-74: evaluations of a polynomial over a domain (thin wrappers over the transforms)."""
+
+    def __init__(self, evaluations, domain):
+        self.evaluations = np.ascontiguousarray(evaluations, dtype=np.uint64).reshape(-1, 4)
+        self.domain = domain
+
+    @classmethod
+    def from_vec_and_domain(cls, evaluations, domain):  # evaluations.rs:42-44
+        return cls(evaluations, domain)
+
+    def interpolate(self):  # evaluations.rs:52-56: iFFT, then trim trailing zeros (DensePolynomial::from_coefficients_vec)
+        coeffs = self.domain.ifft(self.evaluations)
+        nz = np.nonzero(coeffs.any(axis=1))[0]
+        return coeffs[: (nz[-1] + 1 if nz.size else 0)]
+
+
+def evaluate_over_domain(coeffs, domain):
+    """fft/polynomial/mod.rs:261-300 for a dense polynomial no longer than the domain: zero-pad + FFT.
+    (Longer polynomials are folded chunk-wise on the host by the reference; that path stays with the caller.)"""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    if coeffs.shape[0] > domain.size:
+        raise NotImplementedError("polynomial longer than the domain: fold on the host first (polynomial/mod.rs:270-286)")
+    return Evaluations(domain.fft(coeffs), domain)

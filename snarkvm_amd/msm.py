@@ -55,6 +55,31 @@ class RegisteredBases:
         _lib.check(err)
         return out
 
+    def msm_batch(self, scalars_list=None, offsets=None, device_ptrs=None, npoints=None, window_bits=0, montgomery=False):
+        """Independent MSMs over this base vector, pipelined on several HIP streams.  Either `scalars_list` (host
+        (n_k, 4) arrays) or `device_ptrs` + `npoints` (device-resident scalar vectors).  Returns a G1_PROJECTIVE array."""
+        L = _lib.lib()
+        if device_ptrs is not None:
+            count = len(device_ptrs)
+            ns = [int(v) for v in npoints]
+            ptrs = [int(p) for p in device_ptrs]
+            on_dev = 1
+            keep = None
+        else:
+            keep = [np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4) for s in scalars_list]
+            count = len(keep)
+            ns = [k.shape[0] for k in keep]
+            ptrs = [k.ctypes.data for k in keep]
+            on_dev = 0
+        offs = [0] * count if offsets is None else [int(o) for o in offsets]
+        out = np.zeros(count, dtype=G1_PROJECTIVE)
+        c_offs = (ctypes.c_size_t * max(1, count))(*offs)
+        c_ns = (ctypes.c_size_t * max(1, count))(*ns)
+        c_ptrs = (ctypes.c_void_p * max(1, count))(*ptrs)
+        _lib.check(L.snarkvm_hip_msm_registered_batch(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(count), c_offs, c_ns, c_ptrs,
+                                                      ctypes.c_int(on_dev), ctypes.c_int(1 if montgomery else 0), ctypes.c_int(window_bits)))
+        return out
+
     def close(self):
         if self._h:
             _lib.lib().snarkvm_hip_free_bases(self._h)

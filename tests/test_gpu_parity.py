@@ -233,6 +233,24 @@ def test_msm_precomputed_tables(golden, tables):
     rb.close()
 
 
+def test_msm_batch_pipelined(golden):
+    """A batch of independent MSMs (ragged sizes, offsets) pipelined over several streams == one-at-a-time results."""
+    bases = _srs(golden, 6000)
+    rb = RegisteredBases(bases, tables=4)
+    sizes = [6000, 1, 333, 4096, 0, 5000, 17, 2048]
+    offs = [0, 5, 100, 1000, 0, 1000, 3000, 7]
+    scal = [synthetic.random_fr_integers(k, 1300 + i) for i, k in enumerate(sizes)]
+    got = rb.msm_batch(scal, offsets=offs)
+    for i, (k, o) in enumerate(zip(sizes, offs)):
+        want = oracle.g1_to_affine(oracle.g1_msm(bases[o:o + k], scal[i], oracle.MSM_BATCHED)) if k else None
+        a = oracle.g1_to_affine(got[i:i + 1])
+        if k == 0:
+            assert a["infinity"][0] == 1
+        else:
+            assert util.affine_equal(a, want), i
+    rb.close()
+
+
 def _device_bases(n, start=1):
     import torch
 
@@ -333,4 +351,71 @@ def test_kzg10_commit_matches_reference_formula(golden):
     assert kzg10.to_affine(z)["infinity"][0] == 1
     with pytest.raises(kzg10.PCError):
         kzg10.KZG10.commit(pw, np.zeros((n + 1, 4), dtype=np.uint64) + 1)
+    pw.close()
+
+
+# ------------------------------------------------------------------------------------------ Varuna-shaped replay
+def test_varuna_proof_shaped_workload(golden):
+    """BASELINE.json configs[3]: the MSM / NTT / polymul call pattern of one Varuna proof with credits.aleo
+    transfer_private shapes (|R| = |C| = 2^16, |K| = 2^17), random data, every result checked
+    against the oracle.  Commits go through the fused KZG10 path over SRS powers registered once."""
+    from snarkvm_amd import kzg10
+
+    lgR, lgK = 16, 17
+    g = util.g1_generator_affine()
+    powers_g = oracle.g1_gen_bases(g, 1, 1 << (lgK + 1))
+    gamma_g = oracle.g1_gen_bases(g, 1 << 20, 4)
+    pw = kzg10.Powers(powers_g, gamma_g)
+
+    def rnd(n, seed):
+        return oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, seed))
+
+    def check_commit(coeffs, hiding, seed):
+        blind = rnd(3, seed)
+        comm, _ = kzg10.KZG10.commit(pw, coeffs, hiding, (lambda k: blind[:k]) if hiding is not None else None)
+        want = oracle.g1_msm(powers_g[: coeffs.shape[0]], oracle.fr_op("to_bigint", coeffs), oracle.MSM_BATCHED)
+        if hiding is not None:
+            want = oracle.g1_add(want, oracle.g1_msm(gamma_g, oracle.fr_op("to_bigint", blind[: hiding + 1]), oracle.MSM_BATCHED))
+        assert util.affine_equal(oracle.g1_to_affine(comm), oracle.g1_to_affine(want))
+
+    def check_ntt(x, direction, kind=NTTType.Standard):
+        y = x.copy()
+        plugin.NTT(x.shape[0], y, NTTInputOutputOrder.NN, direction, kind)
+        assert np.array_equal(y, oracle.ntt(x, oracle.ORDER_NN, direction, kind))
+        return y
+
+    # round 1: x_poly FFT + w iFFT at |C|, commit w (hiding)
+    w_evals = rnd(1 << lgR, 1)
+    w = check_ntt(w_evals, NTTDirection.Inverse)
+    check_ntt(rnd(1 << lgR, 2), NTTDirection.Forward)
+    check_commit(w, 1, 3)
+    # round 2: z_a, z_b, z_c iFFT at |R|; h_0 ~ z_a * z_b (2 FFT + 1 iFFT at 2|R|); commit h_0
+    za, zb, zc = (check_ntt(rnd(1 << lgR, 10 + i), NTTDirection.Inverse) for i in range(3))
+    h0 = plugin.polymul(1 << (lgR + 1), [za, zb], [])
+    assert np.array_equal(h0, oracle.polymul(lgR + 1, [za, zb]))
+    check_commit(h0, None, 0)
+    # round 3: per matrix iFFT at |C| + polymul at 2|C|; commit g_1 (hiding), h_1
+    for m in range(3):
+        t = check_ntt(rnd(1 << lgR, 20 + m), NTTDirection.Inverse)
+        pm = plugin.polymul(1 << (lgR + 1), [t, za], [])
+        assert np.array_equal(pm, oracle.polymul(lgR + 1, [t, za]))
+    check_commit(rnd((1 << lgR) - 1, 30), 1, 31)
+    check_commit(h0, None, 0)
+    # round 4: per matrix 3 iFFT at |K| + polymul at 2|K|; commit g_a, g_b, g_c
+    for m in range(3):
+        a_ = check_ntt(rnd(1 << lgK, 40 + m), NTTDirection.Inverse)
+        b_ = check_ntt(rnd(1 << lgK, 50 + m), NTTDirection.Inverse)
+        check_ntt(rnd(1 << lgK, 60 + m), NTTDirection.Inverse, NTTType.Coset)
+        if m == 0:
+            pm = plugin.polymul(1 << (lgK + 1), [a_, b_], [])
+            assert np.array_equal(pm, oracle.polymul(lgK + 1, [a_, b_]))
+        check_commit(a_[: (1 << lgK) - 1], None, 0)
+    # round 5 + openings: commits of the largest combined polynomials, pipelined as one batch
+    polys = [rnd((1 << lgK) - 2, 70), rnd(1 << lgK, 71), rnd(1 << lgR, 72), rnd(1 << lgK, 73)]
+    rb = RegisteredBases(powers_g, tables=4)
+    got = rb.msm_batch(polys, montgomery=True)
+    for i, p_ in enumerate(polys):
+        want = oracle.g1_msm(powers_g[: p_.shape[0]], oracle.fr_op("to_bigint", p_), oracle.MSM_BATCHED)
+        assert util.affine_equal(oracle.g1_to_affine(got[i : i + 1]), oracle.g1_to_affine(want))
+    rb.close()
     pw.close()
