@@ -34,8 +34,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the K steps one synchronous MSM at a time instead of one pipelined batch of K independent MSMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-lg-msm", type=int, default=18)
-    ap.add_argument("--cpu-lg-ntt", type=int, default=22)
+    ap.add_argument("--cpu-lg-msm", type=int, default=23)
+    ap.add_argument("--cpu-lg-ntt", type=int, default=24)
     args = ap.parse_args()
 
     import torch
@@ -148,13 +148,14 @@ def main():
         gen = np.zeros(1, dtype=oracle.G1_AFFINE)
         gen["x"] = [1171681672315280277, 6528257384425852712, 7514971432460253787, 2032708395764262463, 12876543207309632302, 107509843840671767]
         gen["y"] = [13572190014569192121, 15344828677741220784, 17067903700058808083, 10342263224753415805, 1083990386877464092, 21335464879237822]
+        cn = min(cn, n)
         cb = oracle.g1_gen_bases(gen, 1, cn)
         cs = scalars[:cn]
         oracle.g1_msm(cb[:1024], cs[:1024])  # warm-up
         t0 = time.perf_counter()
         cpu_res = oracle.g1_msm(cb, cs, oracle.MSM_BATCHED)
         cpu_msm_dt = time.perf_counter() - t0
-        cnn = 1 << args.cpu_lg_ntt
+        cnn = min(1 << args.cpu_lg_ntt, nn)
         cx = x[:cnn].copy()
         t0 = time.perf_counter()
         oracle.ntt(cx)
@@ -164,8 +165,8 @@ def main():
             "unit": "pairs/s",
             "cores": threads,
             "kind": "port",
-            "sample": f"batched::msm restatement (oracle/cpu_oracle.cpp, OpenMP one task per window) on 2^{args.cpu_lg_msm} pairs of the "
-                      f"same workload: {cpu_msm_dt:.2f} s; fft_in_place restatement on 2^{args.cpu_lg_ntt} elements: {cpu_ntt_dt:.2f} s",
+            "sample": f"batched::msm restatement (oracle/cpu_oracle.cpp, OpenMP one task per window) on {cn} pairs of the "
+                      f"same workload: {cpu_msm_dt:.2f} s; fft_in_place restatement on {cnn} elements: {cpu_ntt_dt:.2f} s",
             "host_cores": cores,
             "ntt_value": cnn / cpu_ntt_dt,
             "ntt_unit": "elements/s",
