@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--lg-ntt", type=int, default=24)
     ap.add_argument("--ntt-steps", type=int, default=10)
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--tables", type=int, default=4, help="precomputed 2^(256/tables*j) multiples of the registered bases")
+    ap.add_argument("--tables", type=int, default=16, help="precomputed 2^(256/tables*j) multiples of the registered bases")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the K steps one synchronous MSM at a time instead of one pipelined batch of K independent MSMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -172,6 +172,21 @@ def main():
             "ntt_unit": "elements/s",
         }
 
+    # HBM bytes per dispatch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs; see
+    # profiles/r01_pmc_traffic.json for provenance and the gfx950 x2 FETCH correction).  Only quoted for the
+    # configuration they were collected on; PMC collection cannot run inside this process.
+    pmc = {}
+    try:
+        if args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 16 and not args.window_bits:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+    except Exception:
+        pmc = {}
+
+    def traffic(kernel, fetch_key, times=1):
+        k = pmc.get(kernel)
+        return None if not k else (k[fetch_key] + k["write_bytes"]) * times
+
     if rank == 0:
         acc_ms = phase_ms.get("msm_accumulate", 0.0)
         dig_ms = phase_ms.get("msm_digits", 0.0)
@@ -208,7 +223,8 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
-                "traffic": None,
+                "traffic": traffic("msm_accumulate_kernel<Fp<FqP>, 1>", "fetch_bytes_raw"),
+                "algorithmic_bytes": n * 100.0 * W,
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d); see roofline_scalar_read for the HBM-bound phase",
             },
             # the phase north_star scopes the HBM claim to: scalar read + digit extraction, 32 B per scalar
@@ -219,17 +235,19 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
-                "traffic": None,
+                "traffic": traffic("msm_digits_kernel", "fetch_bytes_x2"),
+                "algorithmic_bytes": 32.0 * n,
                 "bytes_incl_digit_writes_GBps": ((32.0 + 2.0 * W) * n) / (dig_ms * 1e-3) / 1e9 if dig_ms else None,
             },
             "roofline_ntt": {
                 "bound": "hbm",
-                "kernel": "ntt_pass_kernel (3 passes)",
+                "kernel": "ntt_pass_kernel_v2 (3 passes)",
                 "achieved": (64.0 * nn) / (ntt_kernel_ms * 1e-3) / 1e9 if ntt_kernel_ms else None,
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((64.0 * nn) / (ntt_kernel_ms * 1e-3) / 1e9 / 8000.0) if ntt_kernel_ms else None,
-                "traffic": None,
+                "traffic": traffic("ntt_pass_kernel_v2", "fetch_bytes_x2", times=3),
+                "algorithmic_bytes": 64.0 * nn,
             },
             "cpu_baseline": cpu,
         }

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsnarkvm_hip.so")
+LIB_PATH = os.environ.get("SNARKVM_HIP_LIB") or os.path.join(_HERE, "lib", "libsnarkvm_hip.so")  # override: A/B experiments only
 
 # every symbol include/snarkvm_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [

@@ -132,6 +132,7 @@ struct context_t {
         HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)msm_locoff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         hipLaunchKernelGGL(ntt_setup_consts, dim3(1), dim3(64), 0, stream, tb);
         hipLaunchKernelGGL(ntt_fill_tables, dim3(NTT_TW_SIZE / 256), dim3(256), 0, stream, tb);
         HIP_TRY(hipGetLastError());
@@ -221,7 +222,7 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     c.offsets.ensure(ncounts * 4);
     c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
     c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * pl.J * 4);
-    c.boff.ensure(((size_t)nbt + 1) * 4);
+    c.boff.ensure(((size_t)nbt + 2) * 4);
     c.cnt_a.ensure(((size_t)nbt + 1) * 4);
     c.cnt_b.ensure(((size_t)nbt + 1) * 4);
     c.start_a.ensure(((size_t)nbt + 1) * 4);
@@ -268,12 +269,25 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), rank, sp);
     phase_end();
     phase_begin("msm_bucket_rank");
-    hipLaunchKernelGGL(msm_bucket_rank_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, rank, bsize, pl.nb, pl.nchunks, nbt);
+    uint32_t* d_max = bsize + nbt + 1;  // one extra word behind the sizes
+    HIP_TRY(hipMemsetAsync(d_max, 0, 4, st));
+    hipLaunchKernelGGL(msm_bucket_rank_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, rank, bsize, pl.nb, pl.nchunks, nbt, d_max);
     phase_end();
     phase_begin("msm_scatter");
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds + 4096, st, c.digits.as<uint16_t>(), rank, bsize, loc_off,
-                       c.sorted.as<uint32_t>(), sp);
+    hipLaunchKernelGGL(msm_locoff_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds + 4096, st, rank, bsize, loc_off, sp);
+    static const int env_passes = getenv("SNARKVM_HIP_SCATTER_PASSES") ? atoi(getenv("SNARKVM_HIP_SCATTER_PASSES")) : 0;
+    uint32_t npass = env_passes > 0 ? (uint32_t)env_passes : (pl.nb >= 8192 ? 2u : 1u);  // measured: 1: 4.13, 2: 3.92, 4: 5.21, 8: 4.94 ms (2^24)
+    while (pl.nb % npass) npass--;
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W, npass), dim3(1024), lds / npass, st, c.digits.as<uint16_t>(), loc_off,
+                       c.sorted.as<uint32_t>(), sp, npass);
     phase_end();
+    // the largest bucket decides how many reduce rounds are needed (4-byte read-back; worst-case sizing would run
+    // up to 7 mostly idle rounds)
+    uint32_t max_bucket = 0;
+    HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int rounds = 0;
+    for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
     // 5. accumulate
     phase_begin("msm_accumulate");
     hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
@@ -281,14 +295,21 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     {
         static const int acc_waves = getenv("SNARKVM_HIP_ACC_WAVES") ? atoi(getenv("SNARKVM_HIP_ACC_WAVES")) : 3;
         const dim3 grid((unsigned)((T0_max + 255) / 256));
+        // timing experiment only (wrong results): restrict the gather to the first 2^k bases to separate ALU time from HBM gather time
+        static const uint32_t dbg_mask = getenv("SNARKVM_HIP_DEBUG_IDX_MASK") ? (uint32_t)strtoul(getenv("SNARKVM_HIP_DEBUG_IDX_MASK"), nullptr, 0) : 0xffffffffu;
+        // variant: 1 = plain loop (default), 2 = software-prefetched gather, 4 = force <= 128 VGPRs (spills; measured slower)
         if (acc_waves >= 4 && sizeof(typename F::mem_t) == 48)
             hipLaunchKernelGGL((msm_accumulate_kernel<F, 4>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
                                c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
-                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride);
+                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride, dbg_mask);
+        else if (acc_waves == 2 && sizeof(typename F::mem_t) == 48)
+            hipLaunchKernelGGL((msm_accumulate_kernel<F, 2>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
+                               c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
+                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride, dbg_mask);
         else
             hipLaunchKernelGGL((msm_accumulate_kernel<F, 1>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
                                c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
-                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride);
+                               pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride, dbg_mask);
     }
     phase_end();
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
@@ -297,7 +318,7 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     uint32_t *start_in = c.start_a.as<uint32_t>(), *start_out = c.start_b.as<uint32_t>();
     xyzz_mem_t<F> *pin = c.part_a.as<xyzz_mem_t<F>>(), *pout = c.part_b.as<xyzz_mem_t<F>>();
     size_t T_in_max = T0_max;
-    for (int r = 0; r < pl.rounds; r++) {
+    for (int r = 0; r < rounds; r++) {
         size_t T_out_max = T_in_max / pl.S2 + nbt + 1;
         if (T_out_max > T1_max) T_out_max = T1_max;  // both ping-pong buffers hold >= T1_max partials
         hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, cnt_in, cnt_out, nbt, pl.S2);
@@ -393,6 +414,7 @@ SV_HD void field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out)
         case 5: r = x.neg(); break;
         case 6: r = F::unpack(a).int_to_mont(); break;                  // from_bigint: integer -> Montgomery
         case 7: (x.mont_to_int()).pack(out); return;                    // to_bigint: Montgomery -> integer
+        case 9: r = F::diff_of_products(x, y, y, x + y); break;  // x*y - y*(x+y) with one reduction
         case 8: {  // lazy-arithmetic chain used by the NTT butterflies (Fr only): ((a + b) - b + 2r) * b == a * b
             if (F::N != 9) { r = x * y; break; }
             uint32_t kp[F::N];

@@ -231,6 +231,56 @@ struct Fp {
         }
         return cond_sub(t);
     }
+    // a*b - c*d with ONE Montgomery reduction (the XYZZ addition's Y3 = R*(Q - X3) - Y1*PPP): the column accumulator
+    // is signed (v_mad_i64_i32); partial sums stay inside [-13*2^58, 26*2^58] for 13 limbs.  Result canonical.
+    SV_HD static Fp diff_of_products(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+        uint32_t m[N];
+        int32_t nc[N], t[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) nc[i] = -(int32_t)c.v[i];
+        int64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < N) {
+                    acc += (int64_t)(int32_t)a.v[i] * (int32_t)b.v[j];
+                    acc += (int64_t)nc[i] * (int32_t)d.v[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 1 && j < N && i < k) acc += (int64_t)(int32_t)m[i] * (int32_t)P::MOD[j];
+            }
+            if (k < N) {
+                m[k] = (0u - (uint32_t)acc) & LIMB_MASK;
+                acc += m[k];
+            } else {
+                // value in (-p, 2p): every limb but the top one is normalised, the top one carries the sign
+                t[k - N] = (k == 2 * N - 1) ? (int32_t)acc : (int32_t)((uint32_t)acc & LIMB_MASK);
+            }
+            acc >>= 29;  // arithmetic
+        }
+        // three-way correction: T < 0 -> T + p;  T >= p -> T - p
+        uint32_t up[N], dn[N];
+        int32_t cu = 0, cd = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int32_t x = t[i] + (int32_t)P::MOD[i] + cu;
+            up[i] = (uint32_t)x & LIMB_MASK;
+            cu = x >> 29;
+            int32_t y = t[i] - (int32_t)P::MOD[i] + cd;
+            dn[i] = (uint32_t)y & LIMB_MASK;
+            cd = y >> 29;
+        }
+        const bool neg = t[N - 1] < 0;
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = neg ? up[i] : (cd < 0 ? (uint32_t)t[i] : dn[i]);
+        return r;
+    }
     // dedicated squaring: off-diagonal products once, against the doubled operand
     SV_HD Fp sqr() const {
         uint32_t m[N], t[N], v2[N];
@@ -430,6 +480,7 @@ struct fq2_t {
         fq_t a = c0.sqr(), b = c1.sqr(), m = c0 * c1;
         return {a - mul5(b), m.dbl()};
     }
+    SV_HD static fq2_t diff_of_products(const fq2_t& a, const fq2_t& b, const fq2_t& c, const fq2_t& d) { return a * b - c * d; }
     SV_HD static fq2_t load(const void* p) {
         const uint8_t* q = (const uint8_t*)p;
         return {fq_t::load(q), fq_t::load(q + 48)};

@@ -25,6 +25,8 @@
 //               small double-and-add; 8 window sum (LDS tree); 9 Horner across windows -> Jacobian.
 // Digit zero is skipped (batched.rs:350: bucket index wraps to u32::MAX and is ignored).
 #pragma once
+#include <stdlib.h>
+
 #include "ec.cuh"
 
 namespace sv {
@@ -77,9 +79,15 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     p.chunk &= ~7u;  // multiple of 8: 16-byte digit loads
     if (p.chunk > n) p.chunk = (uint32_t)(n ? n : 1);
     p.nchunks = (uint32_t)((n + p.chunk - 1) / p.chunk);
-    p.S = 64;
-    p.S2 = 64;
-    p.L = p.nb < 16 ? p.nb : 16;
+    // tuning knobs (environment overrides are for experiments only)
+    static const int env_S = getenv("SNARKVM_HIP_S") ? atoi(getenv("SNARKVM_HIP_S")) : 0;
+    static const int env_S2 = getenv("SNARKVM_HIP_S2") ? atoi(getenv("SNARKVM_HIP_S2")) : 0;
+    static const int env_L = getenv("SNARKVM_HIP_L") ? atoi(getenv("SNARKVM_HIP_L")) : 0;
+    p.S = env_S > 0 ? env_S : 64;
+    p.S2 = env_S2 > 1 ? env_S2 : 8;
+    p.L = env_L > 0 ? (uint32_t)env_L : 8;
+    if (p.L > p.nb) p.L = p.nb;
+    while (p.nb % p.L) p.L--;
     p.rounds = 0;
     size_t m = ((size_t)p.J * n + p.S - 1) / p.S;
     while (m > 1) {
@@ -275,31 +283,33 @@ __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restri
 // Per bucket k = (w, b): turn the per-chunk counts into ranks (exclusive prefix over chunks, in place) and the
 // bucket size.  Threads adjacent in b -> coalesced.
 __global__ void msm_bucket_rank_kernel(uint32_t* __restrict__ counts_to_rank, uint32_t* __restrict__ size, uint32_t nb,
-                                       uint32_t nchunks, uint32_t nbt) {
+                                       uint32_t nchunks, uint32_t nbt, uint32_t* __restrict__ max_size) {
+    __shared__ uint32_t blk_max;
+    if (threadIdx.x == 0) blk_max = 0;
+    __syncthreads();
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > nbt) return;
-    if (k == nbt) {
-        size[k] = 0;
-        return;
-    }
-    const uint32_t w = k / nb, b = k - w * nb;
     uint32_t run = 0;
-    for (uint32_t ch = 0; ch < nchunks; ch++) {
-        const size_t idx = ((size_t)w * nchunks + ch) * nb + b;
-        const uint32_t c = counts_to_rank[idx];
-        counts_to_rank[idx] = run;
-        run += c;
+    if (k < nbt) {
+        const uint32_t w = k / nb, b = k - w * nb;
+        for (uint32_t ch = 0; ch < nchunks; ch++) {
+            const size_t idx = ((size_t)w * nchunks + ch) * nb + b;
+            const uint32_t c = counts_to_rank[idx];
+            counts_to_rank[idx] = run;
+            run += c;
+        }
     }
-    size[k] = run;
+    if (k <= nbt) size[k] = run;
+    // the host sizes the number of reduce rounds from the largest bucket: one global atomic per block
+    if (run) atomicMax(&blk_max, run);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_max) atomicMax(max_size, blk_max);
 }
 // Scatter into the workgroup's PRIVATE region sorted[(w*nchunks + chunk)*chunk ...], grouped by bucket:
 // all partial-line writes of a region come from one workgroup, so they merge in its L2 (the bucket-major layout
 // measured 8x write amplification, profiles/r01_rocprofv3_pmc_hbm_bytes.txt).  loc_off[w][chunk][b] = offset of
 // bucket b inside the region.
-__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
-                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ size,
-                                                           uint32_t* __restrict__ loc_off, uint32_t* __restrict__ sorted,
-                                                           msm_sort_params_t p) {
+__global__ void __launch_bounds__(1024) msm_locoff_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ size,
+                                                          uint32_t* __restrict__ loc_off, msm_sort_params_t p) {
     extern __shared__ uint32_t cursor[];  // nb counters followed by 1024 scan slots
     uint32_t* part = cursor + p.nb;
     const uint32_t chunk = blockIdx.x, w = blockIdx.y;
@@ -331,6 +341,20 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) loc_off[row + b] = cursor[b];
+}
+// One workgroup per (chunk, window, bucket-range pass).  A pass covers nb / npass consecutive buckets, i.e. a
+// contiguous 1/npass slice of the (chunk, window) region.  rocprofv3 WRITE_SIZE shows 8.7 GB written for 1 GiB of
+// entries (every 4-byte store leaves the write-through L2 as its own 32-byte sector write); splitting the bucket
+// range into passes was tried to let the stores merge in L2 and does not help beyond 2 passes (1: 4.13 ms, 2: 3.92,
+// 4: 5.21, 8: 4.94 at 2^24) - the real fix is an LDS-staged two-level radix partition (known weak spots).
+__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
+                                                           const uint32_t* __restrict__ loc_off, uint32_t* __restrict__ sorted,
+                                                           msm_sort_params_t p, uint32_t npass) {
+    extern __shared__ uint32_t cursor[];  // nb / npass cursors
+    const uint32_t chunk = blockIdx.x, w = blockIdx.y, pass = blockIdx.z;
+    const size_t row = ((size_t)w * p.nchunks + chunk) * p.nb;
+    const uint32_t nbp = p.nb / npass, blo = pass * nbp;
+    for (uint32_t b = threadIdx.x; b < nbp; b += blockDim.x) cursor[b] = loc_off[row + blo + b];
     __syncthreads();
     const size_t lo = (size_t)chunk * p.chunk;
     const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
@@ -354,7 +378,8 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
                     const uint32_t u = (k & 1) ? (wds[k >> 1] >> 16) : (wds[k >> 1] & 0xffffu);
                     const int dv = (int)u - half;
                     val[k] = (voff + i0 + k) | (dv < 0 ? 0x80000000u : 0u);
-                    pos[k] = dv != 0 ? atomicAdd(&cursor[(dv < 0 ? -dv : dv) - 1], 1u) : 0xffffffffu;
+                    const uint32_t bl = (uint32_t)((dv < 0 ? -dv : dv) - 1) - blo;  // digit 0 wraps to a huge value
+                    pos[k] = bl < nbp ? atomicAdd(&cursor[bl], 1u) : 0xffffffffu;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++)
@@ -363,8 +388,9 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
         } else {
             for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
                 const int dv = (int)d[i] - half;
-                if (dv != 0) {
-                    const uint32_t pos = atomicAdd(&cursor[(dv < 0 ? -dv : dv) - 1], 1u);
+                const uint32_t bl = (uint32_t)((dv < 0 ? -dv : dv) - 1) - blo;
+                if (bl < nbp) {
+                    const uint32_t pos = atomicAdd(&cursor[bl], 1u);
                     region[pos] = (voff + (uint32_t)i) | (dv < 0 ? 0x80000000u : 0u);
                 }
             }
@@ -405,7 +431,7 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem
                                                                    const uint32_t* __restrict__ start,
                                                                    xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S,
                                                                    uint32_t nb, uint32_t nchunks, uint32_t chunk, uint32_t n,
-                                                                   size_t table_stride) {
+                                                                   size_t table_stride, uint32_t debug_idx_mask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= start[nbt]) return;
     const uint32_t k = find_bucket(start, nbt, t);
@@ -430,7 +456,9 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem
     uint32_t re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
     size_t phys = ((size_t)w * nchunks + ch) * chunk_stride + loc_off[col + (size_t)ch * nb] + (r - rank[col + (size_t)ch * nb]);
     xyzz_t<F> acc = xyzz_t<F>::inf();
-    while (r < r1) {
+    // next sorted entry + the raw image of its base (software prefetch: the gather of point k+1 is in flight while
+    // point k is being added; MINW == 2 selects this variant)
+    auto fetch = [&](uint32_t& e_out, aff_mem_t<F>& raw) {
         while (r == re) {  // run exhausted: next non-empty run (ranks are contiguous across runs)
             ch++;
             re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
@@ -440,10 +468,32 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem
         r++;
         const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
         const uint32_t tbl = v / n;
-        const uint32_t idx = v - tbl * n;    // bases come in up to two segments
-        const aff_mem_t<F>* src = (idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride;
-        const aff_t<F> pt = load_aff<F>(src);
-        acc.add_affine(pt, (e >> 31) != 0);
+        uint32_t idx = v - tbl * n;          // bases come in up to two segments
+        idx &= debug_idx_mask;               // all ones; narrowed only by the gather-locality experiment
+        raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
+        e_out = e;
+    };
+    if (MINW == 2) {
+        if (r < r1) {
+            uint32_t e_cur, e_nxt = 0;
+            aff_mem_t<F> raw_cur, raw_nxt;
+            fetch(e_cur, raw_cur);
+            while (true) {
+                const bool more = r < r1;
+                if (more) fetch(e_nxt, raw_nxt);
+                acc.add_affine(load_aff<F>(&raw_cur), (e_cur >> 31) != 0);
+                if (!more) break;
+                e_cur = e_nxt;
+                raw_cur = raw_nxt;
+            }
+        }
+    } else {
+        while (r < r1) {
+            uint32_t e;
+            aff_mem_t<F> raw;
+            fetch(e, raw);
+            acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
+        }
     }
     store_xyzz<F>(&partial[t], acc);
 }

@@ -37,14 +37,16 @@ def to_affine(projective):
 class Powers:
     """kzg10/data_structures.rs:151-181 `Powers`: the two base vectors of a committer key, resident in HBM."""
 
-    def __init__(self, powers_of_beta_g, powers_of_beta_times_gamma_g):
+    def __init__(self, powers_of_beta_g, powers_of_beta_times_gamma_g, tables=16):
+        """tables: precomputed 2^(256/tables * j) multiples kept next to every base (see RegisteredBases)."""
         self.powers_of_beta_g = np.ascontiguousarray(powers_of_beta_g, dtype=G1_AFFINE).reshape(-1)
         self.powers_of_beta_times_gamma_g = np.ascontiguousarray(powers_of_beta_times_gamma_g, dtype=G1_AFFINE).reshape(-1)
         self._gamma_offset = self.powers_of_beta_g.shape[0]
         both = np.concatenate([self.powers_of_beta_g, self.powers_of_beta_times_gamma_g])
         self._h = ctypes.c_void_p()
-        _lib.check(_lib.lib().snarkvm_hip_register_bases(ctypes.byref(self._h), ctypes.c_void_p(both.ctypes.data),
-                                                        ctypes.c_size_t(both.shape[0]), ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0)))
+        _lib.check(_lib.lib().snarkvm_hip_register_bases_tables(ctypes.byref(self._h), ctypes.c_void_p(both.ctypes.data),
+                                                               ctypes.c_size_t(both.shape[0]), ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0),
+                                                               ctypes.c_int(int(tables))))
 
     def size(self):  # data_structures.rs:163-165
         return self.powers_of_beta_g.shape[0]

@@ -62,9 +62,18 @@ def test_no_gpu_means_loud_failure_not_fallback():
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(util.ROOT, "snarkvm_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in txt.replace("the oracle is", "").lower() or f == "_never_", (dirpath, f)
+    """oracle/ is test infrastructure: nothing under snarkvm_amd/ (Python or C++/HIP) or include/ may import, include,
+    link or dlopen it; bench.py only inside its cpu_baseline leg; __graft_entry__ only in build()/smoke()."""
+    pat_py = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    pat_c = re.compile(r"#\s*include\s*[\"<][^\">]*oracle|liboracle|cpu_oracle")
+    for top in ("snarkvm_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(util.ROOT, top)):
+            for f in files:
+                path = os.path.join(dirpath, f)
+                if f.endswith(".py"):
+                    assert not pat_py.search(open(path).read()), path
+                elif f.endswith((".hip", ".cuh", ".h", ".hpp", ".cpp")):
+                    assert not pat_c.search(open(path).read()), path
+    bench = open(os.path.join(util.ROOT, "bench.py")).read()
+    first = bench.index("from oracle import")
+    assert bench.count("from oracle import") == 1 and first > bench.index("CPU baseline (rank 0, N = 1 only)")

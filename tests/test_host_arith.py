@@ -12,7 +12,7 @@ from oracle import pyref
 from snarkvm_amd import _lib, synthetic
 from tests import util
 
-OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inverse": 4, "neg": 5, "from_bigint": 6, "to_bigint": 7, "lazy_chain": 8}
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inverse": 4, "neg": 5, "from_bigint": 6, "to_bigint": 7, "lazy_chain": 8, "diff_of_products": 9}
 
 
 def _p(a):
@@ -52,6 +52,9 @@ def test_device_field_arithmetic_on_host_matches_oracle(field):
     assert np.array_equal(host_field(field, "to_bigint", a), ofn("to_bigint", a))
     nz = a[1:40]
     assert np.array_equal(host_field(field, "inverse", nz), ofn("inverse", nz))
+    # a*b - c*d with a single (signed-accumulator) Montgomery reduction, used by the XYZZ addition law
+    want = ofn("sub", ofn("mul", a, b), ofn("mul", b, ofn("add", a, b)))
+    assert np.array_equal(host_field(field, "diff_of_products", a, b), want)
     if field == 0:  # lazy add / sub / mul + final reduction (NTT butterflies) == plain product
         assert np.array_equal(host_field(field, "lazy_chain", a, b), ofn("mul", a, b))
 
