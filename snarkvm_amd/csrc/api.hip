@@ -17,6 +17,7 @@
 #include "ec.cuh"
 #include "ff.cuh"
 #include "msm.cuh"
+#include "msm_sort.cuh"
 #include "ntt.cuh"
 
 using namespace sv;
@@ -70,6 +71,7 @@ struct dev_buf {
 struct msm_ws_t {
     hipStream_t stream = nullptr;
     dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, contrib, wsum, result;
+    dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.cuh)
 };
 
 struct phase_rec {
@@ -252,6 +254,77 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
     }
     phase_end();
+    static const int sort_mode = getenv("SNARKVM_HIP_SORT") ? atoi(getenv("SNARKVM_HIP_SORT")) : 1;  // 1 = radix partition, 0 = chunk-major
+    int rounds = 0;
+    if (sort_mode == 1) {
+        // ---- 2.-4. two-level LDS-staged radix partition (msm_sort.cuh) -> bucket-major `sorted` + boff
+        msm_radix_params_t rp;
+        rp.n = n;
+        rp.c = pl.c;
+        rp.W = pl.W;
+        rp.J = pl.J;
+        rp.LB = (pl.c - 1) < 7 ? (pl.c - 1) : 7;
+        rp.HB = (pl.c - 1) - rp.LB;
+        rp.nb = pl.nb;
+        rp.tiles_per_row = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+        rp.TPW = (uint32_t)pl.J * rp.tiles_per_row;
+        const uint32_t B1 = 1u << rp.HB, B2 = 1u << rp.LB;
+        const uint32_t nbins = (uint32_t)pl.W * B1;
+        const size_t ncounts1 = (size_t)nbins * rp.TPW;
+        const size_t tiles1 = (size_t)pl.W * rp.TPW;
+        const size_t tiles2_max = E_max / SORT_TILE + nbins + 1;
+        c.counts.ensure(ncounts1 * 4);
+        c.offsets.ensure(ncounts1 * 4);
+        c.scan_tmp.ensure(scan_tmp_elems(ncounts1 > (size_t)nbt + 2 ? ncounts1 : (size_t)nbt + 2) * 4);
+        c.rv1.ensure(E_max * 4);
+        c.rl1.ensure(E_max);
+        c.rcounts2.ensure(tiles2_max * B2 * 4);
+        c.roff2.ensure(tiles2_max * B2 * 4);
+        c.rbinstart.ensure(((size_t)nbins + 2) * 4);
+        c.rntiles.ensure(((size_t)nbins + 2) * 4);
+        c.rtstart.ensure(((size_t)nbins + 2) * 4);
+        c.rbsize.ensure(((size_t)nbt + 3) * 4);
+        c.sorted.ensure(E_max * 4);
+        uint32_t* counts1 = c.counts.as<uint32_t>();
+        uint32_t* off1 = c.offsets.as<uint32_t>();
+        uint32_t* bsize = c.rbsize.as<uint32_t>();
+        uint32_t* d_max = bsize + nbt + 1;
+        uint32_t* boffp = c.boff.as<uint32_t>();
+        phase_begin("msm_sort_level1");
+        hipLaunchKernelGGL(radix_hist1_kernel, dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(), counts1, rp);
+        exclusive_scan_u32(st, counts1, off1, ncounts1, c.scan_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(radix_scatter1_kernel, dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(), counts1, off1,
+                           c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(), rp);
+        phase_end();
+        phase_begin("msm_sort_level2");
+        hipLaunchKernelGGL(radix_bin_layout_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, off1, counts1, ncounts1, c.rbinstart.as<uint32_t>(),
+                           nbins, rp.TPW);
+        hipLaunchKernelGGL(radix_bin_tiles_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, c.rbinstart.as<uint32_t>(), c.rntiles.as<uint32_t>(),
+                           nbins);
+        exclusive_scan_u32(st, c.rntiles.as<uint32_t>(), c.rtstart.as<uint32_t>(), (size_t)nbins + 1, c.scan_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(radix_hist2_kernel, dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, c.rl1.as<uint8_t>(), c.rbinstart.as<uint32_t>(),
+                           c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), nbins, rp.LB);
+        HIP_TRY(hipMemsetAsync(d_max, 0, 4, st));
+        hipLaunchKernelGGL(radix_colscan2_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(),
+                           c.rtstart.as<uint32_t>(), bsize, nbins, rp.LB, d_max);
+        exclusive_scan_u32(st, bsize, boffp, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(radix_scatter2_kernel, dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(),
+                           c.rbinstart.as<uint32_t>(), c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
+                           nbins, rp.LB);
+        phase_end();
+        uint32_t max_bucket = 0;
+        HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
+        // ---- 5. accumulate
+        phase_begin("msm_accumulate");
+        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
+        exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+        hipLaunchKernelGGL((msm_accumulate_bm_kernel<F>), dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases,
+                           (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n,
+                           table_stride);
+        phase_end();
+    } else {
     // 2.-4. counting sort by (window, bucket), chunk-major layout
     msm_sort_params_t sp;
     sp.n = n;
@@ -286,7 +359,6 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     uint32_t max_bucket = 0;
     HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    int rounds = 0;
     for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
     // 5. accumulate
     phase_begin("msm_accumulate");
@@ -312,6 +384,7 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
                                pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride, dbg_mask);
     }
     phase_end();
+    }
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
     phase_begin("msm_reduce_partials");
     uint32_t *cnt_in = c.cnt_a.as<uint32_t>(), *cnt_out = c.cnt_b.as<uint32_t>();

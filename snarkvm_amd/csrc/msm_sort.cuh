@@ -1,0 +1,245 @@
+// msm_sort.cuh - bucket sort of the MSM digit matrix by a two-level, LDS-staged radix partition.
+//
+// Why: the first sort scattered 4-byte entries with per-bucket cursors straight into HBM.  On MI355X the L2 is
+// write-through for such stores, so every entry left the chip as its own 32-byte sector: rocprofv3 WRITE_SIZE showed
+// 8.4 GiB written for 1 GiB of entries (profiles/r01_rocprofv3_pmc_hbm_bytes_final.txt).  Here every workgroup first
+// groups the entries of its tile in LDS and then writes whole runs, so the stores of a wave instruction are contiguous:
+//
+//   level 1   tile = TILE digits of one digit row; key = top HB bits of the bucket index (<= 256 bins per window)
+//             -> v1[] (virtual index | sign<<31, 4 B) and l1[] (low LB bucket bits, 1 B), grouped by (window, bin)
+//   level 2   tile = TILE items of one (window, bin) segment; key = low LB bits (<= 128 sub-buckets)
+//             -> sorted[] (4 B entries) grouped by bucket k = window * nb + bin * 2^LB + low, i.e. bucket-major,
+//                with boff[k] = first position of bucket k (the accumulate kernel then reads one contiguous run)
+//
+// Each level is histogram -> exclusive scan -> staged scatter; all positions are deterministic functions of the
+// histograms except the order inside a (tile, bin) run (LDS cursor order), which does not change any bucket's content.
+#pragma once
+#include "msm.cuh"
+
+namespace sv {
+
+static constexpr int SORT_TILE = 8192;     // items per workgroup tile
+static constexpr int SORT_THREADS = 256;   // 32 items per thread
+
+struct msm_radix_params_t {
+    size_t n;              // scalars
+    int c, W, J;           // window bits, bucket windows, base tables (digit row j*W + w feeds window w)
+    int HB, LB;            // bucket index = (bin << LB) | low, bin < 2^HB, low < 2^LB
+    uint32_t nb;           // 2^(c-1)
+    uint32_t tiles_per_row;  // ceil(n / SORT_TILE)
+    uint32_t TPW;          // level-1 tiles per window = J * tiles_per_row
+};
+
+// decode one digit: returns false for digit zero; else bucket index b (0-based) and the sign
+__device__ __forceinline__ bool digit_bucket(uint32_t u, int half, uint32_t& b, uint32_t& neg) {
+    const int dv = (int)u - half;
+    if (dv == 0) return false;
+    neg = dv < 0 ? 0x80000000u : 0u;
+    b = (uint32_t)((dv < 0 ? -dv : dv) - 1);
+    return true;
+}
+
+// ---- level 1 histogram: counts1[(w * B1 + bin) * TPW + tw]
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist1_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts1,
+                                                                   msm_radix_params_t p) {
+    __shared__ uint32_t hist[256];
+    const uint32_t B1 = 1u << p.HB;
+    const uint32_t g = blockIdx.x;            // global level-1 tile
+    const uint32_t w = g / p.TPW, tw = g - w * p.TPW;
+    const uint32_t j = tw / p.tiles_per_row, t = tw - j * p.tiles_per_row;
+    for (uint32_t i = threadIdx.x; i < B1; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)t * SORT_TILE;
+    const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
+    const int half = 1 << (p.c - 1);
+    for_each_digit(digits + (size_t)(j * p.W + w) * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
+        uint32_t b, neg;
+        if (digit_bucket(u, half, b, neg)) atomicAdd(&hist[b >> p.LB], 1u);
+    });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < B1; i += blockDim.x) counts1[((size_t)w * B1 + i) * p.TPW + tw] = hist[i];
+}
+
+// ---- level 1 scatter: stage the tile in LDS grouped by bin, then write whole runs
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint16_t* __restrict__ digits,
+                                                                      const uint32_t* __restrict__ counts1,
+                                                                      const uint32_t* __restrict__ off1, uint32_t* __restrict__ v1,
+                                                                      uint8_t* __restrict__ l1, msm_radix_params_t p) {
+    __shared__ uint32_t lcount[256], lstart[256], cursor[256], gbase[256];
+    __shared__ uint32_t sv_[SORT_TILE];
+    __shared__ uint8_t sl_[SORT_TILE], sbin_[SORT_TILE];
+    const uint32_t B1 = 1u << p.HB;
+    const uint32_t g = blockIdx.x;
+    const uint32_t w = g / p.TPW, tw = g - w * p.TPW;
+    const uint32_t j = tw / p.tiles_per_row, t = tw - j * p.tiles_per_row;
+    // this tile's histogram was computed by radix_hist1_kernel; its global run starts are off1[...]
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        lcount[i] = (i < B1) ? counts1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
+        gbase[i] = (i < B1) ? off1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
+    }
+    __syncthreads();
+    const size_t lo = (size_t)t * SORT_TILE;
+    const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
+    const int half = 1 << (p.c - 1);
+    const uint16_t* row = digits + (size_t)(j * p.W + w) * p.n;
+    if (threadIdx.x == 0) {  // 256-entry exclusive scan: negligible next to the 8192-item tile
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < B1; i++) {
+            lstart[i] = run;
+            cursor[i] = run;
+            run += lcount[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t voff = (uint32_t)((size_t)j * p.n);
+    const uint32_t lmask = (1u << p.LB) - 1;
+    for_each_digit(row, p.n, lo, hi, [&](uint32_t u, size_t i) {
+        uint32_t b, neg;
+        if (digit_bucket(u, half, b, neg)) {
+            const uint32_t bin = b >> p.LB;
+            const uint32_t pos = atomicAdd(&cursor[bin], 1u);
+            sv_[pos] = (voff + (uint32_t)i) | neg;
+            sl_[pos] = (uint8_t)(b & lmask);
+            sbin_[pos] = (uint8_t)bin;
+        }
+    });
+    __syncthreads();
+    const uint32_t total = lstart[B1 - 1] + lcount[B1 - 1];
+    for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
+        const uint32_t bin = sbin_[pos];
+        const size_t dst = (size_t)gbase[bin] + (pos - lstart[bin]);
+        v1[dst] = sv_[pos];
+        l1[dst] = sl_[pos];
+    }
+}
+
+// ---- level 2 tiling: bin q = w * B1 + bin covers [binstart[q], binstart[q+1]) of v1/l1 and gets ceil(size / TILE) tiles
+__global__ void radix_bin_layout_kernel(const uint32_t* __restrict__ off1, const uint32_t* __restrict__ counts1, size_t ncounts1,
+                                        uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t TPW) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nbins) return;
+    binstart[q] = (q < nbins) ? off1[(size_t)q * TPW] : off1[ncounts1 - 1] + counts1[ncounts1 - 1];
+}
+__global__ void radix_bin_tiles_kernel(const uint32_t* __restrict__ binstart, uint32_t* __restrict__ ntiles, uint32_t nbins) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nbins) return;
+    ntiles[q] = (q == nbins) ? 0u : (binstart[q + 1] - binstart[q] + SORT_TILE - 1) / SORT_TILE;
+}
+
+// ---- level 2 histogram: counts2[tile2 * B2 + low]
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist2_kernel(const uint8_t* __restrict__ l1, const uint32_t* __restrict__ binstart,
+                                                                   const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ counts2,
+                                                                   uint32_t nbins, int LB) {
+    __shared__ uint32_t hist[128];
+    const uint32_t t2 = blockIdx.x;
+    if (t2 >= tile2_start[nbins]) return;
+    const uint32_t B2 = 1u << LB;
+    const uint32_t q = find_bucket(tile2_start, nbins, t2);
+    const uint32_t lt = t2 - tile2_start[q];
+    for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const uint32_t lo = binstart[q] + lt * SORT_TILE;
+    uint32_t hi = lo + SORT_TILE;
+    if (hi > binstart[q + 1]) hi = binstart[q + 1];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&hist[l1[i]], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) counts2[(size_t)t2 * B2 + i] = hist[i];
+}
+// ---- per bucket k = q * B2 + low: exclusive prefix of its counts over the tiles of bin q + bucket size
+__global__ void radix_colscan2_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
+                                      const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ bsize, uint32_t nbins, int LB,
+                                      uint32_t* __restrict__ max_size) {
+    __shared__ uint32_t blk_max;
+    if (threadIdx.x == 0) blk_max = 0;
+    __syncthreads();
+    const uint32_t B2 = 1u << LB;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nbt = nbins * B2;
+    uint32_t run = 0;
+    if (k < nbt) {
+        const uint32_t q = k >> LB, low = k & (B2 - 1);
+        const uint32_t t0 = tile2_start[q], t1 = tile2_start[q + 1];
+        for (uint32_t t2 = t0; t2 < t1; t2++) {
+            const size_t idx = (size_t)t2 * B2 + low;
+            off2[idx] = run;
+            run += counts2[idx];
+        }
+    }
+    if (k <= nbt) bsize[k] = run;
+    if (run) atomicMax(&blk_max, run);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_max) atomicMax(max_size, blk_max);
+}
+// ---- level 2 scatter: sorted[boff[k] + off2[tile][low] + rank inside (tile, low)]
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint32_t* __restrict__ v1, const uint8_t* __restrict__ l1,
+                                                                      const uint32_t* __restrict__ binstart,
+                                                                      const uint32_t* __restrict__ tile2_start,
+                                                                      const uint32_t* __restrict__ counts2,
+                                                                      const uint32_t* __restrict__ off2, const uint32_t* __restrict__ boff,
+                                                                      uint32_t* __restrict__ sorted, uint32_t nbins, int LB) {
+    __shared__ uint32_t lcount[128], lstart[128], cursor[128], gbase[128];
+    __shared__ uint32_t sv_[SORT_TILE];
+    __shared__ uint8_t slow_[SORT_TILE];
+    const uint32_t t2 = blockIdx.x;
+    if (t2 >= tile2_start[nbins]) return;
+    const uint32_t B2 = 1u << LB;
+    const uint32_t q = find_bucket(tile2_start, nbins, t2);
+    const uint32_t lt = t2 - tile2_start[q];
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) {
+        lcount[i] = (i < B2) ? counts2[(size_t)t2 * B2 + i] : 0u;
+        gbase[i] = (i < B2) ? boff[(q << LB) | i] + off2[(size_t)t2 * B2 + i] : 0u;
+    }
+    __syncthreads();
+    const uint32_t lo = binstart[q] + lt * SORT_TILE;
+    uint32_t hi = lo + SORT_TILE;
+    if (hi > binstart[q + 1]) hi = binstart[q + 1];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < B2; i++) {
+            lstart[i] = run;
+            cursor[i] = run;
+            run += lcount[i];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t low = l1[i];
+        const uint32_t pos = atomicAdd(&cursor[low], 1u);
+        sv_[pos] = v1[i];
+        slow_[pos] = (uint8_t)low;
+    }
+    __syncthreads();
+    const uint32_t total = hi - lo;
+    for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
+        const uint32_t low = slow_[pos];
+        sorted[(size_t)gbase[low] + (pos - lstart[low])] = sv_[pos];
+    }
+}
+
+// ---- accumulate over bucket-major entries: bucket k owns sorted[boff[k], boff[k+1])
+template <class F>
+__global__ void __launch_bounds__(256) msm_accumulate_bm_kernel(const aff_mem_t<F>* __restrict__ bases,
+                                                                const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
+                                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
+                                                                const uint32_t* __restrict__ start, xyzz_mem_t<F>* __restrict__ partial,
+                                                                uint32_t nbt, uint32_t S, uint32_t n, size_t table_stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= start[nbt]) return;
+    const uint32_t k = find_bucket(start, nbt, t);
+    const uint32_t j = t - start[k];
+    const uint32_t lo = boff[k] + j * S;
+    uint32_t hi = lo + S;
+    if (hi > boff[k + 1]) hi = boff[k + 1];
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    for (uint32_t pos = lo; pos < hi; pos++) {
+        const uint32_t e = sorted[pos];
+        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
+        const uint32_t tbl = v / n;
+        const uint32_t idx = v - tbl * n;    // bases come in up to two segments
+        const aff_mem_t<F> raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
+        acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
+    }
+    store_xyzz<F>(&partial[t], acc);
+}
+
+}  // namespace sv
