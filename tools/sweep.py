@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Size sweep on one MI355X: G1 MSM (registered bases, 4 tables; synchronous and pipelined batch of 8) and Fr NTT
+"""Size sweep on one MI355X: G1 MSM (registered bases, 16 tables; synchronous and pipelined batch of 8) and Fr NTT
 (device resident, NN forward) for 2^14 .. 2^24.  Prints a markdown table (committed under profiles/)."""
 import ctypes
 import os
@@ -23,7 +23,7 @@ def main():
     buf = torch.empty(nmax * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     _lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(nmax)))
-    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=nmax, tables=4)
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=nmax, tables=16)
     del buf
     sc = synthetic.random_fr_integers(nmax, synthetic.SEED_MSM_LARGE)
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
