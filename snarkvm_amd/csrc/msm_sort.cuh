@@ -61,11 +61,26 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist1_kernel(const uint16_
 }
 
 // ---- level 1 scatter: stage the tile in LDS grouped by bin, then write whole runs
+// Exclusive scan over the SORT_THREADS values held one per thread (wave-level shuffles + 4 wave totals in LDS).
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_tot) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += t;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wv; k++) base += wave_tot[k];
+    return base + inc - v;
+}
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint16_t* __restrict__ digits,
                                                                       const uint32_t* __restrict__ counts1,
                                                                       const uint32_t* __restrict__ off1, uint32_t* __restrict__ v1,
                                                                       uint8_t* __restrict__ l1, msm_radix_params_t p) {
-    __shared__ uint32_t lcount[256], lstart[256], cursor[256], gbase[256];
+    __shared__ uint32_t lcount[256], lstart[256], cursor[256], gbase[256], wave_tot[4];
     __shared__ uint32_t sv_[SORT_TILE];
     __shared__ uint8_t sl_[SORT_TILE], sbin_[SORT_TILE];
     const uint32_t B1 = 1u << p.HB;
@@ -73,27 +88,32 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint
     const uint32_t w = g / p.TPW, tw = g - w * p.TPW;
     const uint32_t j = tw / p.tiles_per_row, t = tw - j * p.tiles_per_row;
     // this tile's histogram was computed by radix_hist1_kernel; its global run starts are off1[...]
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-        lcount[i] = (i < B1) ? counts1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
-        gbase[i] = (i < B1) ? off1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
-    }
-    __syncthreads();
     const size_t lo = (size_t)t * SORT_TILE;
     const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
     const int half = 1 << (p.c - 1);
     const uint16_t* row = digits + (size_t)(j * p.W + w) * p.n;
-    if (threadIdx.x == 0) {  // 256-entry exclusive scan: negligible next to the 8192-item tile
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < B1; i++) {
-            lstart[i] = run;
-            cursor[i] = run;
-            run += lcount[i];
-        }
+    // full aligned tile: issue this thread's four 16-byte digit loads before anything else
+    const bool vec = (p.n & 7) == 0 && hi - lo == SORT_TILE;
+    constexpr int NV = SORT_TILE / 8 / SORT_THREADS;
+    uint4 dq[NV];
+    if (vec) {
+        const uint4* d4 = (const uint4*)(row + lo);
+#pragma unroll
+        for (int k = 0; k < NV; k++) dq[k] = d4[threadIdx.x + k * SORT_THREADS];
+    }
+    {
+        const uint32_t i = threadIdx.x;  // SORT_THREADS == 256 >= B1: one bin per thread
+        const uint32_t cnt = (i < B1) ? counts1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
+        gbase[i] = (i < B1) ? off1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
+        lcount[i] = cnt;
+        const uint32_t start = block_excl_scan(cnt, wave_tot);
+        lstart[i] = start;
+        cursor[i] = start;
     }
     __syncthreads();
     const uint32_t voff = (uint32_t)((size_t)j * p.n);
     const uint32_t lmask = (1u << p.LB) - 1;
-    for_each_digit(row, p.n, lo, hi, [&](uint32_t u, size_t i) {
+    auto place = [&](uint32_t u, size_t i) {
         uint32_t b, neg;
         if (digit_bucket(u, half, b, neg)) {
             const uint32_t bin = b >> p.LB;
@@ -102,7 +122,21 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint
             sl_[pos] = (uint8_t)(b & lmask);
             sbin_[pos] = (uint8_t)bin;
         }
-    });
+    };
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const uint32_t wds[4] = {dq[k].x, dq[k].y, dq[k].z, dq[k].w};
+            const size_t i = lo + ((size_t)(threadIdx.x + k * SORT_THREADS) << 3);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                place(wds[m] & 0xffffu, i + 2 * m);
+                place(wds[m] >> 16, i + 2 * m + 1);
+            }
+        }
+    } else {
+        for_each_digit(row, p.n, lo, hi, place);
+    }
     __syncthreads();
     const uint32_t total = lstart[B1 - 1] + lcount[B1 - 1];
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
@@ -177,7 +211,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
                                                                       const uint32_t* __restrict__ counts2,
                                                                       const uint32_t* __restrict__ off2, const uint32_t* __restrict__ boff,
                                                                       uint32_t* __restrict__ sorted, uint32_t nbins, int LB) {
-    __shared__ uint32_t lcount[128], lstart[128], cursor[128], gbase[128];
+    __shared__ uint32_t lcount[128], lstart[128], cursor[128], gbase[128], wave_tot[4];
     __shared__ uint32_t sv_[SORT_TILE];
     __shared__ uint8_t slow_[SORT_TILE];
     const uint32_t t2 = blockIdx.x;
@@ -185,28 +219,41 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
     const uint32_t B2 = 1u << LB;
     const uint32_t q = find_bucket(tile2_start, nbins, t2);
     const uint32_t lt = t2 - tile2_start[q];
-    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) {
-        lcount[i] = (i < B2) ? counts2[(size_t)t2 * B2 + i] : 0u;
-        gbase[i] = (i < B2) ? boff[(q << LB) | i] + off2[(size_t)t2 * B2 + i] : 0u;
-    }
-    __syncthreads();
     const uint32_t lo = binstart[q] + lt * SORT_TILE;
     uint32_t hi = lo + SORT_TILE;
     if (hi > binstart[q + 1]) hi = binstart[q + 1];
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < B2; i++) {
-            lstart[i] = run;
-            cursor[i] = run;
-            run += lcount[i];
+    {
+        const uint32_t i = threadIdx.x;  // one low-bits value per thread (B2 <= 128 < SORT_THREADS)
+        const uint32_t cnt = (i < B2) ? counts2[(size_t)t2 * B2 + i] : 0u;
+        const uint32_t start = block_excl_scan(cnt, wave_tot);
+        if (i < 128) {
+            lcount[i] = cnt;
+            gbase[i] = (i < B2) ? boff[(q << LB) | i] + off2[(size_t)t2 * B2 + i] : 0u;
+            lstart[i] = start;
+            cursor[i] = start;
         }
     }
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t low = l1[i];
-        const uint32_t pos = atomicAdd(&cursor[low], 1u);
-        sv_[pos] = v1[i];
-        slow_[pos] = (uint8_t)low;
+    {
+        // all of a thread's global loads are issued before the first LDS atomic (32 items per thread)
+        constexpr int PER = SORT_TILE / SORT_THREADS;
+        uint32_t lv[PER];
+        uint32_t ll[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t i = lo + threadIdx.x + (uint32_t)k * SORT_THREADS;
+            const bool ok = i < hi;
+            lv[k] = ok ? v1[i] : 0u;
+            ll[k] = ok ? (uint32_t)l1[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (ll[k] != 0xffffffffu) {
+                const uint32_t pos = atomicAdd(&cursor[ll[k]], 1u);
+                sv_[pos] = lv[k];
+                slow_[pos] = (uint8_t)ll[k];
+            }
+        }
     }
     __syncthreads();
     const uint32_t total = hi - lo;
