@@ -127,6 +127,34 @@ RustError snarkvm_hip_msm_g2(void *out, const void *points_with_infinity, size_t
 RustError snarkvm_hip_fr_mul_device(void *d_out, const void *d_a, const void *d_b, size_t n);
 RustError snarkvm_hip_fr_convert_device(void *d_out, const void *d_in, size_t n, int to_bigint);
 
+/* Prover-round Fr vector kernels: the O(n) passes the Varuna prover runs between its NTTs and commitments
+ * (SURVEY.md 8f N2, and the `open` half of KZG10).  Vectors are Fr elements in the reference's memory form
+ * (32 B, Montgomery); with on_device = 1 every vector pointer is device memory on the context's device, otherwise host
+ * memory (staged through HBM by the call).  Scalar operands (`scalar`, `point`, `coeff`, `g`, `c`, `tau`) and the
+ * `remainder` of divide_by_linear are always 32-byte HOST values.
+ *
+ * fr_vec_op: op 0 out = a + b | 1 a - b | 2 a * b | 3 a * b - c (round_functions/second.rs:110-111: rowcheck)
+ *            | 4 a * scalar | 5 a - scalar (kzg10/mod.rs:295) | 6 a + b * scalar (second.rs:113) | 7 scalar - a. */
+RustError snarkvm_hip_fr_vec_op(int op, void *out, const void *a, const void *b, const void *c, const void *scalar,
+                                size_t n, int on_device);
+/* `polynomial / (X - point)` and `polynomial.evaluate(point)` in one pass (KZG10::compute_witness_polynomial,
+ * kzg10/mod.rs:213-236 via polynomial/mod.rs:222-256; DensePolynomial::evaluate, dense.rs:98-114): quotient gets
+ * n - 1 coefficients (may be NULL when only the value is wanted), *remainder = p(point). */
+RustError snarkvm_hip_fr_divide_by_linear(void *quotient, void *remainder, const void *poly, size_t n,
+                                          const void *point, int on_device);
+/* batch_inversion_and_mul (fields/src/lib.rs:66-129): v_i <- coeff / v_i, zero elements stay zero. */
+RustError snarkvm_hip_fr_batch_inversion_and_mul(void *inout, size_t n, const void *coeff, int on_device);
+/* EvaluationDomain::distribute_powers_and_mul_by_const (fft/domain.rs:224-254): v_i <- v_i * c * g^i. */
+RustError snarkvm_hip_fr_distribute_powers(void *inout, size_t n, const void *g, const void *c, int on_device);
+/* EvaluationDomain::evaluate_all_lagrange_coefficients (fft/domain.rs:258-292) for the 2^lg domain. */
+RustError snarkvm_hip_fr_lagrange_coefficients(void *out, uint32_t lg_domain_size, const void *tau, int on_device);
+/* DensePolynomial::divide_by_vanishing_poly (dense.rs:161-169): division of `len` coefficients by X^domain_size - 1.
+ * quotient: len - domain_size coefficients (untouched when len <= domain_size); remainder: min(len, domain_size). */
+RustError snarkvm_hip_fr_divide_by_vanishing(void *quotient, void *remainder, const void *poly, size_t len,
+                                             size_t domain_size, int on_device);
+/* DensePolynomial::mul_by_vanishing_poly (dense.rs:153-159): out (len + domain_size coefficients) = p * (X^D - 1). */
+RustError snarkvm_hip_fr_mul_by_vanishing(void *out, const void *poly, size_t len, size_t domain_size, int on_device);
+
 /* Synthetic base set for benchmarks: out[i] = (start + i) * G as Rust G1Affine (104 B stride) in
  * device memory. */
 RustError snarkvm_hip_g1_generate_bases_device(void *d_out, uint64_t start, size_t npoints);

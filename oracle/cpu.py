@@ -187,3 +187,70 @@ def g1_gen_bases(gen_affine, start, n):
     out = np.zeros(n, dtype=G1_AFFINE)
     lib().oracle_g1_gen_bases(_p(gen_affine), ctypes.c_uint64(start), ctypes.c_size_t(n), _p(out))
     return out
+
+
+# ---- prover-round polynomial helpers (SURVEY.md §8 N2, a15 `open`) ----
+VEC_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_sub": 3, "scale": 4, "sub_scalar": 5, "axpy": 6}
+
+
+def _fr(x):
+    return np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+
+
+def fr_vec_op(op, a, b, c=None):
+    a, b = _fr(a), _fr(b)
+    c = b if c is None else _fr(c)
+    out = np.empty_like(a)
+    lib().oracle_fr_vec_op(ctypes.c_int(VEC_OPS[op]), _p(a), _p(b), _p(c), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def poly_divide(poly, divisor_terms):
+    """Polynomial::divide_with_q_and_r; divisor_terms = [(degree, coeff limbs)], sorted.  Returns (quotient, remainder), trimmed."""
+    poly = _fr(poly)
+    n = poly.shape[0]
+    deg = (ctypes.c_size_t * len(divisor_terms))(*[d for d, _ in divisor_terms])
+    cf = _fr(np.stack([np.asarray(c, dtype=np.uint64).reshape(4) for _, c in divisor_terms]))
+    q = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    r = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    ql, rl = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = lib().oracle_fr_poly_divide(_p(poly), ctypes.c_size_t(n), deg, _p(cf), ctypes.c_size_t(len(divisor_terms)), _p(q),
+                                     ctypes.byref(ql), _p(r), ctypes.byref(rl))
+    if rc:
+        raise ZeroDivisionError("Dividing by zero polynomial is undefined")
+    return q[: ql.value].copy(), r[: rl.value].copy()
+
+
+def poly_evaluate(poly, point):
+    poly = _fr(poly)
+    point = _fr(point)
+    out = np.zeros((1, 4), dtype=np.uint64)
+    lib().oracle_fr_evaluate(_p(poly), ctypes.c_size_t(poly.shape[0]), _p(point), _p(out))
+    return out
+
+
+def batch_inversion_and_mul(v, coeff):
+    v = np.array(v, dtype=np.uint64, copy=True).reshape(-1, 4)
+    lib().oracle_fr_batch_inversion_and_mul(_p(v), ctypes.c_size_t(v.shape[0]), _p(_fr(coeff)))
+    return v
+
+
+def distribute_powers(v, g, c):
+    v = np.array(v, dtype=np.uint64, copy=True).reshape(-1, 4)
+    lib().oracle_fr_distribute_powers(_p(v), ctypes.c_size_t(v.shape[0]), _p(_fr(g)), _p(_fr(c)))
+    return v
+
+
+def lagrange_coefficients(lg, tau):
+    out = np.zeros((1 << lg, 4), dtype=np.uint64)
+    rc = lib().oracle_fr_lagrange_coefficients(ctypes.c_uint32(lg), _p(_fr(tau)), _p(out))
+    if rc:
+        raise ValueError("domain too large")
+    return out
+
+
+def mul_by_vanishing(poly, domain_size):
+    poly = _fr(poly)
+    out = np.zeros((poly.shape[0] + domain_size, 4), dtype=np.uint64)
+    lib().oracle_fr_mul_by_vanishing(_p(poly), ctypes.c_size_t(poly.shape[0]), ctypes.c_size_t(domain_size), _p(out))
+    return out

@@ -1070,6 +1070,111 @@ static void set_threads(int nthreads) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Prover-round polynomial helpers around the NTTs (SURVEY.md §8 N2 / a15 `open`)
+// ---------------------------------------------------------------------------------------------
+static void trim(std::vector<Fr>& v) {  // DensePolynomial::from_coefficients_vec (dense.rs:76-86)
+    while (!v.empty() && v.back().is_zero()) v.pop_back();
+}
+// Polynomial::divide_with_q_and_r (fft/polynomial/mod.rs:222-256): schoolbook long division.  The divisor is a list
+// of (degree, coefficient) terms sorted by degree (SparsePolynomial) - a dense divisor is the same list with every
+// degree present.  Returns false for a zero divisor.
+static bool divide_with_q_and_r(std::vector<Fr> self, const std::vector<std::pair<size_t, Fr>>& divisor, std::vector<Fr>& quotient,
+                                std::vector<Fr>& remainder) {
+    trim(self);
+    if (divisor.empty()) return false;
+    const size_t ddeg = divisor.back().first;
+    quotient.clear();
+    if (self.empty()) {
+        remainder.clear();
+        return true;
+    }
+    if (self.size() - 1 < ddeg) {
+        remainder = self;
+        return true;
+    }
+    quotient.assign(self.size() - 1 - ddeg + 1, Fr::zero());
+    remainder = self;
+    const Fr lead_inv = divisor.back().second.inverse();
+    while (!remainder.empty() && remainder.size() - 1 >= ddeg) {
+        const Fr cur_q = remainder.back() * lead_inv;
+        const size_t cur_deg = remainder.size() - 1 - ddeg;
+        quotient[cur_deg] = cur_q;
+        for (auto& t : divisor) remainder[cur_deg + t.first] -= cur_q * t.second;
+        trim(remainder);
+    }
+    trim(quotient);
+    return true;
+}
+// DensePolynomial::evaluate (dense.rs:98-114): sum of coeff_i * point^i
+static Fr poly_evaluate(const Fr* c, size_t n, const Fr& point) {
+    std::vector<Fr> v(c, c + n);
+    trim(v);
+    if (v.empty()) return Fr::zero();
+    if (point.is_zero()) return v[0];
+    Fr acc = Fr::zero(), pw = Fr::one();
+    for (size_t i = 0; i < v.size(); i++) {
+        acc += pw * v[i];
+        pw *= point;
+    }
+    return acc;
+}
+// fields/src/lib.rs:99-129 (serial_batch_inversion_and_mul): zeros are skipped and stay zero.  The rayon version
+// (:77-93) applies the same function per chunk; every non-zero element becomes coeff / v_i either way.
+static void batch_inversion_and_mul(Fr* v, size_t n, const Fr& coeff) {
+    std::vector<Fr> prod;
+    prod.reserve(n);
+    Fr tmp = Fr::one();
+    for (size_t i = 0; i < n; i++)
+        if (!v[i].is_zero()) {
+            tmp *= v[i];
+            prod.push_back(tmp);
+        }
+    if (prod.empty()) return;
+    tmp = tmp.inverse();
+    tmp *= coeff;
+    size_t k = prod.size();
+    for (size_t i = n; i-- > 0;) {
+        if (v[i].is_zero()) continue;
+        k--;
+        const Fr s = k ? prod[k - 1] : Fr::one();
+        const Fr new_tmp = tmp * v[i];
+        v[i] = tmp * s;
+        tmp = new_tmp;
+    }
+}
+// EvaluationDomain::evaluate_all_lagrange_coefficients (fft/domain.rs:258-292)
+static void evaluate_all_lagrange_coefficients(const EvaluationDomain& d, const Fr& tau, Fr* u) {
+    const size_t size = d.size;
+    uint64_t e[1] = {d.size};
+    const Fr t_size = tau.pow(e, 1);
+    const Fr one = Fr::one();
+    if (t_size.is_one()) {
+        for (size_t i = 0; i < size; i++) u[i] = Fr::zero();
+        Fr omega_i = one;
+        for (size_t i = 0; i < size; i++) {
+            if (omega_i == tau) {
+                u[i] = one;
+                break;
+            }
+            omega_i *= d.group_gen;
+        }
+    } else {
+        Fr l = (t_size - one) * d.size_inv;
+        Fr r = one;
+        std::vector<Fr> ls(size);
+        for (size_t i = 0; i < size; i++) {
+            u[i] = tau - r;
+            ls[i] = l;
+            l *= d.group_gen;
+            r *= d.group_gen;
+        }
+        batch_inversion_and_mul(u, size, one);
+        for (size_t i = 0; i < size; i++) u[i] = ls[i] * u[i];
+    }
+}
+
 extern "C" {
 int oracle_max_threads() { return (int)max_threads(); }
 void oracle_set_threads(int n) { set_threads(n); }
@@ -1123,6 +1228,65 @@ int oracle_ntt(uint64_t* inout, uint32_t lg, int order, int dir, int type) {
 int oracle_polymul(uint64_t* out, size_t pcount, const uint64_t* const* polys, const size_t* plens, size_t ecount,
                    const uint64_t* const* evals, const size_t* elens, uint32_t lg) {
     return polymul_ref((Fr*)out, pcount, (const Fr* const*)polys, plens, ecount, (const Fr* const*)evals, elens, lg);
+}
+
+// ---- prover-round polynomial helpers ----
+// op: 0 a+b, 1 a-b, 2 a*b, 3 a*b-c, 4 a*b[0], 5 a-b[0], 6 a+b*c[0]
+void oracle_fr_vec_op(int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n) {
+    const Fr *A = (const Fr*)a, *B = (const Fr*)b, *C = (const Fr*)c;
+    Fr* O = (Fr*)out;
+    for (size_t i = 0; i < n; i++) {
+        switch (op) {
+            case 0: O[i] = A[i] + B[i]; break;
+            case 1: O[i] = A[i] - B[i]; break;
+            case 2: O[i] = A[i] * B[i]; break;
+            case 3: O[i] = A[i] * B[i] - C[i]; break;
+            case 4: O[i] = A[i] * B[0]; break;
+            case 5: O[i] = A[i] - B[0]; break;
+            case 6: O[i] = A[i] + B[i] * C[0]; break;
+        }
+    }
+}
+// Long division by a divisor given as `terms` (degree, coefficient) pairs.  quot / rem must hold n elements; their
+// trimmed lengths are returned through qlen / rlen.  Returns 1 for a zero divisor.
+int oracle_fr_poly_divide(const uint64_t* poly, size_t n, const size_t* div_deg, const uint64_t* div_coeff, size_t terms, uint64_t* quot,
+                          size_t* qlen, uint64_t* rem, size_t* rlen) {
+    std::vector<Fr> self((const Fr*)poly, (const Fr*)poly + n), q, r;
+    std::vector<std::pair<size_t, Fr>> d;
+    for (size_t i = 0; i < terms; i++) {
+        const Fr cf = ((const Fr*)div_coeff)[i];
+        if (!cf.is_zero()) d.push_back({div_deg[i], cf});
+    }
+    if (!divide_with_q_and_r(self, d, q, r)) return 1;
+    if (!q.empty()) memcpy(quot, q.data(), q.size() * sizeof(Fr));
+    if (!r.empty()) memcpy(rem, r.data(), r.size() * sizeof(Fr));
+    *qlen = q.size();
+    *rlen = r.size();
+    return 0;
+}
+void oracle_fr_evaluate(const uint64_t* poly, size_t n, const uint64_t* point, uint64_t* out) {
+    const Fr v = poly_evaluate((const Fr*)poly, n, *(const Fr*)point);
+    memcpy(out, &v, sizeof v);
+}
+void oracle_fr_batch_inversion_and_mul(uint64_t* v, size_t n, const uint64_t* coeff) {
+    batch_inversion_and_mul((Fr*)v, n, *(const Fr*)coeff);
+}
+void oracle_fr_distribute_powers(uint64_t* v, size_t n, const uint64_t* g, const uint64_t* c) {
+    distribute_powers_and_mul_by_const((Fr*)v, n, *(const Fr*)g, *(const Fr*)c);
+}
+int oracle_fr_lagrange_coefficients(uint32_t lg, const uint64_t* tau, uint64_t* out) {
+    EvaluationDomain d;
+    if (!EvaluationDomain::make((size_t)1 << lg, d)) return 1;
+    evaluate_all_lagrange_coefficients(d, *(const Fr*)tau, (Fr*)out);
+    return 0;
+}
+// DensePolynomial::mul_by_vanishing_poly (dense.rs:153-159): out has len + domain elements (untrimmed)
+void oracle_fr_mul_by_vanishing(const uint64_t* poly, size_t len, size_t domain, uint64_t* out) {
+    const Fr* p = (const Fr*)poly;
+    Fr* o = (Fr*)out;
+    for (size_t i = 0; i < domain; i++) o[i] = Fr::zero();
+    for (size_t i = 0; i < len; i++) o[domain + i] = p[i];
+    for (size_t i = 0; i < len; i++) o[i] -= p[i];
 }
 
 // ---- G1 ----

@@ -19,6 +19,7 @@
 #include "msm.cuh"
 #include "msm_sort.cuh"
 #include "ntt.cuh"
+#include "poly.cuh"
 
 using namespace sv;
 
@@ -89,6 +90,7 @@ struct context_t {
     dev_buf tables_mem;
     // NTT staging
     dev_buf ntt_data, ntt_scratch, ntt_acc;
+    dev_buf poly[5];  // staging / scratch of the prover-round vector kernels (poly.cuh)
     // MSM workspaces: lane 0 runs on the main stream; lanes 1.. are used by the batch API so that the latency-bound
     // tail of one MSM (bucket reduction, Horner) overlaps the throughput-bound accumulation of the next
     static constexpr int LANES = 3;
@@ -784,6 +786,233 @@ RustError snarkvm_hip_fr_convert_device(void* d_out, const void* d_in, size_t n,
         const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(blocks), dim3(256), 0, g_ctx.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_in, n, to_bigint);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+// ---- prover-round polynomial kernels (poly.cuh) ---------------------------------------------------
+static fr_mem_t fr_mem_from_host(const void* p) {
+    fr_mem_t m;
+    memcpy(&m, p, sizeof m);
+    return m;
+}
+static unsigned fr_grid(size_t n, unsigned block = 256) {
+    const size_t b = (n + block - 1) / block;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+// operand `p` (n elements) as a device pointer: itself, or a staged copy in ctx.poly[slot]
+static fr_mem_t* fr_stage_in(int slot, const void* p, size_t n, int on_device) {
+    if (on_device || !p) return (fr_mem_t*)p;
+    g_ctx.poly[slot].ensure(sizeof(fr_mem_t) * (n ? n : 1));
+    if (n) HIP_TRY(hipMemcpyAsync(g_ctx.poly[slot].p, p, sizeof(fr_mem_t) * n, hipMemcpyHostToDevice, g_ctx.stream));
+    return g_ctx.poly[slot].as<fr_mem_t>();
+}
+static fr_mem_t* fr_stage_out(int slot, void* p, size_t n, int on_device) {
+    if (on_device || !p) return (fr_mem_t*)p;
+    g_ctx.poly[slot].ensure(sizeof(fr_mem_t) * (n ? n : 1));
+    return g_ctx.poly[slot].as<fr_mem_t>();
+}
+static void fr_finish_out(fr_mem_t* d, void* p, size_t n, int on_device) {
+    if (!on_device && p && n) HIP_TRY(hipMemcpyAsync(p, d, sizeof(fr_mem_t) * n, hipMemcpyDeviceToHost, g_ctx.stream));
+}
+
+RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b, const void* c, const void* scalar, size_t n, int on_device) {
+    API_BEGIN
+    if (op < 0 || op > FR_OP_RSUB_SCALAR) throw hip_failure{hipErrorInvalidValue, "fr_vec_op: unknown op", __LINE__};
+    const bool need_b = op == FR_OP_ADD || op == FR_OP_SUB || op == FR_OP_MUL || op == FR_OP_MUL_SUB || op == FR_OP_AXPY;
+    const bool need_c = op == FR_OP_MUL_SUB;
+    const bool need_s = op == FR_OP_SCALE || op == FR_OP_SUB_SCALAR || op == FR_OP_AXPY || op == FR_OP_RSUB_SCALAR;
+    if (n && (!out || !a || (need_b && !b) || (need_c && !c) || (need_s && !scalar)))
+        throw hip_failure{hipErrorInvalidValue, "fr_vec_op: missing operand", __LINE__};
+    if (n) {
+        fr_mem_t s{};
+        if (need_s) s = fr_mem_from_host(scalar);
+        const fr_mem_t* da = fr_stage_in(0, a, n, on_device);
+        const fr_mem_t* db = need_b ? fr_stage_in(1, b, n, on_device) : nullptr;
+        const fr_mem_t* dc = need_c ? fr_stage_in(2, c, n, on_device) : nullptr;
+        fr_mem_t* dout = fr_stage_out(3, out, n, on_device);
+        hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, g_ctx.stream, op, dout, da, db, dc, s, n);
+        HIP_TRY(hipGetLastError());
+        fr_finish_out(dout, out, n, on_device);
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+// out[i - shift] = h_i = sum_{k >= i} in[k] m^(k - i) (and *first = h_0 when shift == 1); `out` may be null (only h_0 wanted).
+// Scratch for the chunk values of every level lives in ctx.poly[4].
+static void fr_suffix_horner(const fr_mem_t* d_in, size_t n, const fr_mem_t& m, fr_mem_t* d_out, int shift, fr_mem_t* d_first) {
+    hipStream_t st = g_ctx.stream;
+    int levels = 1;
+    size_t total = 0;
+    for (size_t t = n; t > 1;) {
+        t = (t + POLY_CHUNK - 1) / POLY_CHUNK;
+        total += t;
+        levels++;
+    }
+    g_ctx.poly[4].ensure(sizeof(fr_mem_t) * (total + levels + 2));
+    fr_mem_t* mult = g_ctx.poly[4].as<fr_mem_t>();
+    fr_mem_t* cvbase = mult + levels + 1;
+    hipLaunchKernelGGL(fr_horner_multipliers_kernel, dim3(1), dim3(1), 0, st, m, mult, levels);
+    // up-sweep: level k holds the chunk values of level k - 1 (level 0 = the input)
+    std::vector<const fr_mem_t*> in_at{d_in};
+    std::vector<size_t> n_at{n};
+    fr_mem_t* next = cvbase;
+    while (n_at.back() > 1) {
+        const size_t cur = n_at.back();
+        const size_t T = (cur + POLY_CHUNK - 1) / POLY_CHUNK;
+        const int k = (int)n_at.size() - 1;
+        hipLaunchKernelGGL(fr_horner_up_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, in_at.back(), cur, mult + k, next, T);
+        in_at.push_back(next);
+        n_at.push_back(T);
+        next += T;
+    }
+    // the single value of the top level is h_0 of every level below; down-sweep turns each level's chunk values into
+    // its suffix sums in place, the input level writes to `out`
+    const int top = (int)n_at.size() - 1;
+    for (int k = top; k >= 0; k--) {
+        const size_t cur = n_at[k];
+        const size_t T = (cur + POLY_CHUNK - 1) / POLY_CHUNK;
+        const fr_mem_t* carry = (k < top) ? in_at[k + 1] : nullptr;
+        if (k > 0) {
+            if (k == top) continue;  // one element: it already is its own suffix sum
+            hipLaunchKernelGGL(fr_horner_down_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, in_at[k], cur, mult + k, carry, T,
+                               (fr_mem_t*)in_at[k], 0, (fr_mem_t*)nullptr);
+        } else if (d_out) {
+            hipLaunchKernelGGL(fr_horner_down_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, d_in, cur, mult, carry, T, d_out, shift,
+                               d_first);
+        } else if (d_first) {
+            // only h_0: the value of the top level, or of the lone input element
+            HIP_TRY(hipMemcpyAsync(d_first, top > 0 ? in_at[top] : d_in, sizeof(fr_mem_t), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+RustError snarkvm_hip_fr_divide_by_linear(void* quotient, void* remainder, const void* poly, size_t n, const void* point, int on_device) {
+    API_BEGIN
+    if (!point || (n && !poly)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_linear: missing operand", __LINE__};
+    if (n == 0) {
+        if (remainder) memset(remainder, 0, sizeof(fr_mem_t));
+    } else {
+        const fr_mem_t z = fr_mem_from_host(point);
+        const fr_mem_t* din = fr_stage_in(0, poly, n, on_device);
+        fr_mem_t* dq = (quotient && n > 1) ? fr_stage_out(1, quotient, n - 1, on_device) : nullptr;
+        g_ctx.poly[2].ensure(sizeof(fr_mem_t));
+        fr_mem_t* drem = g_ctx.poly[2].as<fr_mem_t>();
+        fr_suffix_horner(din, n, z, dq, 1, drem);
+        if (dq) fr_finish_out(dq, quotient, n - 1, on_device);
+        if (remainder) HIP_TRY(hipMemcpyAsync(remainder, drem, sizeof(fr_mem_t), hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+static void fr_batch_inverse_run(fr_mem_t* d_v, size_t n, const fr_mem_t& coeff) {
+    // >= 32 elements per thread amortise the per-thread Fermat inversion; cap the thread count for huge vectors
+    size_t T = (n + 31) / 32;
+    if (T > (size_t)1 << 17) T = (size_t)1 << 17;
+    g_ctx.poly[4].ensure(sizeof(fr_mem_t) * n);
+    hipLaunchKernelGGL(fr_batch_inverse_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, g_ctx.stream, d_v, n, coeff, g_ctx.poly[4].as<fr_mem_t>(), T);
+    HIP_TRY(hipGetLastError());
+}
+RustError snarkvm_hip_fr_batch_inversion_and_mul(void* inout, size_t n, const void* coeff, int on_device) {
+    API_BEGIN
+    if (n) {
+        if (!inout || !coeff) throw hip_failure{hipErrorInvalidValue, "fr_batch_inversion_and_mul: missing operand", __LINE__};
+        fr_mem_t* dv = fr_stage_in(0, inout, n, on_device);
+        fr_batch_inverse_run(dv, n, fr_mem_from_host(coeff));
+        fr_finish_out(dv, inout, n, on_device);
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+static void fr_distribute_powers_run(fr_mem_t* d_v, size_t n, const fr_mem_t& g, const fr_mem_t& c) {
+    size_t T = (n + 31) / 32;
+    if (T > (size_t)1 << 17) T = (size_t)1 << 17;
+    hipLaunchKernelGGL(fr_distribute_powers_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, g_ctx.stream, d_v, n, g, c, T);
+    HIP_TRY(hipGetLastError());
+}
+RustError snarkvm_hip_fr_distribute_powers(void* inout, size_t n, const void* g, const void* c, int on_device) {
+    API_BEGIN
+    if (n) {
+        if (!inout || !g || !c) throw hip_failure{hipErrorInvalidValue, "fr_distribute_powers: missing operand", __LINE__};
+        fr_mem_t* dv = fr_stage_in(0, inout, n, on_device);
+        fr_distribute_powers_run(dv, n, fr_mem_from_host(g), fr_mem_from_host(c));
+        fr_finish_out(dv, inout, n, on_device);
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+
+// TWO_ADIC_ROOT_OF_UNITY (fr.rs:115-120), memory form - the host copy of ntt.cuh's device table
+static const uint32_t FR_TWO_ADIC_ROOT_MEM_HOST[8] = {0xda3ad648u, 0xaf80da4du, 0xfc381dacu, 0x5e223adbu,
+                                                      0xb2f92525u, 0x03ba0666u, 0x3befb0ceu, 0x0f906c5bu};
+RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const void* tau, int on_device) {
+    API_BEGIN
+    if (lg > 30) throw hip_failure{hipErrorInvalidValue, "fr_lagrange_coefficients: lg_domain_size > 30", __LINE__};
+    if (!out || !tau) throw hip_failure{hipErrorInvalidValue, "fr_lagrange_coefficients: missing operand", __LINE__};
+    const size_t n = (size_t)1 << lg;
+    // scalar set-up with the same arithmetic compiled for the host (domain.rs:118-147, 258-264)
+    fr_t omega = fr_t::unpack(FR_TWO_ADIC_ROOT_MEM_HOST).from_mem_mont();
+    for (uint32_t i = lg; i < 47; i++) omega = omega.sqr();
+    const fr_mem_t tau_mem = fr_mem_from_host(tau);
+    const fr_t tau_i = fr_t::load(&tau_mem).from_mem_mont();
+    const fr_t t_size = tau_i.pow_u64((uint64_t)n);
+    fr_mem_t one_mem, omega_mem;
+    fr_t::one().to_mem_mont().store(&one_mem);
+    omega.to_mem_mont().store(&omega_mem);
+    fr_mem_t* du = fr_stage_out(0, out, n, on_device);
+    hipStream_t st = g_ctx.stream;
+    hipLaunchKernelGGL(fr_fill_kernel, dim3(fr_grid(n)), dim3(256), 0, st, du, n, one_mem);
+    fr_distribute_powers_run(du, n, omega_mem, one_mem);  // u_i = omega^i
+    if (t_size == fr_t::one()) {
+        hipLaunchKernelGGL(fr_onehot_kernel, dim3(fr_grid(n)), dim3(256), 0, st, du, n, tau_mem, one_mem);
+    } else {
+        fr_mem_t l_mem;
+        ((t_size - fr_t::one()) * fr_t::from_u32((uint32_t)n).inverse()).to_mem_mont().store(&l_mem);
+        hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, st, (int)FR_OP_RSUB_SCALAR, du, (const fr_mem_t*)du, (const fr_mem_t*)nullptr,
+                           (const fr_mem_t*)nullptr, tau_mem, n);  // tau - omega^i
+        fr_batch_inverse_run(du, n, one_mem);
+        fr_distribute_powers_run(du, n, omega_mem, l_mem);  // * l * omega^i
+    }
+    HIP_TRY(hipGetLastError());
+    fr_finish_out(du, out, n, on_device);
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    API_END
+}
+
+RustError snarkvm_hip_fr_divide_by_vanishing(void* quotient, void* remainder, const void* poly, size_t len, size_t domain_size, int on_device) {
+    API_BEGIN
+    if (domain_size == 0) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_vanishing: empty domain", __LINE__};
+    if (len) {
+        if (!poly || !remainder || (len > domain_size && !quotient)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_vanishing: missing operand", __LINE__};
+        const size_t qlen = len > domain_size ? len - domain_size : 0;
+        const size_t rlen = len < domain_size ? len : domain_size;
+        const fr_mem_t* din = fr_stage_in(0, poly, len, on_device);
+        fr_mem_t* dq = qlen ? fr_stage_out(1, quotient, qlen, on_device) : nullptr;
+        fr_mem_t* dr = fr_stage_out(2, remainder, rlen, on_device);
+        const size_t threads = qlen > rlen ? qlen : rlen;
+        hipLaunchKernelGGL(fr_fold_vanishing_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g_ctx.stream, din, len, domain_size, dq, dr);
+        HIP_TRY(hipGetLastError());
+        if (qlen) fr_finish_out(dq, quotient, qlen, on_device);
+        fr_finish_out(dr, remainder, rlen, on_device);
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+RustError snarkvm_hip_fr_mul_by_vanishing(void* out, const void* poly, size_t len, size_t domain_size, int on_device) {
+    API_BEGIN
+    const size_t olen = len + domain_size;
+    if (olen) {
+        if (!out || (len && !poly)) throw hip_failure{hipErrorInvalidValue, "fr_mul_by_vanishing: missing operand", __LINE__};
+        const fr_mem_t* din = fr_stage_in(0, poly, len, on_device);
+        fr_mem_t* dout = fr_stage_out(1, out, olen, on_device);
+        hipLaunchKernelGGL(fr_mul_vanishing_kernel, dim3((unsigned)((olen + 255) / 256)), dim3(256), 0, g_ctx.stream, din, len, domain_size, dout);
+        HIP_TRY(hipGetLastError());
+        fr_finish_out(dout, out, olen, on_device);
         HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     }
     API_END

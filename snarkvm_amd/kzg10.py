@@ -1,4 +1,4 @@
-"""`KZG10::{commit, commit_lagrange}` (algorithms/src/polycommit/kzg10/mod.rs:98-206) on the gfx950 backend.
+"""`KZG10::{commit, commit_lagrange, open, open_lagrange}` (algorithms/src/polycommit/kzg10/mod.rs:98-322) on the gfx950 backend.
 
 The committer key's base vectors (`powers_of_beta_g`, `powers_of_beta_times_gamma_g`; data_structures.rs:151-181) are
 registered ONCE in HBM in the kernels' native format - the reference's GPU path re-uploads 104 B/point on every call
@@ -12,12 +12,16 @@ with `skip_leading_zeros_and_convert_to_bigints` (mod.rs:455-474) split into a h
 projective commitment; `KZGCommitment(commitment.into())` is one affine normalisation (`to_affine`).
 
 Degree-bounded commitments (sonic_pc) use the same call with `powers` = the shifted powers slice.
+
+An opening (mod.rs:213-322) is the quotient by (X - point) - a device suffix-Horner pass that also yields p(point)
+(poly.divide_by_linear) - followed by the same fused MSM over the witness polynomial and, when hiding, the quotient of
+the blinding polynomial over the gamma powers.
 """
 import ctypes
 
 import numpy as np
 
-from . import _lib
+from . import _lib, poly
 from .layout import G1_AFFINE, G1_PROJECTIVE
 
 
@@ -72,6 +76,21 @@ class KZGRandomness:
     @classmethod
     def empty(cls):
         return cls()
+
+    def is_hiding(self):  # data_structures.rs:335-337: the blinding polynomial is non-zero
+        return bool(np.asarray(self.blinding_polynomial).any())
+
+
+class KZGProof:
+    """data_structures.rs:395-430: w = commitment to the witness polynomial (G1Affine record),
+    random_v = evaluation of the blinding polynomial at the point ((1, 4) Montgomery limbs) or None."""
+
+    def __init__(self, w, random_v=None):
+        self.w = w
+        self.random_v = random_v
+
+    def is_hiding(self):
+        return self.random_v is not None
 
 
 class KZG10:
@@ -132,3 +151,72 @@ class KZG10:
             ctypes.c_size_t(lagrange_basis._gamma_offset), ctypes.c_size_t(blind.shape[0]),
             ctypes.c_void_p(np.ascontiguousarray(scalars).ctypes.data), ctypes.c_int(0), ctypes.c_int(1), ctypes.c_int(0)))
         return out, randomness
+
+    @staticmethod
+    def compute_witness_polynomial(coeffs, point, randomness):
+        """mod.rs:213-236: (p / (X - point), blinding_p / (X - point) if hiding else None); remainders are dropped."""
+        witness, _ = poly.divide_by_linear(coeffs, point)
+        random_witness = None
+        if randomness.is_hiding():
+            random_witness, _ = poly.divide_by_linear(randomness.blinding_polynomial, point)
+        return witness, random_witness
+
+    @staticmethod
+    def open_with_witness_polynomial(powers, point, randomness, witness_polynomial, hiding_witness_polynomial=None):
+        """mod.rs:238-270.  One fused MSM: witness coefficients over powers_of_beta_g[lz..], the hiding witness over
+        powers_of_beta_times_gamma_g; `to_affine` gives KZGProof.w."""
+        witness = poly.trim(witness_polynomial)
+        degree = max(witness.shape[0] - 1, 0)
+        if degree + 1 > powers.size():  # check_degree_is_too_large (mod.rs:407-415)
+            raise PCError(f"TooManyCoefficients: {degree + 1} > {powers.size()}")
+        nz = np.nonzero(witness.any(axis=1))[0]
+        lz, plain = (0, witness[:0]) if nz.size == 0 else (int(nz[0]), witness[int(nz[0]):])
+        random_v = None
+        blind = np.zeros((0, 4), dtype=np.uint64)
+        if hiding_witness_polynomial is not None:
+            random_v = poly.evaluate(randomness.blinding_polynomial, point)  # blinding_p.evaluate(point), mod.rs:254
+            blind = np.ascontiguousarray(hiding_witness_polynomial, dtype=np.uint64).reshape(-1, 4)  # untrimmed: convert_to_bigints(&coeffs)
+            if blind.shape[0] > powers.powers_of_beta_times_gamma_g.shape[0]:
+                raise PCError("HidingBoundToolarge")
+        scalars = np.concatenate([plain, blind]) if blind.shape[0] else plain
+        out = np.zeros(1, dtype=G1_PROJECTIVE)
+        _lib.check(_lib.lib().snarkvm_hip_msm_registered_ex(
+            ctypes.c_void_p(out.ctypes.data), powers._h, ctypes.c_size_t(lz), ctypes.c_size_t(plain.shape[0]),
+            ctypes.c_size_t(powers._gamma_offset), ctypes.c_size_t(blind.shape[0]),
+            ctypes.c_void_p(np.ascontiguousarray(scalars).ctypes.data), ctypes.c_int(0), ctypes.c_int(1), ctypes.c_int(0)))
+        return KZGProof(to_affine(out)[0], random_v)
+
+    @staticmethod
+    def open(powers, coeffs, point, rand):
+        """mod.rs:304-322."""
+        coeffs = poly.trim(coeffs)
+        degree = max(coeffs.shape[0] - 1, 0)
+        if degree + 1 > powers.size():
+            raise PCError(f"TooManyCoefficients: {degree + 1} > {powers.size()}")
+        witness, hiding_witness = KZG10.compute_witness_polynomial(coeffs, point, rand)
+        return KZG10.open_with_witness_polynomial(powers, point, rand, witness, hiding_witness)
+
+    @staticmethod
+    def open_lagrange(lagrange_basis, domain_elements, evaluations, point, evaluation_at_point):
+        """mod.rs:274-301: witness evaluations (e_i - v) / (omega_i - point) by one batch inversion, then commit_lagrange.
+        Raises when the point lies in the domain (a zero divisor evaluation)."""
+        evaluations = np.ascontiguousarray(evaluations, dtype=np.uint64).reshape(-1, 4)
+        domain_elements = np.ascontiguousarray(domain_elements, dtype=np.uint64).reshape(-1, 4)
+        if max(evaluations.shape[0] - 1, 0) + 1 > lagrange_basis.size():
+            raise PCError("TooManyCoefficients")
+        divisor_evals = poly.vec_op("sub_scalar", domain_elements, scalar=point)
+        if not divisor_evals.any(axis=1).all():
+            raise PCError("Point cannot be in the domain")
+        size = 1
+        while size < evaluations.shape[0]:
+            size <<= 1
+        if size != lagrange_basis.size():
+            raise PCError("`evaluations.len()` must equal `domain.size()`")
+        if divisor_evals.shape[0] != evaluations.shape[0]:
+            raise PCError("length mismatch")
+        one = np.array([[0x7d1c7ffffffffff3, 0x7257f50f6ffffff2, 0x16d81575512c0fee, 0x0d4bda322bbb9a9d]], dtype=np.uint64)  # Fr R (fr.rs:158-163)
+        divisor_evals = poly.batch_inversion_and_mul(divisor_evals, one)
+        numer = poly.vec_op("sub_scalar", evaluations, scalar=evaluation_at_point)
+        witness_evals = poly.vec_op("mul", divisor_evals, numer)
+        comm, _ = KZG10.commit_lagrange(lagrange_basis, witness_evals, None, None)
+        return KZGProof(to_affine(comm)[0], None)

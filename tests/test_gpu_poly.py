@@ -1,0 +1,189 @@
+"""Parity of the prover-round polynomial kernels (snarkvm_amd/csrc/poly.cuh through the C ABI) and of KZG10::open
+against the oracle, on a real MI355X.  Bit-exact: Fr results are unique Montgomery residues."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import cpu as oracle
+from snarkvm_amd import _lib, kzg10, poly, synthetic
+from tests import util
+from tests.test_gpu_parity import _srs
+
+pytestmark = pytest.mark.gpu
+
+ONE = None
+
+
+def _rnd(n, seed):
+    return oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, seed)) if n else np.zeros((0, 4), dtype=np.uint64)
+
+
+def _one():
+    return util.ints_to_fr_mont([1])
+
+
+def _linear_divisor(point):
+    minus = oracle.fr_op("neg", np.asarray(point, dtype=np.uint64).reshape(1, 4))[0]
+    return [(0, minus), (1, _one()[0])]
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1000, 1024, 1025, 32 * 32 + 1, 70001, 1 << 18])
+def test_vec_ops(n):
+    a, b, c = _rnd(n, 1), _rnd(n, 2), _rnd(n, 3)
+    s = _rnd(1, 4)
+    for op in ("add", "sub", "mul", "mul_sub"):
+        assert np.array_equal(poly.vec_op(op, a, b, c), oracle.fr_vec_op(op, a, b, c)), op
+    assert np.array_equal(poly.vec_op("scale", a, scalar=s), oracle.fr_vec_op("scale", a, s))
+    assert np.array_equal(poly.vec_op("sub_scalar", a, scalar=s), oracle.fr_vec_op("sub_scalar", a, s))
+    assert np.array_equal(poly.vec_op("axpy", a, b, scalar=s), oracle.fr_vec_op("axpy", a, b, s))
+    assert np.array_equal(poly.vec_op("rsub_scalar", a, scalar=s), oracle.fr_op("neg", oracle.fr_vec_op("sub_scalar", a, s)))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 64, 1023, 1024, 1025, 32 * 32 * 32 + 5, 100003, 1 << 18])
+def test_divide_by_linear_and_evaluate(n):
+    """polynomial / (X - z) (kzg10/mod.rs:213-236) and DensePolynomial::evaluate (dense.rs:98-114)."""
+    a = _rnd(n, 10 + n)
+    z = _rnd(1, 5)
+    q, rem = poly.divide_by_linear(a, z)
+    wq, wr = oracle.poly_divide(a, _linear_divisor(z))
+    assert np.array_equal(q, wq)
+    want_val = oracle.poly_evaluate(a, z)
+    assert np.array_equal(rem, want_val)
+    assert np.array_equal(poly.evaluate(a, z), want_val)
+    if wr.shape[0]:
+        assert np.array_equal(wr, want_val)  # remainder theorem
+
+
+def test_divide_by_linear_special_points():
+    a = _rnd(5000, 77)
+    a[-3:] = 0  # untrimmed input
+    for z in (np.zeros((1, 4), dtype=np.uint64), _one(), oracle.fr_op("neg", _one())):
+        q, rem = poly.divide_by_linear(a, z)
+        wq, _ = oracle.poly_divide(a, _linear_divisor(z))
+        assert np.array_equal(q, wq)
+        assert np.array_equal(rem, oracle.poly_evaluate(a, z))
+    # exact division: (X - z) * q has remainder zero
+    z = _rnd(1, 6)
+    q = _rnd(3000, 8)
+    prod = oracle.polymul(12, [q, np.stack([_linear_divisor(z)[0][1], _one()[0]])])
+    got_q, rem = poly.divide_by_linear(prod, z)
+    assert np.array_equal(got_q, q) and not rem.any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1000, 4096, 70001, 1 << 18])
+def test_batch_inversion_and_mul(n):
+    v = _rnd(n, 20 + n)
+    for z in (0, 5, 17, n - 1, n // 2):
+        if n > 3 and z < n:
+            v[z] = 0
+    coeff = _rnd(1, 21)
+    assert np.array_equal(poly.batch_inversion_and_mul(v, coeff), oracle.batch_inversion_and_mul(v, coeff))
+    assert np.array_equal(poly.batch_inversion_and_mul(v, _one()), oracle.batch_inversion_and_mul(v, _one()))
+
+
+def test_batch_inversion_all_zero_and_roundtrip():
+    z = np.zeros((100, 4), dtype=np.uint64)
+    assert not poly.batch_inversion_and_mul(z, _one()).any()
+    v = _rnd(5000, 31)
+    inv = poly.batch_inversion_and_mul(v, _one())
+    assert np.array_equal(poly.vec_op("mul", v, inv), np.tile(_one(), (5000, 1)))
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 5000, 1 << 16, (1 << 18) + 7])
+def test_distribute_powers(n):
+    v = _rnd(n, 40 + n)
+    g, c = _rnd(1, 41), _rnd(1, 42)
+    assert np.array_equal(poly.distribute_powers_and_mul_by_const(v, g, c), oracle.distribute_powers(v, g, c))
+
+
+@pytest.mark.parametrize("lg", [0, 1, 2, 5, 6, 10, 16])
+def test_evaluate_all_lagrange_coefficients(lg):
+    tau = _rnd(1, 50 + lg)
+    assert np.array_equal(poly.evaluate_all_lagrange_coefficients(1 << lg, tau), oracle.lagrange_coefficients(lg, tau))
+    # tau in the domain: one-hot branch
+    gen = oracle.domain(lg)[0:1]
+    k = (1 << lg) * 3 // 4
+    tau_in = oracle.distribute_powers(np.tile(_one(), ((1 << lg), 1)), gen, _one())[k : k + 1]
+    got = poly.evaluate_all_lagrange_coefficients(1 << lg, tau_in)
+    assert np.array_equal(got, oracle.lagrange_coefficients(lg, tau_in))
+    assert np.array_equal(got[k], _one()[0]) and int(got.any(axis=1).sum()) == 1
+
+
+@pytest.mark.parametrize("n,D", [(5, 8), (8, 8), (9, 8), (16, 8), (40, 8), (3 * 4096 + 17, 4096), (1 << 17, 1 << 16), ((1 << 17) + 5, 1 << 16)])
+def test_divide_and_mul_by_vanishing(n, D):
+    a = _rnd(n, 60 + n)
+    q, r = poly.divide_by_vanishing_poly(a, D)
+    wq, wr = oracle.poly_divide(a, [(0, oracle.fr_op("neg", _one())[0]), (D, _one()[0])])
+    assert np.array_equal(q, wq) and np.array_equal(r, wr)
+    m = poly.mul_by_vanishing_poly(a, D)
+    assert np.array_equal(m, poly.trim(oracle.mul_by_vanishing(a, D)))
+    q2, r2 = poly.divide_by_vanishing_poly(m, D)
+    assert np.array_equal(q2, poly.trim(a)) and r2.shape[0] == 0
+
+
+def test_varuna_h0_on_device(golden):
+    """KAT-polymul16 end to end on the device: (iNTT(z_a) * iNTT(z_b) - iNTT(z_c)) / (X^8 - 1) == h_0.txt."""
+    from snarkvm_amd import fft
+    from tests.test_oracle import _kat_polymul16
+
+    z_a, z_b, z_c, h_0 = _kat_polymul16(golden)
+    dom = fft.EvaluationDomain.new(8)
+    ca, cb, cc = (dom.ifft(util.ints_to_fr_mont(v)) for v in (z_a, z_b, z_c))
+    m = fft.PolyMultiplier()
+    m.add_polynomial(poly.trim(ca), "z_a")
+    m.add_polynomial(poly.trim(cb), "z_b")
+    rowcheck = m.multiply()
+    cpad = np.zeros_like(rowcheck)
+    cpad[: cc.shape[0]] = cc[: rowcheck.shape[0]]
+    rowcheck = poly.vec_op("sub", rowcheck, cpad)
+    q, r = poly.divide_by_vanishing_poly(rowcheck, 8)
+    assert r.shape[0] == 0
+    assert util.fr_mont_to_ints(q) == h_0
+
+
+def test_kzg10_open_matches_reference_formula(golden):
+    """KZG10::open (kzg10/mod.rs:304-322): w = commit(p / (X - z)) [+ commit_gamma(blinding / (X - z))], random_v =
+    blinding(z); against the oracle's long division + CPU MSM."""
+    n = 2500
+    powers_g = _srs(golden, n)
+    gamma_g = oracle.g1_gen_bases(util.g1_generator_affine(), 11, 8)
+    pw = kzg10.Powers(powers_g, gamma_g)
+    coeffs = _rnd(n, 4243)
+    point = _rnd(1, 4244)
+    blind = _rnd(3, 4245)
+    for hiding in (False, True):
+        rand = kzg10.KZGRandomness(blind) if hiding else kzg10.KZGRandomness.empty()
+        proof = kzg10.KZG10.open(pw, coeffs, point, rand)
+        wq, _ = oracle.poly_divide(coeffs, _linear_divisor(point))
+        want = oracle.g1_msm(powers_g, oracle.fr_op("to_bigint", wq), oracle.MSM_BATCHED)
+        if hiding:
+            bq, _ = oracle.poly_divide(blind, _linear_divisor(point))
+            want = oracle.g1_add(want, oracle.g1_msm(gamma_g, oracle.fr_op("to_bigint", bq), oracle.MSM_BATCHED))
+            assert np.array_equal(proof.random_v, oracle.poly_evaluate(blind, point))
+        else:
+            assert proof.random_v is None
+        assert util.affine_equal(np.array([proof.w]), oracle.g1_to_affine(want))
+    with pytest.raises(kzg10.PCError):
+        kzg10.KZG10.open(pw, _rnd(n + 1, 1), point, kzg10.KZGRandomness.empty())
+    pw.close()
+
+
+def test_kzg10_open_lagrange(golden):
+    """KZG10::open_lagrange (kzg10/mod.rs:274-301) over a stand-in Lagrange basis."""
+    lg = 9
+    n = 1 << lg
+    basis_g = _srs(golden, n)
+    pw = kzg10.Powers(basis_g, oracle.g1_gen_bases(util.g1_generator_affine(), 3, 2))
+    gen = oracle.domain(lg)[0:1]
+    elems = oracle.distribute_powers(np.tile(_one(), (n, 1)), gen, _one())
+    evals = _rnd(n, 9001)
+    point, value = _rnd(1, 9002), _rnd(1, 9003)
+    proof = kzg10.KZG10.open_lagrange(pw, elems, evals, point, value)
+    div = oracle.batch_inversion_and_mul(oracle.fr_vec_op("sub_scalar", elems, point), _one())
+    wit = oracle.fr_vec_op("mul", div, oracle.fr_vec_op("sub_scalar", evals, value))
+    want = oracle.g1_msm(basis_g, oracle.fr_op("to_bigint", wit), oracle.MSM_BATCHED)
+    assert util.affine_equal(np.array([proof.w]), oracle.g1_to_affine(want)) and proof.random_v is None
+    with pytest.raises(kzg10.PCError):
+        kzg10.KZG10.open_lagrange(pw, elems, evals, elems[5:6], value)
+    pw.close()
