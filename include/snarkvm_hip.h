@@ -88,6 +88,20 @@ RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t **handle, const 
                                             size_t ffi_affine_sz, int on_device, int tables);
 void snarkvm_hip_free_bases(snarkvm_hip_bases_t *handle);
 
+/* The reference's canonical encoding of G1 points (curves/src/templates/macros.rs:66-140, utilities/src/serialize/
+ * flags.rs:72-99) decoded / encoded on the device: uncompressed = x, y as 48-byte little-endian canonical integers with
+ * the infinity flag in bit 6 of the last byte (96 B; the body of a `.usrs` SRS file after its u64 count); compressed =
+ * x with bit 7 = "y is the larger root", bit 6 = infinity (48 B; y recovered by a square root, affine.rs:140-150).
+ * validate = 1 additionally checks curve and prime-order-subgroup membership (`Valid::check`, macros.rs:106-113).
+ * Errors (both flag bits set, coordinate >= q, no square root, failed validation) return a non-zero code and name the
+ * SerializationError in the message.
+ * register_bases_serialized: bytes (host) -> a registered base vector, never materialising the Rust layout. */
+RustError snarkvm_hip_register_bases_serialized(snarkvm_hip_bases_t **handle, const void *bytes, size_t npoints,
+                                                int compressed, int validate, int tables);
+/* bytes (host) -> Rust `[G1Affine]` (104 B stride, host) and back. */
+RustError snarkvm_hip_g1_deserialize(void *out_affine, const void *bytes, size_t n, int compressed, int validate);
+RustError snarkvm_hip_g1_serialize(void *out_bytes, const void *affine, size_t n, size_t ffi_affine_sz, int compressed);
+
 /* MSM over registered bases [offset, offset + npoints).  `scalars` in host (scalars_on_device = 0) or
  * device memory.  `out` is a 144-byte host buffer (Jacobian, as snarkvm_msm).  `window_bits` = 0 picks
  * the window size automatically. */

@@ -245,3 +245,89 @@ def horner(coeffs, x):
     for c in reversed(coeffs):
         acc = (acc * x + c) % R_MOD
     return acc
+
+
+# ---------------------------------------------------------------------------------------------
+# Canonical serialisation of G1 points (curves/src/templates/macros.rs:66-140,
+# fields/src/macros.rs:187-282, utilities/src/serialize/flags.rs:72-99)
+# ---------------------------------------------------------------------------------------------
+class SerializationError(ValueError):
+    pass
+
+
+def fq_sqrt(a):
+    """A square root of a in Fq or None (Tonelli-Shanks; the reference's sqrt_impl, fields/src/macros.rs:85-180, may
+    return the other root - callers select by comparison, affine.rs:144-148)."""
+    a %= Q_MOD
+    if a == 0:
+        return 0
+    if pow(a, (Q_MOD - 1) // 2, Q_MOD) != 1:
+        return None
+    s, t = 0, Q_MOD - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (Q_MOD - 1) // 2, Q_MOD) != Q_MOD - 1:
+        z += 1
+    c, x, b, m = pow(z, t, Q_MOD), pow(a, (t + 1) // 2, Q_MOD), pow(a, t, Q_MOD), s
+    while b != 1:
+        k, b2 = 0, b
+        while b2 != 1:
+            b2, k = b2 * b2 % Q_MOD, k + 1
+        w = pow(c, 1 << (m - k - 1), Q_MOD)
+        c, x, b, m = w * w % Q_MOD, x * w % Q_MOD, b * w * w % Q_MOD, k
+    return x
+
+
+def g1_serialize(p, compressed):
+    """p = (x, y) canonical ints or None (infinity).  macros.rs:66-97."""
+    if compressed:
+        if p is None:
+            x, flags = 0, 1 << 6
+        else:
+            x, flags = p[0], (1 << 7) if p[1] > (-p[1]) % Q_MOD else 0  # SWFlags::from_y_sign(y > -y)
+        b = bytearray(x.to_bytes(48, "little"))
+        b[47] |= flags
+        return bytes(b)
+    x, y, flags = (0, 1, 1 << 6) if p is None else (p[0], p[1], 0)  # Affine::zero() = (0, 1, infinity)
+    b = bytearray(x.to_bytes(48, "little") + y.to_bytes(48, "little"))
+    b[95] |= flags
+    return bytes(b)
+
+
+def _read_fq_with_flags(b):
+    """deserialize_with_flags::<SWFlags> (fields/src/macros.rs:255-281, flags.rs:87-98): (value, positive, infinity)."""
+    b = bytearray(b)
+    pos, inf = (b[47] >> 7) & 1, (b[47] >> 6) & 1
+    if pos and inf:
+        raise SerializationError("UnexpectedFlags")
+    b[47] &= 0x3F
+    v = int.from_bytes(b, "little")
+    if v >= Q_MOD:
+        raise SerializationError("coordinate >= q")
+    return v, bool(pos), bool(inf)
+
+
+def g1_deserialize(b, compressed, validate=False):
+    """macros.rs:115-140.  Returns (x, y) canonical ints or None for infinity."""
+    if compressed:
+        x, pos, inf = _read_fq_with_flags(b[:48])
+        if inf:
+            return None
+        y = fq_sqrt((x * x * x + G1_B) % Q_MOD)
+        if y is None:
+            raise SerializationError("InvalidData")
+        ny = (-y) % Q_MOD
+        y = y if (y < ny) != pos else ny  # affine.rs:147
+        p = (x, y)
+    else:
+        x = int.from_bytes(b[:48], "little")
+        if x >= Q_MOD:
+            raise SerializationError("coordinate >= q")
+        y, _, inf = _read_fq_with_flags(b[48:96])
+        if inf:
+            return None
+        p = (x, y)
+    if validate and not (g1_is_on_curve(p) and g1_mul(p, R_MOD) is None):
+        raise SerializationError("InvalidData")
+    return p

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,7 @@
 #include "msm_sort.cuh"
 #include "ntt.cuh"
 #include "poly.cuh"
+#include "serde.cuh"
 
 using namespace sv;
 
@@ -90,6 +92,7 @@ struct context_t {
     dev_buf tables_mem;
     // NTT staging
     dev_buf ntt_data, ntt_scratch, ntt_acc;
+    dev_buf serde_status;  // one u32 of SERDE_* bits (serde.cuh)
     dev_buf poly[5];  // staging / scratch of the prover-round vector kernels (poly.cuh)
     // MSM workspaces: lane 0 runs on the main stream; lanes 1.. are used by the batch API so that the latency-bound
     // tail of one MSM (bucket reduction, Horner) overlaps the throughput-bound accumulation of the next
@@ -645,6 +648,13 @@ RustError snarkvm_hip_msm_g2(void* out, const void* points, size_t npoints, cons
     API_END
 }
 
+// tables 1 .. J-1 of a registered base vector: table j = 2^(256 / J) * table j-1
+static void precompute_tables(snarkvm_hip_bases* h) {
+    for (int j = 1; j < h->tables; j++)
+        hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, g_ctx.stream,
+                           h->d + (size_t)(j - 1) * h->n, h->d + (size_t)j * h->n, h->n, 256 / h->tables);
+    HIP_TRY(hipGetLastError());
+}
 static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables) {
     if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
     if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
@@ -662,13 +672,89 @@ static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points
             src = g_ctx.bases_tmp.as<uint8_t>();
         }
         convert_bases<fq_t>(g_ctx, src, ffi_affine_sz, npoints, h->d);
-        for (int j = 1; j < tables; j++)
-            hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, g_ctx.stream,
-                               h->d + (size_t)(j - 1) * npoints, h->d + (size_t)j * npoints, npoints, 256 / tables);
-        HIP_TRY(hipGetLastError());
+        precompute_tables(h);
         HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     }
     *handle = h;
+}
+
+// ---- canonical (de)serialisation of G1 points (serde.cuh) ---------------------------------------
+static void serde_throw_on_status(uint32_t st, const char* who) {
+    if (!st) return;
+    std::string m = std::string(who) + ":";
+    if (st & SERDE_BAD_FLAGS) m += " UnexpectedFlags (both flag bits set)";
+    if (st & SERDE_NOT_CANONICAL) m += " coordinate >= q";
+    if (st & SERDE_NOT_ON_CURVE) m += " InvalidData (point not on the curve)";
+    if (st & SERDE_NOT_IN_SUBGROUP) m += " InvalidData (point not in the prime-order subgroup)";
+    throw std::runtime_error(m);  // SerializationError: surfaces as RustError code 1 with this message
+}
+// bytes (host) -> native base slots and / or Rust-layout records (both device); returns the SERDE_* status bits
+static uint32_t g1_deserialize_run(const void* bytes, size_t n, int compressed, int validate, g1_aff_mem_t* d_native, uint8_t* d_rust) {
+    const size_t psz = compressed ? 48 : 96;
+    g_ctx.bases_tmp.ensure(n * psz);
+    g_ctx.serde_status.ensure(4);
+    HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, bytes, n * psz, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipMemsetAsync(g_ctx.serde_status.p, 0, 4, g_ctx.stream));
+    hipLaunchKernelGGL(g1_deserialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, g_ctx.bases_tmp.as<uint8_t>(), n, compressed,
+                       validate, d_native, d_rust, g_ctx.serde_status.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, g_ctx.serde_status.p, 4, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    return st;
+}
+RustError snarkvm_hip_register_bases_serialized(snarkvm_hip_bases_t** handle, const void* bytes, size_t npoints, int compressed, int validate,
+                                                int tables) {
+    API_BEGIN
+    if (!handle || (npoints && !bytes)) throw hip_failure{hipErrorInvalidValue, "register_bases_serialized: null argument", __LINE__};
+    if (tables != 1 && tables != 2 && tables != 4 && tables != 8 && tables != 16)
+        throw hip_failure{hipErrorInvalidValue, "register_bases_serialized: tables must be 1, 2, 4, 8 or 16", __LINE__};
+    snarkvm_hip_bases* h = new snarkvm_hip_bases();
+    h->n = npoints;
+    h->tables = tables;
+    if (npoints) {
+        try {
+            HIP_TRY(hipMalloc((void**)&h->d, (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
+            serde_throw_on_status(g1_deserialize_run(bytes, npoints, compressed, validate, h->d, nullptr), "register_bases_serialized");
+            precompute_tables(h);
+            HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        } catch (...) {
+            if (h->d) (void)hipFree(h->d);
+            delete h;
+            throw;
+        }
+    }
+    *handle = h;
+    API_END
+}
+RustError snarkvm_hip_g1_deserialize(void* out_affine, const void* bytes, size_t n, int compressed, int validate) {
+    API_BEGIN
+    if (n) {
+        if (!out_affine || !bytes) throw hip_failure{hipErrorInvalidValue, "g1_deserialize: null argument", __LINE__};
+        g_ctx.poly[0].ensure(n * 104);
+        const uint32_t st = g1_deserialize_run(bytes, n, compressed, validate, nullptr, g_ctx.poly[0].as<uint8_t>());
+        serde_throw_on_status(st, "g1_deserialize");
+        HIP_TRY(hipMemcpyAsync(out_affine, g_ctx.poly[0].p, n * 104, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
+RustError snarkvm_hip_g1_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz, int compressed) {
+    API_BEGIN
+    if (n) {
+        if (!out_bytes || !affine) throw hip_failure{hipErrorInvalidValue, "g1_serialize: null argument", __LINE__};
+        if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "g1_serialize: bad stride", __LINE__};
+        const size_t psz = compressed ? 48 : 96;
+        g_ctx.bases_tmp.ensure(n * ffi_affine_sz);
+        g_ctx.poly[0].ensure(n * psz);
+        HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, affine, n * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
+        hipLaunchKernelGGL(g1_serialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, g_ctx.bases_tmp.as<uint8_t>(), ffi_affine_sz, n,
+                           compressed, g_ctx.poly[0].as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_bytes, g_ctx.poly[0].p, n * psz, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
 }
 RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
     API_BEGIN

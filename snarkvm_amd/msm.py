@@ -39,6 +39,18 @@ class RegisteredBases:
                                                       ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0), ctypes.c_int(self.tables))
         _lib.check(err)
 
+    @classmethod
+    def from_serialized(cls, data, npoints, compressed=False, validate=False, tables=1):
+        """Register bases straight from their canonical encoding (e.g. the body of a `.usrs` SRS file): the bytes are
+        decoded on the device into the engine's base slots (snarkvm_hip_register_bases_serialized)."""
+        from . import serialize
+
+        self = cls.__new__(cls)
+        self.tables = int(tables)
+        self.n = int(npoints)
+        self._h = serialize.register_bases_serialized(data, npoints, compressed, validate, tables)
+        return self
+
     def msm(self, scalars=None, offset=0, device_ptr=None, npoints=None, window_bits=0):
         """sum_i scalars[i] * bases[offset + i]; scalars either a host (n,4) u64 array or a device pointer."""
         L = _lib.lib()

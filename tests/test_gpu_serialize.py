@@ -1,0 +1,83 @@
+"""Device (de)serialisation of G1 points (snarkvm_amd/csrc/serde.cuh through the C ABI) against the Python oracle and
+the real SRS bytes, on an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import cpu as oracle
+from oracle import pyref
+from snarkvm_amd import serialize, synthetic
+from snarkvm_amd.msm import RegisteredBases
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_usrs_bytes_decode_on_device(golden):
+    raw = bytes(golden["srs_g1"])
+    n = len(raw) // 96
+    got = serialize.g1_deserialize(raw, compressed=False)
+    want = util.g1_affine_from_ints(util.srs_points_ints(raw, n))
+    assert util.affine_equal(got, want)
+    assert util.g1_affine_to_ints(got[:1])[0] == pyref.G1_GEN
+    # the reference's `Valid::check` (on curve + prime-order subgroup) holds for real SRS points
+    assert util.affine_equal(serialize.g1_deserialize(raw[: 96 * 64], compressed=False, validate=True), want[:64])
+    # and encoding is the inverse
+    assert serialize.g1_serialize(got, compressed=False) == raw
+
+
+def test_compressed_roundtrip_matches_oracle(golden):
+    pts = util.srs_points_ints(golden["srs_g1"], 200)
+    pts = pts + [pyref.g1_neg(p) for p in pts[:50]] + [None, None]
+    aff = util.g1_affine_from_ints(pts)
+    comp = serialize.g1_serialize(aff, compressed=True)
+    assert comp == b"".join(pyref.g1_serialize(p, True) for p in pts)
+    back = serialize.g1_deserialize(comp, compressed=True)
+    assert util.affine_equal(back, aff)
+    unc = serialize.g1_serialize(aff, compressed=False)
+    assert unc == b"".join(pyref.g1_serialize(p, False) for p in pts)
+    assert util.affine_equal(serialize.g1_deserialize(unc, compressed=False), aff)
+
+
+def test_decode_errors_on_device():
+    gen = pyref.g1_serialize(pyref.G1_GEN, compressed=True)
+    bad = bytearray(gen)
+    bad[47] |= 0xC0
+    with pytest.raises(serialize.SerializationError):
+        serialize.g1_deserialize(gen + bytes(bad), compressed=True)
+    with pytest.raises(serialize.SerializationError):
+        serialize.g1_deserialize(pyref.Q_MOD.to_bytes(48, "little"), compressed=True)
+    x = 1
+    while pyref.fq_sqrt((x ** 3 + 1) % pyref.Q_MOD) is not None:
+        x += 1
+    with pytest.raises(serialize.SerializationError):
+        serialize.g1_deserialize(x.to_bytes(48, "little"), compressed=True)
+    x = 2
+    while True:
+        y = pyref.fq_sqrt((x ** 3 + 1) % pyref.Q_MOD)
+        if y is not None and pyref.g1_mul((x, y), pyref.R_MOD) is not None:
+            break
+        x += 1
+    enc = pyref.g1_serialize((x, y), compressed=False)
+    assert util.g1_affine_to_ints(serialize.g1_deserialize(enc, compressed=False)) == [(x, y)]
+    with pytest.raises(serialize.SerializationError):
+        serialize.g1_deserialize(enc, compressed=False, validate=True)
+    with pytest.raises(serialize.SerializationError):  # off-curve
+        serialize.g1_deserialize((5).to_bytes(48, "little") + (7).to_bytes(48, "little"), compressed=False, validate=True)
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_msm_over_bases_registered_from_bytes(golden, compressed):
+    """SRS bytes -> device base slots -> MSM, equal to the oracle's MSM over the decoded points."""
+    raw = bytes(golden["srs_g1"])
+    n = len(raw) // 96
+    pts = util.srs_points_ints(raw, n)
+    aff = util.g1_affine_from_ints(pts)
+    data = b"".join(pyref.g1_serialize(p, True) for p in pts) if compressed else raw
+    scalars = synthetic.random_fr_integers(n, 606)
+    want = oracle.g1_to_affine(oracle.g1_msm(aff, scalars))
+    for tables in (1, 16):
+        rb = RegisteredBases.from_serialized(data, n, compressed=compressed, tables=tables)
+        assert util.affine_equal(oracle.g1_to_affine(rb.msm(scalars)), want)
+        rb.close()
+    count, body = serialize.split_usrs(len(pts).to_bytes(8, "little") + raw)
+    assert count == n and bytes(body) == raw

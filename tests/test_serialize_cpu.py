@@ -1,0 +1,78 @@
+"""Canonical G1 encoding: the Python oracle (oracle/pyref.py) against the real SRS bytes committed under tests/golden,
+and the constants of snarkvm_amd/csrc/serde.cuh re-derived from the reference's field parameters."""
+import os
+import re
+
+import pytest
+
+from oracle import pyref
+from tests import util
+
+
+def _words(src, name):
+    m = re.search(name + r"\[\d+\] = \{(.*?)\}", src, re.S)
+    vals = [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-fA-F]+u?", m.group(1))]
+    return sum(v << (32 * i) for i, v in enumerate(vals))
+
+
+def test_serde_constants_match_reference(golden):
+    src = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "serde.cuh")).read()
+    fq = golden["constants"]["fq"]
+    q = pyref.from_limbs(fq["MODULUS"])
+    t = pyref.from_limbs(fq["T"])
+    assert q - 1 == t << fq["TWO_ADICITY"] and fq["TWO_ADICITY"] == 46
+    assert _words(src, "FQ_T_MINUS_ONE_DIV_TWO") == (t - 1) // 2
+    root = pyref.fq_from_mont(pyref.from_limbs(fq["TWO_ADIC_ROOT_OF_UNITY"]))
+    assert _words(src, "FQ_TWO_ADIC_ROOT_INT") == root
+    assert pow(root, 1 << 46, q) == 1 and pow(root, 1 << 45, q) == q - 1
+    assert _words(src, "FR_MODULUS_WORDS") == pyref.from_limbs(golden["constants"]["fr"]["MODULUS"])
+
+
+def test_real_srs_bytes_decode_to_curve_points(golden):
+    """powers-of-beta-15.usrs: point 0 is the G1 generator, every decoded point is on the curve, re-encoding is the identity."""
+    raw = golden["srs_g1"]
+    pts = [pyref.g1_deserialize(raw[96 * i : 96 * i + 96], compressed=False) for i in range(64)]
+    assert pts[0] == pyref.G1_GEN
+    assert all(pyref.g1_is_on_curve(p) for p in pts)
+    assert pts == util.srs_points_ints(raw, 64)
+    for i, p in enumerate(pts):
+        assert pyref.g1_serialize(p, compressed=False) == bytes(raw[96 * i : 96 * i + 96])
+    assert pyref.g1_deserialize(raw[:96], compressed=False, validate=True) == pyref.G1_GEN
+
+
+def test_compressed_roundtrip_and_sign_rule(golden):
+    pts = util.srs_points_ints(golden["srs_g1"], 16)
+    for p in pts + [pyref.g1_neg(p) for p in pts[:4]] + [None]:
+        c = pyref.g1_serialize(p, compressed=True)
+        assert len(c) == 48
+        assert pyref.g1_deserialize(c, compressed=True) == p
+        if p is not None:
+            assert bool(c[47] >> 7) == (p[1] > pyref.Q_MOD - p[1])  # bit 7 = y is the larger root
+    u = pyref.g1_serialize(None, compressed=False)
+    assert u[95] == 1 << 6 and pyref.g1_deserialize(u, compressed=False) is None
+
+
+def test_decode_errors():
+    bad = bytearray(pyref.g1_serialize(pyref.G1_GEN, compressed=True))
+    bad[47] |= 0xC0
+    with pytest.raises(pyref.SerializationError):
+        pyref.g1_deserialize(bytes(bad), compressed=True)
+    with pytest.raises(pyref.SerializationError):  # x >= q
+        pyref.g1_deserialize((pyref.Q_MOD).to_bytes(48, "little"), compressed=True)
+    # an x with no point above it
+    x = 1
+    while pyref.fq_sqrt((x ** 3 + 1) % pyref.Q_MOD) is not None:
+        x += 1
+    with pytest.raises(pyref.SerializationError):
+        pyref.g1_deserialize(x.to_bytes(48, "little"), compressed=True)
+    # a curve point outside the prime-order subgroup fails validation only
+    x = 2
+    while True:
+        y = pyref.fq_sqrt((x ** 3 + 1) % pyref.Q_MOD)
+        if y is not None and pyref.g1_mul((x, y), pyref.R_MOD) is not None:
+            break
+        x += 1
+    enc = pyref.g1_serialize((x, y), compressed=False)
+    assert pyref.g1_deserialize(enc, compressed=False) == (x, y)
+    with pytest.raises(pyref.SerializationError):
+        pyref.g1_deserialize(enc, compressed=False, validate=True)
