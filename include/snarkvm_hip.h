@@ -125,6 +125,10 @@ RustError snarkvm_hip_msm_registered_batch(void *outs, const snarkvm_hip_bases_t
                                            const size_t *offsets, const size_t *npoints, const void *const *scalars,
                                            int scalars_on_device, int scalars_montgomery, int window_bits);
 
+/* out (144 B) = sum of n G1Projective points (host buffers).  Combines the per-device partial results of an MSM whose
+ * point range was split over several GPUs (the host `dadd` loop of snarkvm.cu:290-295). */
+RustError snarkvm_hip_g1_sum(void *out, const void *in_projective, size_t n);
+
 /* `From<Projective> for Affine` (curves/src/templates/short_weierstrass_jacobian/affine.rs:331-353) for n
  * G1Projective (144 B) -> G1Affine (104 B), host buffers. */
 RustError snarkvm_hip_g1_to_affine(void *out_affine, const void *in_projective, size_t n);

@@ -838,6 +838,23 @@ RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t
     memcpy(outs, stage, count * 144);
     API_END
 }
+RustError snarkvm_hip_g1_sum(void* out, const void* in_projective, size_t n) {
+    API_BEGIN
+    if (!out || (n && !in_projective)) throw hip_failure{hipErrorInvalidValue, "g1_sum: null argument", __LINE__};
+    if (n == 0) {
+        write_infinity<fq_t>(out);
+    } else {
+        g_ctx.poly[0].ensure(n * 144 + 144);
+        uint32_t* d_in = g_ctx.poly[0].as<uint32_t>();
+        uint32_t* d_out = d_in + 36 * n;
+        HIP_TRY(hipMemcpyAsync(d_in, in_projective, n * 144, hipMemcpyHostToDevice, g_ctx.stream));
+        hipLaunchKernelGGL(g1_sum_kernel, dim3(1), dim3(64), 0, g_ctx.stream, (const uint32_t*)d_in, n, d_out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, d_out, 144, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    API_END
+}
 RustError snarkvm_hip_g1_to_affine(void* out_affine, const void* in_projective, size_t n) {
     API_BEGIN
     if (n) {

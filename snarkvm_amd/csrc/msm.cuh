@@ -633,6 +633,36 @@ __global__ void g1_to_affine_kernel(const uint32_t* in, uint32_t* out, size_t n)
 }
 
 // ------------------------------------------------------------------------------------------
+// Sum of a few Jacobian points (the per-device partial results of a point-range-split MSM: replaces the host `dadd`
+// loop of algorithms/cuda/cuda/snarkvm.cu:290-295).  One workgroup; lane t adds points t, t + 64, ..., then an LDS tree.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) g1_sum_kernel(const uint32_t* in, size_t n, uint32_t* out) {
+    __shared__ g1_xyzz_mem_t part[64];
+    g1_xyzz_t acc = g1_xyzz_t::inf();
+    for (size_t i = threadIdx.x; i < n; i += 64) {
+        const uint32_t* src = in + 36 * i;
+        g1_jac_t j = {fq_t::from_raw_words(src), fq_t::from_raw_words(src + 12), fq_t::from_raw_words(src + 24)};
+        acc.add(g1_xyzz_t::from_jacobian(j));
+    }
+    g1_store_xyzz(&part[threadIdx.x], acc);
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            g1_xyzz_t a = g1_load_xyzz(&part[threadIdx.x]);
+            a.add(g1_load_xyzz(&part[threadIdx.x + s]));
+            g1_store_xyzz(&part[threadIdx.x], a);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const g1_jac_t r = g1_load_xyzz(&part[0]).to_jacobian();
+        r.x.to_raw_words(out);
+        r.y.to_raw_words(out + 12);
+        r.z.to_raw_words(out + 24);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Synthetic base generation (benchmark / test utility): out[i] = (start + i) * G in the Rust layout
 // ------------------------------------------------------------------------------------------
 static constexpr int GEN_RUN = 32;

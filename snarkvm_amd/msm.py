@@ -119,3 +119,15 @@ def msm_g2(bases, scalars):
                                         ctypes.c_void_p(scalars.ctypes.data), ctypes.c_size_t(G2_AFFINE.itemsize))
     _lib.check(err)
     return out
+
+
+def g1_sum(points):
+    """Sum of G1Projective records on the device (snarkvm_hip_g1_sum): the combine step of a point-range-split MSM."""
+    pts = np.ascontiguousarray(points)
+    raw = np.frombuffer(pts.tobytes(), dtype=np.uint8)
+    if raw.size % G1_PROJECTIVE.itemsize:
+        raise ValueError("g1_sum: input is not a whole number of G1Projective records")
+    n = raw.size // G1_PROJECTIVE.itemsize
+    out = np.zeros(1, dtype=G1_PROJECTIVE)
+    _lib.check(_lib.lib().snarkvm_hip_g1_sum(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(raw.ctypes.data), ctypes.c_size_t(n)))
+    return out

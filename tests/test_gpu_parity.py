@@ -8,7 +8,7 @@ import pytest
 
 from oracle import cpu as oracle
 from oracle import pyref
-from snarkvm_amd import _lib, fft, plugin, synthetic
+from snarkvm_amd import _lib, batch, fft, plugin, synthetic
 from snarkvm_amd.layout import G1_AFFINE, G1_PROJECTIVE, NTTDirection, NTTInputOutputOrder, NTTType
 from snarkvm_amd.msm import RegisteredBases, VariableBase
 from tests import util
@@ -419,3 +419,29 @@ def test_varuna_proof_shaped_workload(golden):
         assert util.affine_equal(oracle.g1_to_affine(got[i : i + 1]), oracle.g1_to_affine(want))
     rb.close()
     pw.close()
+
+
+def test_g1_sum_of_partial_results(golden):
+    """snarkvm_hip_g1_sum: the combine step of a point-range-split MSM equals the unsplit MSM."""
+    from snarkvm_amd.msm import g1_sum
+
+    n = 5000
+    bases = _srs(golden, n)
+    scalars = synthetic.random_fr_integers(n, 8080)
+    rb = RegisteredBases(bases, tables=16)
+    want = oracle.g1_to_affine(oracle.g1_msm(bases, scalars))
+    for world in (1, 2, 3, 8, 70):
+        parts = []
+        for r in range(world):
+            lo, hi = batch.split_range(n, world, r)
+            parts.append(rb.msm(scalars[lo:hi], offset=lo))
+        total = g1_sum(np.concatenate(parts))
+        assert util.affine_equal(oracle.g1_to_affine(total), want), world
+    inf = g1_sum(np.zeros(0, dtype=G1_PROJECTIVE))
+    assert oracle.g1_to_affine(inf)["infinity"][0] == 1
+    # P + (-P) and P + P through the complete addition
+    p = rb.msm(scalars[:10])
+    neg = oracle.g1_msm(bases[:10], oracle.fr_op("to_bigint", oracle.fr_op("neg", oracle.fr_op("from_bigint", scalars[:10]))))
+    assert oracle.g1_to_affine(g1_sum(np.concatenate([p, neg])))["infinity"][0] == 1
+    assert util.affine_equal(oracle.g1_to_affine(g1_sum(np.concatenate([p, p]))), oracle.g1_to_affine(oracle.g1_add(p, p)))
+    rb.close()
