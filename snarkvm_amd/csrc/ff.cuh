@@ -422,9 +422,16 @@ struct Fp {
             }
         return res;
     }
-    SV_HD Fp pow_u64(uint64_t e) const {
-        uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
-        return pow_words(w, 2);
+    SV_HD Fp pow_u64(uint64_t e) const {  // starts at the top set bit: small exponents cost ~log2(e) squarings
+        if (e == 0) return one();
+        int top = 63;
+        while (!((e >> top) & 1)) top--;
+        Fp res = *this;
+        for (int bit = top - 1; bit >= 0; bit--) {
+            res = res.sqr();
+            if ((e >> bit) & 1) res = res * *this;
+        }
+        return res;
     }
     // Fermat inverse a^(p-2): the same residue as the reference's binary EEA (fp_256.rs:290-340), a != 0
     SV_HD Fp inverse() const {

@@ -128,6 +128,40 @@ class KZG10:
         return out, randomness
 
     @staticmethod
+    def commit_device(powers, coeffs, hiding_bound=None, rng=None):
+        """`commit` for a coefficient vector that already lives in HBM (e.g. the output of a device iNTT): `coeffs` is a
+        CUDA torch tensor viewing n Fr elements (any dtype, 32 * n bytes).  Nothing returns to the host but the 144-byte
+        result: `to_bigint` is fused into the MSM's scalar read, leading zeros need no special case on the device (a zero
+        digit touches no bucket), and the blinding coefficients are appended in HBM.  Same result as `commit`."""
+        import torch
+
+        nbytes = coeffs.numel() * coeffs.element_size()
+        if nbytes % 32 or not coeffs.is_cuda or not coeffs.is_contiguous():
+            raise PCError("commit_device: need a contiguous CUDA tensor of 32-byte Fr elements")
+        n = nbytes // 32
+        if n > powers.size():
+            raise PCError(f"TooManyCoefficients: {n} > {powers.size()}")
+        randomness = KZGRandomness.empty()
+        flat = coeffs.view(torch.uint8).reshape(-1)
+        k = 0
+        if hiding_bound is not None:
+            if rng is None:
+                raise PCError("MissingRng")
+            randomness = KZGRandomness(np.ascontiguousarray(rng(hiding_bound + 1), dtype=np.uint64).reshape(-1, 4))
+            k = randomness.blinding_polynomial.shape[0]
+            if k > powers.powers_of_beta_times_gamma_g.shape[0]:
+                raise PCError("HidingBoundToolarge")
+            blind = torch.from_numpy(randomness.blinding_polynomial.view(np.uint8).reshape(-1).copy()).to(flat.device)
+            flat = torch.cat([flat, blind])
+        torch.cuda.current_stream().synchronize()  # the library runs on its own stream
+        out = np.zeros(1, dtype=G1_PROJECTIVE)
+        _lib.check(_lib.lib().snarkvm_hip_msm_registered_ex(
+            ctypes.c_void_p(out.ctypes.data), powers._h, ctypes.c_size_t(0), ctypes.c_size_t(n),
+            ctypes.c_size_t(powers._gamma_offset), ctypes.c_size_t(k), ctypes.c_void_p(flat.data_ptr()), ctypes.c_int(1), ctypes.c_int(1),
+            ctypes.c_int(0)))
+        return out, randomness
+
+    @staticmethod
     def commit_lagrange(lagrange_basis, evaluations, hiding_bound=None, rng=None):
         """mod.rs:159-206: same MSM shape over `lagrange_basis_at_beta_g` (pass it as `Powers.powers_of_beta_g`);
         the evaluation vector is not trimmed and must fill the basis' power-of-two size."""

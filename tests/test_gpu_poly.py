@@ -187,3 +187,78 @@ def test_kzg10_open_lagrange(golden):
     with pytest.raises(kzg10.PCError):
         kzg10.KZG10.open_lagrange(pw, elems, evals, elems[5:6], value)
     pw.close()
+
+
+def test_device_resident_round2_slice_and_openings(golden):
+    """a Varuna second-round slice that never leaves HBM between its steps - evaluations -> device
+    iNTT -> z_a * z_b - z_c on the 2|R| domain (device NTTs + rowcheck kernel) -> device iNTT -> division by X^|R| - 1
+    -> commit straight from the device vector; then three openings (kzg10/mod.rs:304-322).  Every result is compared
+    with the oracle's CPU restatement of the same reference functions."""
+    import ctypes
+
+    import torch
+
+    lgR = 12
+    n, n2 = 1 << lgR, 1 << (lgR + 1)
+    L = _lib.lib()
+    powers_g = _srs(golden, n2)
+    gamma_g = oracle.g1_gen_bases(util.g1_generator_affine(), 7, 4)
+    pw = kzg10.Powers(powers_g, gamma_g)
+    dev = torch.device("cuda:0")
+
+    def P(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def to_dev(a, pad_to=None):
+        t = torch.zeros((pad_to or a.shape[0], 4), dtype=torch.int64, device=dev)
+        t[: a.shape[0]] = torch.from_numpy(a.view(np.int64)).to(dev)
+        return t
+
+    def ntt_dev(t, lg, direction):
+        torch.cuda.synchronize()
+        _lib.check(L.snarkvm_hip_ntt_device(P(t), ctypes.c_uint32(lg), 0, direction, 0))
+
+    # z_a, z_b, z_c evaluations on R with z_a * z_b == z_c on R (so that the quotient is exact)
+    ea, eb = _rnd(n, 501), _rnd(n, 502)
+    ec = oracle.fr_vec_op("mul", ea, eb)
+    d = [to_dev(e, n2) for e in (ea, eb, ec)]
+    for t in d:
+        ntt_dev(t, lgR, 1)          # coefficients of z_m (degree < |R|), zero-padded to 2|R|
+    dc_coeffs = d[2].clone()
+    for t in d[:2]:
+        ntt_dev(t, lgR + 1, 0)      # evaluations on the doubled domain
+    prod = torch.empty_like(d[0])
+    torch.cuda.synchronize()
+    _lib.check(L.snarkvm_hip_fr_vec_op(2, P(prod), P(d[0]), P(d[1]), None, None, ctypes.c_size_t(n2), 1))
+    ntt_dev(prod, lgR + 1, 1)       # z_a * z_b in coefficient form
+    _lib.check(L.snarkvm_hip_fr_vec_op(1, P(prod), P(prod), P(dc_coeffs), None, None, ctypes.c_size_t(n2), 1))  # - z_c
+    quot = torch.zeros((n2 - n, 4), dtype=torch.int64, device=dev)
+    rem = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    _lib.check(L.snarkvm_hip_fr_divide_by_vanishing(P(quot), P(rem), P(prod), ctypes.c_size_t(n2), ctypes.c_size_t(n), 1))
+    assert not bool(rem.any())      # exact: z_a z_b - z_c vanishes on R
+    comm, _ = kzg10.KZG10.commit_device(pw, quot)
+    # oracle: the same pipeline with the restated reference functions
+    ca, cb, cc = (oracle.ntt(e, oracle.ORDER_NN, oracle.INVERSE) for e in (ea, eb, ec))
+    rowcheck = oracle.polymul(lgR + 1, [ca, cb])
+    cpad = np.zeros_like(rowcheck)
+    cpad[:n] = cc
+    rowcheck = oracle.fr_vec_op("sub", rowcheck, cpad)
+    h0, r0 = oracle.poly_divide(rowcheck, [(0, oracle.fr_op("neg", _one())[0]), (n, _one()[0])])
+    assert r0.shape[0] == 0
+    got_h0 = quot.cpu().numpy().view(np.uint64)
+    assert np.array_equal(poly.trim(got_h0), h0)
+    want = oracle.g1_msm(powers_g[: h0.shape[0]], oracle.fr_op("to_bigint", h0), oracle.MSM_BATCHED)
+    assert util.affine_equal(oracle.g1_to_affine(comm), oracle.g1_to_affine(want))
+    # hiding commit from the device vector equals the host-path commit
+    blind = _rnd(2, 77)
+    c_dev, _ = kzg10.KZG10.commit_device(pw, quot, 1, lambda k: blind[:k])
+    c_host, _ = kzg10.KZG10.commit(pw, got_h0, 1, lambda k: blind[:k])
+    assert util.affine_equal(oracle.g1_to_affine(c_dev), oracle.g1_to_affine(c_host))
+    # three openings of the committed polynomials at one challenge point
+    point = _rnd(1, 88)
+    for coeffs in (ca, cb, h0):
+        proof = kzg10.KZG10.open(pw, coeffs, point, kzg10.KZGRandomness.empty())
+        wq, _ = oracle.poly_divide(coeffs, _linear_divisor(point))
+        want = oracle.g1_msm(powers_g[: wq.shape[0]], oracle.fr_op("to_bigint", wq), oracle.MSM_BATCHED)
+        assert util.affine_equal(np.array([proof.w]), oracle.g1_to_affine(want))
+    pw.close()
