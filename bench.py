@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--lg-ntt", type=int, default=24)
     ap.add_argument("--ntt-steps", type=int, default=10)
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--tables", type=int, default=16, help="precomputed 2^(256/tables*j) multiples of the registered bases")
+    ap.add_argument("--tables", type=int, default=0, help="precomputed 2^(table_bits*j) multiples of the registered bases (0: from --table-bits)")
+    ap.add_argument("--table-bits", type=int, default=-1,
+                    help="bits per base table = widest bucket window; -1: 22 / 20 / 16 by size; tables = ceil(254 / table_bits)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the K steps one synchronous MSM at a time instead of one pipelined batch of K independent MSMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,15 +73,26 @@ def main():
     bases_dev = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     _lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(bases_dev.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(n)))
-    rb = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=args.tables)
+    if args.table_bits < 0:
+        # measured on MI355X (profiles/r01_size_sweep.md): 22-bit windows win from 2^24, 20-bit from 2^22, 16-bit below
+        args.table_bits = 16 if args.tables else (22 if args.lg_msm >= 24 else 20 if args.lg_msm >= 22 else 16)
+    if not args.tables:
+        args.tables = 16 if args.table_bits == 16 else -(-254 // args.table_bits)
+    rb = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=args.tables,
+                         window_bits=0 if (args.table_bits == 16 and args.tables == 16) or args.tables == 1 else args.table_bits)
     del bases_dev
     scalars = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE + rank)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ MSM: W warm-up + K timed steps
-    for _ in range(args.warmup):
-        rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
+    if args.no_pipeline:
+        for _ in range(args.warmup):
+            rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
+    elif args.warmup:
+        # the pipelined path runs on LANES = 3 HIP streams with one workspace each: W warm-up steps per stream, so that no
+        # workspace is allocated (hipMalloc / hipFree synchronise the device) inside the timed region
+        rb.msm_batch(device_ptrs=[d_scalars.data_ptr()] * (3 * args.warmup), npoints=[n] * (3 * args.warmup), window_bits=args.window_bits)
     barrier()
     t0 = time.perf_counter()
     if args.no_pipeline:
@@ -190,8 +203,8 @@ def main():
     if rank == 0:
         acc_ms = phase_ms.get("msm_accumulate", 0.0)
         dig_ms = phase_ms.get("msm_digits", 0.0)
-        cbits = args.window_bits or 16
-        W = (256 // cbits) if args.tables > 1 else (254 + cbits - 1) // cbits  # digit rows per scalar
+        cbits = args.window_bits or (args.table_bits if args.tables > 1 else 16)
+        W = args.tables * (args.table_bits // cbits) if args.tables > 1 else (254 + cbits - 1) // cbits  # digit rows per scalar
         out = {
             "metric": "BLS12-377 G1 MSM scalar-point pairs/sec (+ Fr NTT elements/sec in ntt_*)",
             "value": pairs_per_s,
@@ -207,7 +220,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"G1 Pippenger MSM 2^{args.lg_msm} (BASELINE.json configs[1]), bases (i+1)G registered in HBM, "
                                    f"uniform scalars in HBM; independent instance per GPU",
-                       "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables,
+                       "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables, "table_bits": args.table_bits,
                        "pipelined_batch": not args.no_pipeline},
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
@@ -218,12 +231,12 @@ def main():
             # bases (96 B) + sorted index (4 B) per (pair, window) - reported against the HBM peak for context.
             "roofline": {
                 "bound": "hbm",
-                "kernel": "msm_accumulate_kernel",
+                "kernel": "msm_accumulate_bm_kernel",
                 "achieved": (n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 if acc_ms else None,
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
-                "traffic": traffic("msm_accumulate_kernel<Fp<FqP>, 1>", "fetch_bytes_raw"),
+                "traffic": traffic("msm_accumulate_bm_kernel<Fp<FqP> >", "fetch_bytes_raw"),
                 "algorithmic_bytes": n * 100.0 * W,
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d); see roofline_scalar_read for the HBM-bound phase",
             },
@@ -237,7 +250,7 @@ def main():
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
                 "traffic": traffic("msm_digits_kernel", "fetch_bytes_x2"),
                 "algorithmic_bytes": 32.0 * n,
-                "bytes_incl_digit_writes_GBps": ((32.0 + 2.0 * W) * n) / (dig_ms * 1e-3) / 1e9 if dig_ms else None,
+                "bytes_incl_digit_writes_GBps": ((32.0 + (4.0 if cbits > 16 else 2.0) * W) * n) / (dig_ms * 1e-3) / 1e9 if dig_ms else None,
             },
             "roofline_ntt": {
                 "bound": "hbm",

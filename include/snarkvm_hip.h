@@ -86,6 +86,12 @@ RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t **handle, const void *p
  * group element. */
 RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t **handle, const void *points, size_t npoints,
                                             size_t ffi_affine_sz, int on_device, int tables);
+/* General form: table j = 2^(window_bits * j) * P_i for j < tables, with tables * window_bits >= 254 and window_bits <= 23.
+ * With window_bits > 16 a large MSM runs ONE bucket window of 2^(window_bits - 1) buckets: only `tables` bucket additions
+ * per scalar (12 at window_bits = 22 instead of 16) at the price of a deeper sort and a two-axis bucket fold - the
+ * Pippenger optimum for n ~ 2^24.  Smaller MSMs over the same handle fall back to a divisor of window_bits. */
+RustError snarkvm_hip_register_bases_windowed(snarkvm_hip_bases_t **handle, const void *points, size_t npoints,
+                                              size_t ffi_affine_sz, int on_device, int tables, int window_bits);
 void snarkvm_hip_free_bases(snarkvm_hip_bases_t *handle);
 
 /* The reference's canonical encoding of G1 points (curves/src/templates/macros.rs:66-140, utilities/src/serialize/

@@ -75,6 +75,8 @@ struct msm_ws_t {
     hipStream_t stream = nullptr;
     dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, contrib, wsum, result;
     dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.cuh)
+    dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
+    dev_buf fold_sums, fold_idx;                                              // two-axis bucket fold (wide windows)
 };
 
 struct phase_rec {
@@ -185,6 +187,7 @@ struct snarkvm_hip_bases {
     g1_aff_mem_t* d = nullptr;  // tables * n entries: table j at d + j * n holds 2^(256 / tables * j) * P_i
     size_t n = 0;
     int tables = 1;
+    int table_bits = 256;  // table j = 2^(table_bits * j) * P
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -204,7 +207,7 @@ static void write_infinity(void* out) {
 template <class F>
 static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
                     const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
-                    size_t table_stride = 0, int lane_idx = 0, bool sync = true) {
+                    size_t table_stride = 0, int lane_idx = 0, bool sync = true, int table_bits = 0) {
     msm_ws_t& c = ctx.lane[lane_idx];
     // per-phase HIP events only on the synchronous single-MSM path (lane 0)
     auto phase_begin = [&](const char* name) { if (lane_idx == 0 && sync) ctx.phase_begin(name); };
@@ -215,7 +218,8 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         return;
     }
     if (n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: npoints must be < 2^31", __LINE__};
-    const msm_plan_t pl = msm_make_plan(n, window_bits, tables);
+    const msm_plan_t pl = msm_make_plan(n, window_bits, tables, table_bits);
+    const bool wide = pl.c > 16;  // u32 digits, three-level sort, two-axis bucket fold
     if ((size_t)pl.Wd * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: windows * npoints must be < 2^32", __LINE__};
     if ((size_t)pl.J * n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: tables * npoints must be < 2^31", __LINE__};
     hipStream_t st = c.stream;
@@ -223,12 +227,8 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     const size_t E_max = (size_t)pl.Wd * n;
     const uint32_t nbt = pl.nbt;
 
-    c.digits.ensure(E_max * sizeof(uint16_t));
-    const size_t ncounts = (size_t)nbt * pl.nchunks;
-    c.counts.ensure(ncounts * 4);
-    c.offsets.ensure(ncounts * 4);
-    c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
-    c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * pl.J * 4);
+    c.digits.ensure(E_max * (wide ? sizeof(uint32_t) : sizeof(uint16_t)));
+    c.scan_tmp.ensure((scan_tmp_elems((size_t)nbt + 1)) * 4);
     c.boff.ensure(((size_t)nbt + 2) * 4);
     c.cnt_a.ensure(((size_t)nbt + 1) * 4);
     c.cnt_b.ensure(((size_t)nbt + 1) * 4);
@@ -240,9 +240,18 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
     c.part_a.ensure(T0_max * sizeof(xyzz_mem_t<F>));
     c.part_b.ensure(T1_max * sizeof(xyzz_mem_t<F>));
-    const uint32_t J = pl.nb / pl.L;
-    c.contrib.ensure((size_t)pl.W * J * sizeof(xyzz_mem_t<F>));
-    c.wsum.ensure((size_t)pl.W * sizeof(xyzz_mem_t<F>));
+    // tail geometry: a wide window is first folded into two windows of 2^fold_m entries (msm_fold_kernel)
+    const int K = pl.c - 1;
+    const int fold_m = (K + 1) / 2, fold_hb = K - fold_m;
+    const uint32_t tail_nb = wide ? (1u << fold_m) : pl.nb;
+    const int tail_W = wide ? 2 : pl.W;
+    const int tail_c = wide ? fold_m : pl.c;
+    uint32_t tail_L = pl.L;
+    if (tail_L > tail_nb) tail_L = tail_nb;
+    while (tail_nb % tail_L) tail_L--;
+    const uint32_t J = tail_nb / tail_L;
+    c.contrib.ensure((size_t)tail_W * J * sizeof(xyzz_mem_t<F>));
+    c.wsum.ensure((size_t)tail_W * sizeof(xyzz_mem_t<F>));
     c.result.ensure(sizeof(jac_mem_t<F>));
 
     // 1. digits
@@ -256,38 +265,43 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         dp.montgomery = scalars_montgomery;
         size_t blocks = (n + 255) / 256;
         if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
+        if (wide)
+            hipLaunchKernelGGL((msm_digits_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint32_t>(), dp);
+        else
+            hipLaunchKernelGGL((msm_digits_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
     }
     phase_end();
     static const int sort_mode = getenv("SNARKVM_HIP_SORT") ? atoi(getenv("SNARKVM_HIP_SORT")) : 1;  // 1 = radix partition, 0 = chunk-major
     int rounds = 0;
-    if (sort_mode == 1) {
-        // ---- 2.-4. two-level LDS-staged radix partition (msm_sort.cuh) -> bucket-major `sorted` + boff
+    if (sort_mode == 1 || wide) {
+        // ---- 2.-4. LDS-staged radix partition (msm_sort.cuh) -> bucket-major `sorted` + boff; two levels, three when wide
         msm_radix_params_t rp;
         rp.n = n;
         rp.c = pl.c;
         rp.W = pl.W;
         rp.J = pl.J;
-        rp.LB = (pl.c - 1) < 7 ? (pl.c - 1) : 7;
-        rp.HB = (pl.c - 1) - rp.LB;
+        const int LBL = K < 7 ? K : 7;  // key bits of the last level
+        rp.LB = wide ? 14 : LBL;        // bits left below the level-1 key
+        rp.HB = K - rp.LB;
         rp.nb = pl.nb;
         rp.tiles_per_row = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
         rp.TPW = (uint32_t)pl.J * rp.tiles_per_row;
-        const uint32_t B1 = 1u << rp.HB, B2 = 1u << rp.LB;
+        const uint32_t B1 = 1u << rp.HB;
         const uint32_t nbins = (uint32_t)pl.W * B1;
         const size_t ncounts1 = (size_t)nbins * rp.TPW;
         const size_t tiles1 = (size_t)pl.W * rp.TPW;
-        const size_t tiles2_max = E_max / SORT_TILE + nbins + 1;
+        const uint32_t nseg_last = wide ? nbins << 7 : nbins;  // segments feeding the last level
+        const size_t tiles2_max = E_max / SORT_TILE + nseg_last + 1;
         c.counts.ensure(ncounts1 * 4);
         c.offsets.ensure(ncounts1 * 4);
         c.scan_tmp.ensure(scan_tmp_elems(ncounts1 > (size_t)nbt + 2 ? ncounts1 : (size_t)nbt + 2) * 4);
         c.rv1.ensure(E_max * 4);
-        c.rl1.ensure(E_max);
-        c.rcounts2.ensure(tiles2_max * B2 * 4);
-        c.roff2.ensure(tiles2_max * B2 * 4);
+        c.rl1.ensure(E_max * (wide ? 2 : 1));
+        c.rcounts2.ensure(tiles2_max * 128 * 4);
+        c.roff2.ensure(tiles2_max * 128 * 4);
         c.rbinstart.ensure(((size_t)nbins + 2) * 4);
-        c.rntiles.ensure(((size_t)nbins + 2) * 4);
-        c.rtstart.ensure(((size_t)nbins + 2) * 4);
+        c.rntiles.ensure(((size_t)nseg_last + 2) * 4);
+        c.rtstart.ensure(((size_t)nseg_last + 2) * 4);
         c.rbsize.ensure(((size_t)nbt + 3) * 4);
         c.sorted.ensure(E_max * 4);
         uint32_t* counts1 = c.counts.as<uint32_t>();
@@ -296,41 +310,109 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         uint32_t* d_max = bsize + nbt + 1;
         uint32_t* boffp = c.boff.as<uint32_t>();
         phase_begin("msm_sort_level1");
-        hipLaunchKernelGGL(radix_hist1_kernel, dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(), counts1, rp);
-        exclusive_scan_u32(st, counts1, off1, ncounts1, c.scan_tmp.as<uint32_t>());
-        hipLaunchKernelGGL(radix_scatter1_kernel, dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(), counts1, off1,
-                           c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(), rp);
-        phase_end();
-        phase_begin("msm_sort_level2");
+        if (wide) {
+            hipLaunchKernelGGL((radix_hist1_kernel<uint32_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint32_t>(), counts1, rp);
+            exclusive_scan_u32(st, counts1, off1, ncounts1, c.scan_tmp.as<uint32_t>());
+            hipLaunchKernelGGL((radix_scatter1_kernel<uint32_t, uint16_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint32_t>(),
+                               counts1, off1, c.rv1.as<uint32_t>(), c.rl1.as<uint16_t>(), rp);
+        } else {
+            hipLaunchKernelGGL((radix_hist1_kernel<uint16_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(), counts1, rp);
+            exclusive_scan_u32(st, counts1, off1, ncounts1, c.scan_tmp.as<uint32_t>());
+            hipLaunchKernelGGL((radix_scatter1_kernel<uint16_t, uint8_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(),
+                               counts1, off1, c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(), rp);
+        }
         hipLaunchKernelGGL(radix_bin_layout_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, off1, counts1, ncounts1, c.rbinstart.as<uint32_t>(),
                            nbins, rp.TPW);
-        hipLaunchKernelGGL(radix_bin_tiles_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, c.rbinstart.as<uint32_t>(), c.rntiles.as<uint32_t>(),
-                           nbins);
-        exclusive_scan_u32(st, c.rntiles.as<uint32_t>(), c.rtstart.as<uint32_t>(), (size_t)nbins + 1, c.scan_tmp.as<uint32_t>());
-        hipLaunchKernelGGL(radix_hist2_kernel, dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, c.rl1.as<uint8_t>(), c.rbinstart.as<uint32_t>(),
-                           c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), nbins, rp.LB);
+        phase_end();
+        // one further level: items (v_in, rem_in) grouped in `nseg` segments -> grouped by (segment, next `bits` key bits)
+        auto tile_segments = [&](const uint32_t* seg_start, uint32_t nseg) {
+            hipLaunchKernelGGL(radix_bin_tiles_kernel, dim3((nseg + 1 + 255) / 256), dim3(256), 0, st, seg_start, c.rntiles.as<uint32_t>(), nseg);
+            exclusive_scan_u32(st, c.rntiles.as<uint32_t>(), c.rtstart.as<uint32_t>(), (size_t)nseg + 1, c.scan_tmp.as<uint32_t>());
+        };
+        // per (segment, key): exclusive prefix of the tile counts + group sizes; few big segments -> one workgroup per segment
+        auto colscan = [&](uint32_t* sizes, uint32_t nsegs, int bits, uint32_t* dmax) {
+            if (nsegs <= 4096)
+                hipLaunchKernelGGL(radix_colscan2_seg_kernel, dim3(nsegs), dim3(1024), 0, st, c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(),
+                                   c.rtstart.as<uint32_t>(), sizes, nsegs, bits, dmax);
+            else
+                hipLaunchKernelGGL(radix_colscan2_kernel, dim3(((nsegs << bits) + 1 + 255) / 256), dim3(256), 0, st, c.rcounts2.as<uint32_t>(),
+                                   c.roff2.as<uint32_t>(), c.rtstart.as<uint32_t>(), sizes, nsegs, bits, dmax);
+        };
+        const uint32_t* seg_start = c.rbinstart.as<uint32_t>();
+        uint32_t nseg = nbins;
+        const uint32_t* v_in = c.rv1.as<uint32_t>();
+        if (wide) {
+            phase_begin("msm_sort_level2");
+            const uint32_t ngroups = nseg << 7;
+            const size_t tmax = E_max / SORT_TILE + nseg + 1;
+            c.rv2.ensure(E_max * 4);
+            c.rl2.ensure(E_max);
+            c.rmid_size.ensure(((size_t)ngroups + 3) * 4);
+            c.rmid_boff.ensure(((size_t)ngroups + 3) * 4);
+            c.scan_tmp.ensure(scan_tmp_elems((size_t)ngroups + 2) * 4);
+            uint32_t* msize = c.rmid_size.as<uint32_t>();
+            uint32_t* mboff = c.rmid_boff.as<uint32_t>();
+            tile_segments(seg_start, nseg);
+            hipLaunchKernelGGL((radix_hist2_kernel<uint16_t>), dim3((unsigned)tmax), dim3(SORT_THREADS), 0, st, c.rl1.as<uint16_t>(), seg_start,
+                               c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), nseg, 7, 7);
+            HIP_TRY(hipMemsetAsync(msize + ngroups + 1, 0, 4, st));
+            colscan(msize, nseg, 7, msize + ngroups + 1);
+            exclusive_scan_u32(st, msize, mboff, (size_t)ngroups + 1, c.scan_tmp.as<uint32_t>());
+            hipLaunchKernelGGL((radix_scatter2_kernel<uint16_t, uint8_t>), dim3((unsigned)tmax), dim3(SORT_THREADS), 0, st, v_in, c.rl1.as<uint16_t>(),
+                               seg_start, c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), mboff, c.rv2.as<uint32_t>(),
+                               c.rl2.as<uint8_t>(), nseg, 7, 7);
+            phase_end();
+            seg_start = mboff;
+            nseg = ngroups;
+            v_in = c.rv2.as<uint32_t>();
+        }
+        phase_begin(wide ? "msm_sort_level3" : "msm_sort_level2");
+        tile_segments(seg_start, nseg);
+        const uint8_t* rem_last = wide ? c.rl2.as<uint8_t>() : c.rl1.as<uint8_t>();
+        hipLaunchKernelGGL((radix_hist2_kernel<uint8_t>), dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, rem_last, seg_start,
+                           c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), nseg, LBL, 0);
         HIP_TRY(hipMemsetAsync(d_max, 0, 4, st));
-        hipLaunchKernelGGL(radix_colscan2_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(),
-                           c.rtstart.as<uint32_t>(), bsize, nbins, rp.LB, d_max);
+        colscan(bsize, nseg, LBL, d_max);
         exclusive_scan_u32(st, bsize, boffp, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-        hipLaunchKernelGGL(radix_scatter2_kernel, dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(),
-                           c.rbinstart.as<uint32_t>(), c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
-                           nbins, rp.LB);
+        hipLaunchKernelGGL((radix_scatter2_kernel<uint8_t, uint8_t>), dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, v_in, rem_last, seg_start,
+                           c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
+                           (uint8_t*)nullptr, nseg, LBL, 0);
         phase_end();
         uint32_t max_bucket = 0;
         HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
+        static const int seg_mode = getenv("SNARKVM_HIP_SEG") ? atoi(getenv("SNARKVM_HIP_SEG")) : 1;  // 1 = balanced segments (default)
         // ---- 5. accumulate
         phase_begin("msm_accumulate");
-        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
-        exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-        hipLaunchKernelGGL((msm_accumulate_bm_kernel<F>), dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases,
-                           (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n,
-                           table_stride);
+        if (seg_mode) {
+            // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
+            // (the tail kernels add up to TAIL_PARTIALS leftover partials per bucket themselves: one reduce round less)
+            static const size_t tail_partials = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 4;
+            for (size_t m = max_bucket ? ((size_t)max_bucket - 1) / pl.S + 2 : 0; m > tail_partials; m = (m + pl.S2 - 1) / pl.S2) rounds++;
+            hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
+            exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+            const size_t nthreads = (E_max + pl.S - 1) / pl.S;
+            hipLaunchKernelGGL((msm_accumulate_seg_kernel<F>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                               d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                               c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
+        } else {
+            for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
+            hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
+            exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+            hipLaunchKernelGGL((msm_accumulate_bm_kernel<F>), dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases,
+                               d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                               c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
+        }
         phase_end();
     } else {
     // 2.-4. counting sort by (window, bucket), chunk-major layout
+    {
+        const size_t ncounts = (size_t)nbt * pl.nchunks;
+        c.counts.ensure(ncounts * 4);
+        c.offsets.ensure(ncounts * 4);
+        c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
+        c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * pl.J * 4);
+    }
     msm_sort_params_t sp;
     sp.n = n;
     sp.chunk = pl.chunk;
@@ -411,13 +493,27 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     phase_end();
     // 7.-9. bucket reduction, window sums, Horner
     phase_begin("msm_bucket_reduce");
-    const uint32_t total_threads = (uint32_t)pl.W * J;
-    hipLaunchKernelGGL((msm_bucket_reduce_kernel<F>), dim3((total_threads + 255) / 256), dim3(256), 0, st, pin, start_in, cnt_in,
-                       c.contrib.as<xyzz_mem_t<F>>(), pl.nb, pl.L, total_threads);
-    hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(pl.W), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, c.contrib.as<xyzz_mem_t<F>>(), c.wsum.as<xyzz_mem_t<F>>(), J);
+    const xyzz_mem_t<F>* tail_sums = pin;
+    const uint32_t *tail_start = start_in, *tail_cnt = cnt_in;
+    if (wide) {
+        const uint32_t slots = 2u << fold_m;
+        c.fold_sums.ensure((size_t)slots * sizeof(xyzz_mem_t<F>));
+        c.fold_idx.ensure((size_t)slots * 8);
+        uint32_t* fstart = c.fold_idx.as<uint32_t>();
+        uint32_t* fcnt = fstart + slots;
+        hipLaunchKernelGGL((msm_fold_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, pin,
+                           start_in, cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
+        tail_sums = c.fold_sums.as<xyzz_mem_t<F>>();
+        tail_start = fstart;
+        tail_cnt = fcnt;
+    }
+    const uint32_t total_threads = (uint32_t)tail_W * J;
+    hipLaunchKernelGGL((msm_bucket_reduce_kernel<F>), dim3((total_threads + 255) / 256), dim3(256), 0, st, tail_sums, tail_start, tail_cnt,
+                       c.contrib.as<xyzz_mem_t<F>>(), tail_nb, tail_L, total_threads);
+    hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(tail_W), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, c.contrib.as<xyzz_mem_t<F>>(), c.wsum.as<xyzz_mem_t<F>>(), J);
     phase_end();
     phase_begin("msm_final_horner");
-    hipLaunchKernelGGL((msm_final_kernel<F>), dim3(1), dim3(64), 0, st, c.wsum.as<xyzz_mem_t<F>>(), c.result.as<jac_mem_t<F>>(), pl.W, pl.c);
+    hipLaunchKernelGGL((msm_final_kernel<F>), dim3(1), dim3(64), 0, st, c.wsum.as<xyzz_mem_t<F>>(), c.result.as<jac_mem_t<F>>(), tail_W, tail_c);
     phase_end();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(jac_mem_t<F>), hipMemcpyDeviceToHost, st));  // `out` is pinned when !sync
@@ -652,17 +748,24 @@ RustError snarkvm_hip_msm_g2(void* out, const void* points, size_t npoints, cons
 static void precompute_tables(snarkvm_hip_bases* h) {
     for (int j = 1; j < h->tables; j++)
         hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, g_ctx.stream,
-                           h->d + (size_t)(j - 1) * h->n, h->d + (size_t)j * h->n, h->n, 256 / h->tables);
+                           h->d + (size_t)(j - 1) * h->n, h->d + (size_t)j * h->n, h->n, h->table_bits);
     HIP_TRY(hipGetLastError());
 }
-static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables) {
+static void check_tables(int tables, int table_bits, const char* who) {
+    const bool legacy = table_bits == 0 && (tables == 1 || tables == 2 || tables == 4 || tables == 8 || tables == 16);
+    const bool windowed = table_bits >= 2 && table_bits <= MSM_C_MAX && tables >= 1 && tables <= 127 && tables * table_bits >= 254;
+    if (!legacy && !windowed)
+        throw std::runtime_error(std::string(who) + ": tables must be 1, 2, 4, 8 or 16, or tables * window_bits >= 254 with window_bits in 2..23");
+}
+static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables,
+                                int table_bits = 0) {
     if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
     if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
-    if (tables != 1 && tables != 2 && tables != 4 && tables != 8 && tables != 16)
-        throw hip_failure{hipErrorInvalidValue, "register_bases: tables must be 1, 2, 4, 8 or 16", __LINE__};
+    check_tables(tables, table_bits, "register_bases");
     snarkvm_hip_bases* h = new snarkvm_hip_bases();
     h->n = npoints;
     h->tables = tables;
+    h->table_bits = table_bits ? table_bits : 256 / tables;
     if (npoints) {
         HIP_TRY(hipMalloc((void**)&h->d, (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
         const uint8_t* src = (const uint8_t*)points;
@@ -707,11 +810,11 @@ RustError snarkvm_hip_register_bases_serialized(snarkvm_hip_bases_t** handle, co
                                                 int tables) {
     API_BEGIN
     if (!handle || (npoints && !bytes)) throw hip_failure{hipErrorInvalidValue, "register_bases_serialized: null argument", __LINE__};
-    if (tables != 1 && tables != 2 && tables != 4 && tables != 8 && tables != 16)
-        throw hip_failure{hipErrorInvalidValue, "register_bases_serialized: tables must be 1, 2, 4, 8 or 16", __LINE__};
+    check_tables(tables, 0, "register_bases_serialized");
     snarkvm_hip_bases* h = new snarkvm_hip_bases();
     h->n = npoints;
     h->tables = tables;
+    h->table_bits = 256 / tables;
     if (npoints) {
         try {
             HIP_TRY(hipMalloc((void**)&h->d, (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
@@ -767,6 +870,13 @@ RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t** handle, const 
     register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables);
     API_END
 }
+RustError snarkvm_hip_register_bases_windowed(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
+                                              int tables, int window_bits) {
+    API_BEGIN
+    if (window_bits <= 0) throw hip_failure{hipErrorInvalidValue, "register_bases_windowed: window_bits must be positive", __LINE__};
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables, window_bits);
+    API_END
+}
 void snarkvm_hip_free_bases(snarkvm_hip_bases_t* h) {
     if (!h) return;
     std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -777,7 +887,7 @@ RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, si
                                      int scalars_on_device, int window_bits) {
     API_BEGIN
     if (!h || offset + npoints > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered: range exceeds the registered bases", __LINE__};
-    if (window_bits && (window_bits < 2 || window_bits > 16)) throw hip_failure{hipErrorInvalidValue, "msm_registered: window_bits must be 0 or 2..16", __LINE__};
+    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_registered: window_bits must be 0 or 2..23", __LINE__};
     const uint4* d_sc = (const uint4*)scalars;
     if (!scalars_on_device && npoints) {
         g_ctx.scalars_tmp.ensure(npoints * 32);
@@ -786,7 +896,7 @@ RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, si
         g_ctx.phase_end();
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
-    msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits, nullptr, ~(size_t)0, 0, h->tables, h->n);
+    msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits, nullptr, ~(size_t)0, 0, h->tables, h->n, 0, true, h->table_bits);
     API_END
 }
 
@@ -794,7 +904,7 @@ RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h,
                                         const void* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
     API_BEGIN
     if (!h || off0 + n0 > h->n || off1 + n1 > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: range exceeds the registered bases", __LINE__};
-    if (window_bits && (window_bits < 2 || window_bits > 16)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: window_bits must be 0 or 2..16", __LINE__};
+    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: window_bits must be 0 or 2..23", __LINE__};
     const size_t n = n0 + n1;
     const uint4* d_sc = (const uint4*)scalars;
     if (!scalars_on_device && n) {
@@ -804,14 +914,14 @@ RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h,
         g_ctx.phase_end();
         d_sc = g_ctx.scalars_tmp.as<uint4>();
     }
-    msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery, h->tables, h->n);
+    msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery, h->tables, h->n, 0, true, h->table_bits);
     API_END
 }
 RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t* h, size_t count, const size_t* offsets, const size_t* npoints,
                                            const void* const* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
     API_BEGIN
     if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null handle", __LINE__};
-    if (window_bits && (window_bits < 2 || window_bits > 16)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: window_bits must be 0 or 2..16", __LINE__};
+    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: window_bits must be 0 or 2..23", __LINE__};
     if (count * 144 > g_ctx.batch_pinned_cap) {
         if (g_ctx.batch_pinned) HIP_TRY(hipHostFree(g_ctx.batch_pinned));
         g_ctx.batch_pinned = nullptr;
@@ -832,7 +942,7 @@ RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t
             d_sc = ws.scalars.as<uint4>();
         }
         msm_run<fq_t>(g_ctx, h->d + offsets[k], d_sc, npoints[k], stage + 144 * k, window_bits, nullptr, ~(size_t)0, scalars_montgomery, h->tables,
-                      h->n, lane, false);
+                      h->n, lane, false, h->table_bits);
     }
     for (int l = 0; l < context_t::LANES; l++) HIP_TRY(hipStreamSynchronize(g_ctx.lane[l].stream));
     memcpy(outs, stage, count * 144);

@@ -55,20 +55,48 @@ static inline int msm_pick_c(size_t n) {
     if (c > 16) c = 16;
     return c;
 }
-// tables == 1: W = ceil(254 / c) windows.  tables == J > 1 (registered bases with precomputed 2^(256/J * j) multiples):
-// the 256 scalar bits split into J parts of 256/J bits; c must divide the part width.
-static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables = 1) {
+// tables == 1: W = ceil(254 / c) windows.  tables == J > 1 (registered bases with precomputed 2^(part * j) multiples,
+// part = table_bits, default 256 / J): the scalar bits split into J parts of `part` bits; c must divide the part width.
+// c > 16 ("wide" windows, one bucket window per table: c == part) needs J * c >= 254 and runs the three-level sort and the
+// two-axis bucket fold; it pays when every bucket still receives tens of points (J * n >> 2^(c-1)).
+static constexpr int MSM_C_MAX = 23;
+static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables = 1, int table_bits = 0) {
     msm_plan_t p;
     p.n = n;
     p.J = tables < 1 ? 1 : tables;
     if (p.J == 1) {
         p.c = c_override ? c_override : msm_pick_c(n);
+        if (p.c > 16) p.c = 16;
         p.W = (254 + p.c - 1) / p.c;
     } else {
-        const int part = 256 / p.J;
-        p.c = c_override ? c_override : (n >= 4096 ? 16 : 8);
-        if (p.c > part) p.c = part;
-        while (part % p.c) p.c--;  // largest divisor of the part width not above the request
+        const int part = table_bits > 0 ? table_bits : 256 / p.J;
+        if (c_override) {
+            p.c = c_override;
+            if (p.c > part) p.c = part;
+            while (part % p.c) p.c--;  // largest divisor of the part width not above the request
+            if (p.c > 16 && p.c != part) {  // wide windows exist only as one window per table
+                p.c = 16;
+                while (part % p.c) p.c--;
+            }
+        } else if (part <= 16) {
+            p.c = n >= 4096 ? 16 : 8;
+            if (p.c > part) p.c = part;
+            while (part % p.c) p.c--;
+        } else {
+            // wide tables: the divisor d of the part width (d <= 16, or the whole part) with the least estimated work:
+            // J * (part / d) * n bucket additions + ~8 addition-equivalents of sort / fold overhead per bucket
+            double best = 0;
+            p.c = 0;
+            for (int d = 2; d <= part && d <= MSM_C_MAX; d++) {
+                if (part % d || (d > 16 && d != part)) continue;
+                const double cost = (double)p.J * (part / d) * (double)n + (double)(part / d) * (double)((size_t)1 << (d - 1)) * 8.0;
+                if (p.c == 0 || cost < best) {
+                    best = cost;
+                    p.c = d;
+                }
+            }
+            if (p.c == 0) p.c = 1;
+        }
         p.W = part / p.c;
     }
     p.Wd = p.W * p.J;
@@ -83,7 +111,14 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     static const int env_S = getenv("SNARKVM_HIP_S") ? atoi(getenv("SNARKVM_HIP_S")) : 0;
     static const int env_S2 = getenv("SNARKVM_HIP_S2") ? atoi(getenv("SNARKVM_HIP_S2")) : 0;
     static const int env_L = getenv("SNARKVM_HIP_L") ? atoi(getenv("SNARKVM_HIP_L")) : 0;
-    p.S = env_S > 0 ? env_S : 64;
+    // points per accumulate thread: long segments amortise the partial-sum flushes of big MSMs, short ones keep >= ~4 waves
+    // per SIMD busy on small ones (the accumulate of a small MSM is S dependent additions of latency)
+    {
+        const size_t E = (size_t)p.Wd * n;
+        p.S = E >= ((size_t)1 << 27) ? 128 : 64;
+        while (p.S > 16 && E / p.S < ((size_t)1 << 18)) p.S >>= 1;
+    }
+    if (env_S > 0) p.S = env_S;
     p.S2 = env_S2 > 1 ? env_S2 : 8;
     p.L = env_L > 0 ? (uint32_t)env_L : 8;
     if (p.L > p.nb) p.L = p.nb;
@@ -193,7 +228,8 @@ struct msm_digit_params_t {
     size_t n;
     int montgomery;  // scalars are Fr elements in Montgomery form: fuse Fr::to_bigint (kzg10/mod.rs:469-474) into the read
 };
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
+template <class DT>  // uint16_t for c <= 16, uint32_t for wider windows
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict__ scalars, DT* __restrict__ digits,
                                                          msm_digit_params_t p) {
     // 256 scalars per block iteration: coalesced 16-byte loads into LDS, then one scalar per thread
     __shared__ uint4 stage[512];
@@ -225,7 +261,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict
             for (int w = 0; w < p.W; w++) {
                 const int bit = p.c * w, wi = bit >> 5, sh = bit & 31;
                 uint64_t two = (uint64_t)s[wi] | ((uint64_t)s[wi + 1] << 32);
-                digits[(size_t)w * p.n + i] = (uint16_t)((uint32_t)(two >> sh) & mask);
+                digits[(size_t)w * p.n + i] = (DT)((uint32_t)(two >> sh) & mask);
             }
         }
         __syncthreads();
@@ -534,7 +570,7 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const xyzz_mem_t
     xyzz_t<F> run = xyzz_t<F>::inf(), acc = xyzz_t<F>::inf();
     for (int l = (int)L - 1; l >= 0; l--) {
         const uint32_t k = k0 + (uint32_t)l;
-        if (cnt[k]) run.add(load_xyzz<F>(&sums[start[k]]));
+        for (uint32_t q = 0; q < cnt[k]; q++) run.add(load_xyzz<F>(&sums[start[k] + q]));  // a few partials may be left per bucket
         acc.add(run);
     }
     if (j) acc.add(run.mul_small(j * L));
@@ -561,6 +597,55 @@ __global__ void __launch_bounds__(256) msm_window_sum_kernel(const xyzz_mem_t<F>
         __syncthreads();
     }
     if (threadIdx.x == 0) wsum[w] = sh[0];
+}
+// 7b. Two-axis fold of one WIDE window (nb = 2^K buckets, K = hb + m): with bucket index b = hi * 2^m + lo,
+//        sum_b (b + 1) B_b = 2^m * sum_hi hi * H_hi + sum_lo (lo + 1) * L_lo,   H_hi = sum_lo B_(hi,lo),  L_lo = sum_hi B_(hi,lo),
+//     so 2 additions per bucket, all independent, replace the long running sums; what is left are two small "windows" of
+//     2^m entries (L at index lo, weight lo + 1; H_hi at index hi - 1, weight hi) combined by the regular tail with c = m.
+//     Workgroups [0, 2^m) fold columns (fixed lo), workgroups [2^m, 2^m + 2^hb) fold rows (fixed hi).
+template <class F>
+__global__ void __launch_bounds__(256) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
+                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out_sums,
+                                                       uint32_t* __restrict__ out_start, uint32_t* __restrict__ out_cnt, int m, int hb) {
+    extern __shared__ uint4 sh_raw[];
+    xyzz_mem_t<F>* sh = (xyzz_mem_t<F>*)sh_raw;
+    const uint32_t nlo = 1u << m, nhi = 1u << hb;
+    const bool column = blockIdx.x < nlo;
+    const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
+    const uint32_t slot = column ? fixed : nlo + fixed - 1;  // H_0 has weight 0 and no slot
+    if (!column && fixed == 0) {
+        if (threadIdx.x == 0) {  // the one unused slot at the top of window 1
+            out_start[2 * nlo - 1] = 2 * nlo - 1;
+            out_cnt[2 * nlo - 1] = 0;
+        }
+        return;
+    }
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    const uint32_t cntv = column ? nhi : nlo;
+    for (uint32_t i = threadIdx.x; i < cntv; i += blockDim.x) {
+        const uint32_t k = column ? (i << m) + fixed : (fixed << m) + i;
+        for (uint32_t q = 0; q < cnt[k]; q++) acc.add(load_xyzz<F>(&sums[start[k] + q]));
+    }
+    store_xyzz<F>(&sh[threadIdx.x], acc);
+    __syncthreads();
+    for (int off = (int)blockDim.x / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            xyzz_t<F> a = load_xyzz<F>(&sh[threadIdx.x]);
+            a.add(load_xyzz<F>(&sh[threadIdx.x + off]));
+            store_xyzz<F>(&sh[threadIdx.x], a);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_sums[slot] = sh[0];
+        out_start[slot] = slot;
+        out_cnt[slot] = 1;
+        if (!column && nhi < nlo + 1 && fixed == nhi - 1)  // slots of window 1 beyond the last H stay empty
+            for (uint32_t s2 = nlo + nhi - 1; s2 < 2 * nlo - 1; s2++) {
+                out_start[s2] = s2;
+                out_cnt[s2] = 0;
+            }
+    }
 }
 // 9. Horner across windows (batched.rs:404-413) and conversion to the reference's Jacobian memory image
 template <class F>

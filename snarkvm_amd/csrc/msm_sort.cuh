@@ -1,4 +1,4 @@
-// msm_sort.cuh - bucket sort of the MSM digit matrix by a two-level, LDS-staged radix partition.
+// msm_sort.cuh - bucket sort of the MSM digit matrix by a multi-level, LDS-staged radix partition.
 //
 // Why: the first sort scattered 4-byte entries with per-bucket cursors straight into HBM.  On MI355X the L2 is
 // write-through for such stores, so every entry left the chip as its own 32-byte sector: rocprofv3 WRITE_SIZE showed
@@ -6,10 +6,12 @@
 // groups the entries of its tile in LDS and then writes whole runs, so the stores of a wave instruction are contiguous:
 //
 //   level 1   tile = TILE digits of one digit row; key = top HB bits of the bucket index (<= 256 bins per window)
-//             -> v1[] (virtual index | sign<<31, 4 B) and l1[] (low LB bucket bits, 1 B), grouped by (window, bin)
-//   level 2   tile = TILE items of one (window, bin) segment; key = low LB bits (<= 128 sub-buckets)
-//             -> sorted[] (4 B entries) grouped by bucket k = window * nb + bin * 2^LB + low, i.e. bucket-major,
-//                with boff[k] = first position of bucket k (the accumulate kernel then reads one contiguous run)
+//             -> v[] (virtual index | sign<<31, 4 B) and rem[] (the remaining RB low bucket bits, 1 or 2 B),
+//                grouped by (window, bin)
+//   level k   tile = TILE items of one segment of the previous level; key = the next <= 7 bits of the remainder
+//             -> v'[] (+ rem'[] while bits remain), grouped by (segment, key); seg_start'[] = first position of each group
+//   Windows up to c = 16 take two levels (8 + 7 bits), wider windows (c <= 23, registered bases with one bucket window)
+//   three (8 + 7 + 7).  After the last level the entries are bucket-major: bucket k owns sorted[boff[k], boff[k+1]).
 //
 // Each level is histogram -> exclusive scan -> staged scatter; all positions are deterministic functions of the
 // histograms except the order inside a (tile, bin) run (LDS cursor order), which does not change any bucket's content.
@@ -24,7 +26,7 @@ static constexpr int SORT_THREADS = 256;   // 32 items per thread
 struct msm_radix_params_t {
     size_t n;              // scalars
     int c, W, J;           // window bits, bucket windows, base tables (digit row j*W + w feeds window w)
-    int HB, LB;            // bucket index = (bin << LB) | low, bin < 2^HB, low < 2^LB
+    int HB, LB;            // bucket index = (bin << LB) | rem, bin < 2^HB (level-1 key), rem < 2^LB (<= 7: one more level, <= 14: two)
     uint32_t nb;           // 2^(c-1)
     uint32_t tiles_per_row;  // ceil(n / SORT_TILE)
     uint32_t TPW;          // level-1 tiles per window = J * tiles_per_row
@@ -39,8 +41,35 @@ __device__ __forceinline__ bool digit_bucket(uint32_t u, int half, uint32_t& b, 
     return true;
 }
 
+// Visit the digits (u16 or u32) of scalars [lo, hi) of one row; 16-byte loads when the row is 16-byte aligned.
+template <class DT, class Fn>
+__device__ __forceinline__ void for_each_digit_t(const DT* __restrict__ d, size_t n, size_t lo, size_t hi, Fn fn) {
+    constexpr int DPV = 16 / (int)sizeof(DT);
+    if ((n & (DPV - 1)) == 0 && (lo & (DPV - 1)) == 0 && ((hi - lo) & (DPV - 1)) == 0) {
+        const uint4* d4 = (const uint4*)(d + lo);
+        const size_t nvec = (hi - lo) / DPV;
+        for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+            const uint4 q = d4[v];
+            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+            const size_t i = lo + v * DPV;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (sizeof(DT) == 2) {
+                    fn(wds[k] & 0xffffu, i + 2 * k);
+                    fn(wds[k] >> 16, i + 2 * k + 1);
+                } else {
+                    fn(wds[k], i + k);
+                }
+            }
+        }
+    } else {
+        for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) fn((uint32_t)d[i], i);
+    }
+}
+
 // ---- level 1 histogram: counts1[(w * B1 + bin) * TPW + tw]
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist1_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts1,
+template <class DT>
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist1_kernel(const DT* __restrict__ digits, uint32_t* __restrict__ counts1,
                                                                    msm_radix_params_t p) {
     __shared__ uint32_t hist[256];
     const uint32_t B1 = 1u << p.HB;
@@ -52,7 +81,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist1_kernel(const uint16_
     const size_t lo = (size_t)t * SORT_TILE;
     const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
     const int half = 1 << (p.c - 1);
-    for_each_digit(digits + (size_t)(j * p.W + w) * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
+    for_each_digit_t<DT>(digits + (size_t)(j * p.W + w) * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
         uint32_t b, neg;
         if (digit_bucket(u, half, b, neg)) atomicAdd(&hist[b >> p.LB], 1u);
     });
@@ -76,13 +105,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_t
     for (uint32_t k = 0; k < wv; k++) base += wave_tot[k];
     return base + inc - v;
 }
-__global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint16_t* __restrict__ digits,
+template <class DT, class RT>
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* __restrict__ digits,
                                                                       const uint32_t* __restrict__ counts1,
                                                                       const uint32_t* __restrict__ off1, uint32_t* __restrict__ v1,
-                                                                      uint8_t* __restrict__ l1, msm_radix_params_t p) {
+                                                                      RT* __restrict__ l1, msm_radix_params_t p) {
     __shared__ uint32_t lcount[256], lstart[256], cursor[256], gbase[256], wave_tot[4];
     __shared__ uint32_t sv_[SORT_TILE];
-    __shared__ uint8_t sl_[SORT_TILE], sbin_[SORT_TILE];
+    __shared__ RT sl_[SORT_TILE];
+    __shared__ uint8_t sbin_[SORT_TILE];
     const uint32_t B1 = 1u << p.HB;
     const uint32_t g = blockIdx.x;
     const uint32_t w = g / p.TPW, tw = g - w * p.TPW;
@@ -91,10 +122,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint
     const size_t lo = (size_t)t * SORT_TILE;
     const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
     const int half = 1 << (p.c - 1);
-    const uint16_t* row = digits + (size_t)(j * p.W + w) * p.n;
-    // full aligned tile: issue this thread's four 16-byte digit loads before anything else
-    const bool vec = (p.n & 7) == 0 && hi - lo == SORT_TILE;
-    constexpr int NV = SORT_TILE / 8 / SORT_THREADS;
+    const DT* row = digits + (size_t)(j * p.W + w) * p.n;
+    // full aligned tile: issue this thread's 16-byte digit loads before anything else
+    constexpr int DPV = 16 / (int)sizeof(DT);  // digits per 16-byte load
+    const bool vec = (p.n & (DPV - 1)) == 0 && hi - lo == SORT_TILE;
+    constexpr int NV = SORT_TILE / DPV / SORT_THREADS;
     uint4 dq[NV];
     if (vec) {
         const uint4* d4 = (const uint4*)(row + lo);
@@ -119,7 +151,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint
             const uint32_t bin = b >> p.LB;
             const uint32_t pos = atomicAdd(&cursor[bin], 1u);
             sv_[pos] = (voff + (uint32_t)i) | neg;
-            sl_[pos] = (uint8_t)(b & lmask);
+            sl_[pos] = (RT)(b & lmask);
             sbin_[pos] = (uint8_t)bin;
         }
     };
@@ -127,15 +159,19 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const uint
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const uint32_t wds[4] = {dq[k].x, dq[k].y, dq[k].z, dq[k].w};
-            const size_t i = lo + ((size_t)(threadIdx.x + k * SORT_THREADS) << 3);
+            const size_t i = lo + (size_t)(threadIdx.x + k * SORT_THREADS) * DPV;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                place(wds[m] & 0xffffu, i + 2 * m);
-                place(wds[m] >> 16, i + 2 * m + 1);
+                if (sizeof(DT) == 2) {
+                    place(wds[m] & 0xffffu, i + 2 * m);
+                    place(wds[m] >> 16, i + 2 * m + 1);
+                } else {
+                    place(wds[m], i + m);
+                }
             }
         }
     } else {
-        for_each_digit(row, p.n, lo, hi, place);
+        for_each_digit_t<DT>(row, p.n, lo, hi, place);
     }
     __syncthreads();
     const uint32_t total = lstart[B1 - 1] + lcount[B1 - 1];
@@ -160,10 +196,11 @@ __global__ void radix_bin_tiles_kernel(const uint32_t* __restrict__ binstart, ui
     ntiles[q] = (q == nbins) ? 0u : (binstart[q + 1] - binstart[q] + SORT_TILE - 1) / SORT_TILE;
 }
 
-// ---- level 2 histogram: counts2[tile2 * B2 + low]
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist2_kernel(const uint8_t* __restrict__ l1, const uint32_t* __restrict__ binstart,
+// ---- level k histogram: counts2[tile2 * B2 + key], key = (rem >> shift) & (B2 - 1) (B2 = 2^LB keys; `shift` bits stay for later levels)
+template <class RIN>
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist2_kernel(const RIN* __restrict__ l1, const uint32_t* __restrict__ binstart,
                                                                    const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ counts2,
-                                                                   uint32_t nbins, int LB) {
+                                                                   uint32_t nbins, int LB, int shift) {
     __shared__ uint32_t hist[128];
     const uint32_t t2 = blockIdx.x;
     if (t2 >= tile2_start[nbins]) return;
@@ -175,7 +212,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist2_kernel(const uint8_t
     const uint32_t lo = binstart[q] + lt * SORT_TILE;
     uint32_t hi = lo + SORT_TILE;
     if (hi > binstart[q + 1]) hi = binstart[q + 1];
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&hist[l1[i]], 1u);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&hist[((uint32_t)l1[i] >> shift) & (B2 - 1)], 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) counts2[(size_t)t2 * B2 + i] = hist[i];
 }
@@ -202,18 +239,66 @@ __global__ void radix_colscan2_kernel(const uint32_t* __restrict__ counts2, uint
     if (k <= nbt) bsize[k] = run;
     if (run) atomicMax(&blk_max, run);
     __syncthreads();
-    if (threadIdx.x == 0 && blk_max) atomicMax(max_size, blk_max);
+    // thousands of workgroups: only those that can still raise the maximum touch the global atomic
+    if (threadIdx.x == 0 && blk_max > __atomic_load_n(max_size, __ATOMIC_RELAXED)) atomicMax(max_size, blk_max);
 }
-// ---- level 2 scatter: sorted[boff[k] + off2[tile][low] + rank inside (tile, low)]
-__global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint32_t* __restrict__ v1, const uint8_t* __restrict__ l1,
+// Same result, one workgroup per SEGMENT (few segments with many tiles each: the per-key loop over ~100 tiles is split
+// over 8 slices of 128 key lanes).  blockDim.x must be 1024.
+__global__ void __launch_bounds__(1024) radix_colscan2_seg_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
+                                                                  const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ bsize,
+                                                                  uint32_t nbins, int LB, uint32_t* __restrict__ max_size) {
+    __shared__ uint32_t part[8][128];
+    __shared__ uint32_t blk_max;
+    const uint32_t B2 = 1u << LB;
+    const uint32_t q = blockIdx.x;
+    const uint32_t key = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    if (threadIdx.x == 0) blk_max = 0;
+    const uint32_t t0 = tile2_start[q], t1 = tile2_start[q + 1];
+    const uint32_t per = (t1 - t0 + 7) / 8;
+    uint32_t a = t0 + sl * per, b = a + per;
+    if (a > t1) a = t1;
+    if (b > t1) b = t1;
+    uint32_t s = 0;
+    if (key < B2)
+        for (uint32_t t2 = a; t2 < b; t2++) s += counts2[(size_t)t2 * B2 + key];
+    part[sl][key] = s;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (uint32_t i = 0; i < 8; i++) {
+        const uint32_t v = part[i][key];
+        if (i < sl) run += v;
+        total += v;
+    }
+    if (key < B2) {
+        for (uint32_t t2 = a; t2 < b; t2++) {
+            const size_t idx = (size_t)t2 * B2 + key;
+            const uint32_t cnt = counts2[idx];
+            off2[idx] = run;
+            run += cnt;
+        }
+        if (sl == 0) {
+            bsize[(size_t)q * B2 + key] = total;
+            if (total) atomicMax(&blk_max, total);
+        }
+    }
+    if (q == 0 && threadIdx.x == 0) bsize[(size_t)nbins * B2] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_max > __atomic_load_n(max_size, __ATOMIC_RELAXED)) atomicMax(max_size, blk_max);
+}
+// ---- level k scatter: out[boff[k] + off2[tile][key] + rank inside (tile, key)], k = q * B2 + key; the remainder bits below
+// `shift` travel along in rem_out while levels remain (rem_out == nullptr on the last level)
+template <class RIN, class ROUT>
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint32_t* __restrict__ v1, const RIN* __restrict__ l1,
                                                                       const uint32_t* __restrict__ binstart,
                                                                       const uint32_t* __restrict__ tile2_start,
                                                                       const uint32_t* __restrict__ counts2,
                                                                       const uint32_t* __restrict__ off2, const uint32_t* __restrict__ boff,
-                                                                      uint32_t* __restrict__ sorted, uint32_t nbins, int LB) {
+                                                                      uint32_t* __restrict__ sorted, ROUT* __restrict__ rem_out, uint32_t nbins,
+                                                                      int LB, int shift) {
     __shared__ uint32_t lcount[128], lstart[128], cursor[128], gbase[128], wave_tot[4];
     __shared__ uint32_t sv_[SORT_TILE];
     __shared__ uint8_t slow_[SORT_TILE];
+    __shared__ ROUT srem_[SORT_TILE];
     const uint32_t t2 = blockIdx.x;
     if (t2 >= tile2_start[nbins]) return;
     const uint32_t B2 = 1u << LB;
@@ -223,7 +308,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
     uint32_t hi = lo + SORT_TILE;
     if (hi > binstart[q + 1]) hi = binstart[q + 1];
     {
-        const uint32_t i = threadIdx.x;  // one low-bits value per thread (B2 <= 128 < SORT_THREADS)
+        const uint32_t i = threadIdx.x;  // one key per thread (B2 <= 128 < SORT_THREADS)
         const uint32_t cnt = (i < B2) ? counts2[(size_t)t2 * B2 + i] : 0u;
         const uint32_t start = block_excl_scan(cnt, wave_tot);
         if (i < 128) {
@@ -246,20 +331,25 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
             lv[k] = ok ? v1[i] : 0u;
             ll[k] = ok ? (uint32_t)l1[i] : 0xffffffffu;
         }
+        const uint32_t rmask = (1u << shift) - 1;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             if (ll[k] != 0xffffffffu) {
-                const uint32_t pos = atomicAdd(&cursor[ll[k]], 1u);
+                const uint32_t key = (ll[k] >> shift) & (B2 - 1);
+                const uint32_t pos = atomicAdd(&cursor[key], 1u);
                 sv_[pos] = lv[k];
-                slow_[pos] = (uint8_t)ll[k];
+                slow_[pos] = (uint8_t)key;
+                if (rem_out) srem_[pos] = (ROUT)(ll[k] & rmask);
             }
         }
     }
     __syncthreads();
     const uint32_t total = hi - lo;
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
-        const uint32_t low = slow_[pos];
-        sorted[(size_t)gbase[low] + (pos - lstart[low])] = sv_[pos];
+        const uint32_t key = slow_[pos];
+        const size_t dst = (size_t)gbase[key] + (pos - lstart[key]);
+        sorted[dst] = sv_[pos];
+        if (rem_out) rem_out[dst] = srem_[pos];
     }
 }
 
@@ -287,6 +377,55 @@ __global__ void __launch_bounds__(256) msm_accumulate_bm_kernel(const aff_mem_t<
         acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
     }
     store_xyzz<F>(&partial[t], acc);
+}
+
+// ---- balanced ("segmented") accumulate: thread t owns the S consecutive entries sorted[tS, (t+1)S) whatever buckets they
+// belong to, and flushes one partial sum per bucket it touches.  Every lane of a wave performs exactly S mixed additions,
+// so small or uneven buckets (wide windows: ~100 entries each) cost no SIMD idle time.  Bucket k receives one partial from
+// each of the threads tS in [boff[k] / S, (boff[k+1] - 1) / S]: cnt[k] = that count, slot = start[k] + (t - boff[k] / S),
+// the (cnt, start, partial) triple the reduce rounds consume.
+__global__ void msm_alloc_seg_kernel(const uint32_t* __restrict__ boff, uint32_t* __restrict__ cnt, uint32_t nbt, uint32_t S) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nbt) return;
+    uint32_t c = 0;
+    if (k < nbt) {
+        const uint32_t lo = boff[k], hi = boff[k + 1];
+        if (hi > lo) c = (hi - 1) / S - lo / S + 1;
+    }
+    cnt[k] = c;
+}
+template <class F>
+__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const aff_mem_t<F>* __restrict__ bases,
+                                                                 const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
+                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
+                                                                 const uint32_t* __restrict__ start, xyzz_mem_t<F>* __restrict__ partial,
+                                                                 uint32_t nbt, uint32_t S, uint32_t n, size_t table_stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = boff[nbt];
+    const uint64_t lo64 = (uint64_t)t * S;
+    if (lo64 >= total) return;
+    const uint32_t lo = (uint32_t)lo64;
+    const uint32_t hi = (total - lo < S) ? total : lo + S;
+    uint32_t k = find_bucket(boff, nbt, lo);  // the non-empty bucket that contains entry `lo`
+    uint32_t kend = boff[k + 1];
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    for (uint32_t pos = lo; pos < hi; pos++) {
+        if (pos >= kend) {  // bucket k ends inside this segment: flush and move to the bucket of `pos`
+            store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);
+            acc = xyzz_t<F>::inf();
+            do {
+                k++;
+                kend = boff[k + 1];
+            } while (pos >= kend);
+        }
+        const uint32_t e = sorted[pos];
+        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
+        const uint32_t tbl = v / n;
+        const uint32_t idx = v - tbl * n;    // bases come in up to two segments
+        const aff_mem_t<F> raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
+        acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
+    }
+    store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);
 }
 
 }  // namespace sv

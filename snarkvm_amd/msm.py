@@ -23,20 +23,27 @@ class VariableBase:
 class RegisteredBases:
     """Device-resident base vector (snarkvm_hip_register_bases)."""
 
-    def __init__(self, bases=None, device_ptr=None, npoints=None, tables=1):
-        """tables > 1 precomputes 2^(256/tables * j) * P_i (j < tables) once, shrinking the serial tail of every MSM."""
+    def __init__(self, bases=None, device_ptr=None, npoints=None, tables=1, window_bits=0):
+        """tables > 1 precomputes 2^(256/tables * j) * P_i (j < tables) once, shrinking the serial tail of every MSM.
+        window_bits > 0 selects the general form: table j = 2^(window_bits * j) * P_i with tables * window_bits >= 254;
+        window_bits up to 23 (e.g. tables=12, window_bits=22 for n ~ 2^24) trades bucket additions for bucket count."""
         L = _lib.lib()
         self._h = ctypes.c_void_p()
         self.tables = int(tables)
+        self.window_bits = int(window_bits)
         if device_ptr is not None:
             self.n = int(npoints)
-            err = L.snarkvm_hip_register_bases_tables(ctypes.byref(self._h), ctypes.c_void_p(device_ptr), ctypes.c_size_t(self.n),
-                                                      ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(1), ctypes.c_int(self.tables))
+            src, on_device = ctypes.c_void_p(device_ptr), 1
         else:
             bases = np.ascontiguousarray(bases, dtype=G1_AFFINE).reshape(-1)
             self.n = bases.shape[0]
-            err = L.snarkvm_hip_register_bases_tables(ctypes.byref(self._h), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(self.n),
-                                                      ctypes.c_size_t(G1_AFFINE.itemsize), ctypes.c_int(0), ctypes.c_int(self.tables))
+            src, on_device = ctypes.c_void_p(bases.ctypes.data), 0
+        if self.window_bits:
+            err = L.snarkvm_hip_register_bases_windowed(ctypes.byref(self._h), src, ctypes.c_size_t(self.n), ctypes.c_size_t(G1_AFFINE.itemsize),
+                                                        ctypes.c_int(on_device), ctypes.c_int(self.tables), ctypes.c_int(self.window_bits))
+        else:
+            err = L.snarkvm_hip_register_bases_tables(ctypes.byref(self._h), src, ctypes.c_size_t(self.n), ctypes.c_size_t(G1_AFFINE.itemsize),
+                                                      ctypes.c_int(on_device), ctypes.c_int(self.tables))
         _lib.check(err)
 
     @classmethod
@@ -47,6 +54,7 @@ class RegisteredBases:
 
         self = cls.__new__(cls)
         self.tables = int(tables)
+        self.window_bits = 0
         self.n = int(npoints)
         self._h = serialize.register_bases_serialized(data, npoints, compressed, validate, tables)
         return self

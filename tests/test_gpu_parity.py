@@ -292,6 +292,76 @@ def test_msm_full_size_closed_form(lg):
     rb.close()
 
 
+@pytest.mark.parametrize("tables,window_bits", [(15, 17), (15, 18), (13, 20), (12, 22), (12, 23)])
+def test_msm_wide_windows_vs_oracle(golden, tables, window_bits):
+    """Registered bases with 2^(window_bits * j) tables and ONE window wider than 16 bits: u32 digits, three-level sort,
+    two-axis bucket fold.  Forced (window_bits passed to the call) and automatic window choice, edge scalars included."""
+    n = 40000
+    bases = _srs(golden, n)
+    bases[17]["infinity"] = 1
+    sc = synthetic.random_fr_integers(n, 7000 + window_bits)
+    r = pyref.R_MOD
+    sc[0] = 0
+    sc[1] = util.limbs(1, 4)
+    sc[2] = util.limbs(r - 1, 4)
+    sc[3] = util.limbs((1 << 252) + 12345, 4)
+    sc[4] = sc[5]
+    sc[100:200] = 0
+    rb = RegisteredBases(bases, tables=tables, window_bits=window_bits)
+    want = oracle.g1_to_affine(oracle.g1_msm(bases, sc))
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc, window_bits=window_bits)), want)   # wide path forced
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc)), want)                            # planner's choice
+    # sub-range with an offset, tiny and empty inputs through the same handle
+    want2 = oracle.g1_to_affine(oracle.g1_msm(bases[1000:1777], sc[:777]))
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc[:777], offset=1000, window_bits=window_bits)), want2)
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc[:777], offset=1000)), want2)
+    one = oracle.g1_to_affine(oracle.g1_msm(bases[5:6], sc[5:6]))
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc[5:6], offset=5, window_bits=window_bits)), one)
+    assert oracle.g1_to_affine(rb.msm(sc[:0]))["infinity"][0] == 1
+    # batch API over the wide tables
+    got = rb.msm_batch([sc, sc[:12345]], window_bits=window_bits)
+    assert util.affine_equal(oracle.g1_to_affine(got[0:1]), want)
+    assert util.affine_equal(oracle.g1_to_affine(got[1:2]), oracle.g1_to_affine(oracle.g1_msm(bases[:12345], sc[:12345])))
+    rb.close()
+
+
+def test_msm_wide_windows_skewed_buckets(golden):
+    """All scalars equal / tiny: every digit lands in a handful of buckets (multi-round partial reduction on the wide path)."""
+    n = 30000
+    bases = _srs(golden, n)
+    rb = RegisteredBases(bases, tables=12, window_bits=22)
+    for val in (3, (1 << 21) + 1, pyref.R_MOD - 2):
+        sc = np.tile(util.limbs(val, 4), (n, 1))
+        want = oracle.g1_to_affine(oracle.g1_msm(bases, sc))
+        assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc, window_bits=22)), want), val
+    rb.close()
+
+
+def test_msm_2_24_wide_closed_form():
+    """2^24 pairs over 12 tables of 22-bit windows (the bench configuration), closed form as above."""
+    import torch
+
+    n = 1 << 24
+    buf = _device_bases(n, start=1)
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=12, window_bits=22)
+    del buf
+    sc = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    got = rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
+    k = util.weighted_sum_mod_r(sc, start=1)
+    want = oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), util.limbs(k, 4)))
+    assert util.affine_equal(oracle.g1_to_affine(got), want)
+    # witness-like scalars (half zero, a quarter small): heavily skewed low buckets
+    sc2 = synthetic.witness_like_scalars(n, 31337)
+    d_sc2 = torch.from_numpy(sc2.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    got2 = rb.msm(device_ptr=d_sc2.data_ptr(), npoints=n)
+    k2 = util.weighted_sum_mod_r(sc2, start=1)
+    assert util.affine_equal(oracle.g1_to_affine(got2), oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), util.limbs(k2, 4))))
+    rb.close()
+
+
 # ------------------------------------------------------------------------------------------ G2
 def _g2_bases(golden, n):
     from oracle import cpu as o
