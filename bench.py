@@ -190,7 +190,7 @@ def main():
     # configuration they were collected on; PMC collection cannot run inside this process.
     pmc = {}
     try:
-        if args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 16 and not args.window_bits:
+        if args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pmc = json.load(f)["kernels"]
     except Exception:
@@ -231,12 +231,12 @@ def main():
             # bases (96 B) + sorted index (4 B) per (pair, window) - reported against the HBM peak for context.
             "roofline": {
                 "bound": "hbm",
-                "kernel": "msm_accumulate_bm_kernel",
+                "kernel": "msm_accumulate_seg_kernel",
                 "achieved": (n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 if acc_ms else None,
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
-                "traffic": traffic("msm_accumulate_bm_kernel<Fp<FqP> >", "fetch_bytes_raw"),
+                "traffic": traffic("msm_accumulate_seg_kernel<Fp<FqP> >", "fetch_bytes_raw"),
                 "algorithmic_bytes": n * 100.0 * W,
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d); see roofline_scalar_read for the HBM-bound phase",
             },
@@ -248,7 +248,7 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
-                "traffic": traffic("msm_digits_kernel", "fetch_bytes_x2"),
+                "traffic": traffic("msm_digits_kernel<unsigned int>", "fetch_bytes_x2"),
                 "algorithmic_bytes": 32.0 * n,
                 "bytes_incl_digit_writes_GBps": ((32.0 + (4.0 if cbits > 16 else 2.0) * W) * n) / (dig_ms * 1e-3) / 1e9 if dig_ms else None,
             },

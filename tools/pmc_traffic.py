@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite output) into profiles/*_pmc_traffic.json:
+bytes per dispatch and kernel.  FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE under-reports 16 B/lane
+streaming loads by 2x (MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are kept."""
+import json
+import sqlite3
+import sys
+
+
+def per_dispatch(path, counter):
+    db = sqlite3.connect(path)
+    cols = [d[0] for d in db.execute("select * from counters_collection limit 1").description]
+    ix = {c: i for i, c in enumerate(cols)}
+    agg = {}
+    for r in db.execute("select * from counters_collection"):
+        if r[ix["counter_name"]] != counter:
+            continue
+        # rocprofv3 emits one row per (dispatch, counter instance): sum the instances of a dispatch, average over dispatches
+        key = r[ix["kernel_name"]].split("(")[0].replace("sv::", "").replace("void ", "")
+        d = agg.setdefault(key, {})
+        did = r[ix["dispatch_id"]] if "dispatch_id" in ix else len(d)
+        d[did] = d.get(did, 0.0) + float(r[ix["value"]])
+    return {k: sum(v.values()) / len(v) * 1024.0 for k, v in agg.items()}
+
+
+def main():
+    fetch_db, write_db, source = sys.argv[1], sys.argv[2], sys.argv[3]
+    f = per_dispatch(fetch_db, "FETCH_SIZE")
+    w = per_dispatch(write_db, "WRITE_SIZE")
+    out = {
+        "source": source,
+        "units": "bytes per dispatch; FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE is "
+                 "doubled for 16 B/lane streaming loads on gfx950 (fetch_bytes_x2); gathers are quoted raw",
+        "kernels": {k: {"fetch_bytes_raw": f.get(k, 0.0), "fetch_bytes_x2": 2 * f.get(k, 0.0), "write_bytes": w.get(k, 0.0)} for k in sorted(set(f) | set(w))},
+    }
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
