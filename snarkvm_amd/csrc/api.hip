@@ -243,10 +243,12 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     // tail geometry: a wide window is first folded into two windows of 2^fold_m entries (msm_fold_kernel)
     const int K = pl.c - 1;
     const int fold_m = (K + 1) / 2, fold_hb = K - fold_m;
-    const uint32_t tail_nb = wide ? (1u << fold_m) : pl.nb;
-    const int tail_W = wide ? 2 : pl.W;
-    const int tail_c = wide ? fold_m : pl.c;
-    uint32_t tail_L = pl.L;
+    static const int fold_min_k = getenv("SNARKVM_HIP_FOLD_MIN_K") ? atoi(getenv("SNARKVM_HIP_FOLD_MIN_K")) : 11;
+    const bool fold = pl.W == 1 && (wide || K >= fold_min_k);  // also shortens the latency-bound tail of 16-bit windows
+    const uint32_t tail_nb = fold ? (1u << fold_m) : pl.nb;
+    const int tail_W = fold ? 2 : pl.W;
+    const int tail_c = fold ? fold_m : pl.c;
+    uint32_t tail_L = fold ? (pl.L < 4 ? pl.L : 4) : pl.L;
     if (tail_L > tail_nb) tail_L = tail_nb;
     while (tail_nb % tail_L) tail_L--;
     const uint32_t J = tail_nb / tail_L;
@@ -392,9 +394,15 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
-            hipLaunchKernelGGL((msm_accumulate_seg_kernel<F>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                               d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                               c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
+            static const int acc_minw = getenv("SNARKVM_HIP_ACC_MINW") ? atoi(getenv("SNARKVM_HIP_ACC_MINW")) : 1;
+            if (acc_minw >= 3 && sizeof(typename F::mem_t) == 48)
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 3>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                                   d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
+            else
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                                   d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
         } else {
             for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
             hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
@@ -495,7 +503,7 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     phase_begin("msm_bucket_reduce");
     const xyzz_mem_t<F>* tail_sums = pin;
     const uint32_t *tail_start = start_in, *tail_cnt = cnt_in;
-    if (wide) {
+    if (fold) {
         const uint32_t slots = 2u << fold_m;
         c.fold_sums.ensure((size_t)slots * sizeof(xyzz_mem_t<F>));
         c.fold_idx.ensure((size_t)slots * 8);

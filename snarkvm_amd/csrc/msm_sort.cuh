@@ -394,8 +394,8 @@ __global__ void msm_alloc_seg_kernel(const uint32_t* __restrict__ boff, uint32_t
     }
     cnt[k] = c;
 }
-template <class F>
-__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const aff_mem_t<F>* __restrict__ bases,
+template <class F, int MINW>  // MINW: waves per SIMD asked of the register allocator (3 -> <= 168 VGPRs for G1)
+__global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff_mem_t<F>* __restrict__ bases,
                                                                  const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
                                                                  const uint32_t* __restrict__ start, xyzz_mem_t<F>* __restrict__ partial,
