@@ -46,11 +46,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; a launcher that already narrowed HIP_VISIBLE_DEVICES to one device per rank leaves index 0
+    dev_index = local_rank if (world > 1 and torch.cuda.device_count() > local_rank) else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
         torch.cuda.set_device(0)
 
@@ -59,7 +61,7 @@ def main():
     from snarkvm_amd.msm import RegisteredBases
 
     L = _lib.lib()
-    _lib.check(L.snarkvm_hip_set_device(ctypes.c_int(local_rank if world > 1 else 0)))
+    _lib.check(L.snarkvm_hip_set_device(ctypes.c_int(dev_index)))
 
     def barrier():
         torch.cuda.synchronize()
