@@ -146,6 +146,17 @@ RustError snarkvm_hip_g1_to_affine(void *out_affine, const void *in_projective, 
 RustError snarkvm_hip_msm_g2(void *out, const void *points_with_infinity, size_t npoints, const void *scalars,
                              size_t ffi_affine_sz);
 
+/* Registered G2 bases (static G2 vectors, e.g. powers of beta H): the same precomputed-table scheme as
+ * snarkvm_hip_register_bases_tables / _windowed (window_bits = 0: tables in {1, 2, 4, 8, 16} of 256 / tables bits).  Without
+ * tables a G2 MSM ends in a serial chain of ~240 Fq2 doublings (~10 ms whatever its size); with them that chain is gone.
+ * `points` is a host Rust `[G2Affine]` (stride >= 200), `out` a G2Projective (288 B). */
+typedef struct snarkvm_hip_bases_g2 snarkvm_hip_bases_g2_t;
+RustError snarkvm_hip_register_bases_g2(snarkvm_hip_bases_g2_t **handle, const void *points, size_t npoints,
+                                        size_t ffi_affine_sz, int tables, int window_bits);
+void snarkvm_hip_free_bases_g2(snarkvm_hip_bases_g2_t *handle);
+RustError snarkvm_hip_msm_g2_registered(void *out, const snarkvm_hip_bases_g2_t *handle, size_t offset, size_t npoints,
+                                        const void *scalars, int scalars_on_device, int window_bits);
+
 /* Fr vector helpers on device memory: out[i] = a[i] * b[i] (polynomial_inner_multiply,
  * polynomial.cuh:36-45); Fr::to_bigint / from_bigint over a vector (kzg10/mod.rs:469-474). */
 RustError snarkvm_hip_fr_mul_device(void *d_out, const void *d_a, const void *d_b, size_t n);

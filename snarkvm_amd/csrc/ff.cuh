@@ -488,6 +488,11 @@ struct fq2_t {
         return {a - mul5(b), m.dbl()};
     }
     SV_HD static fq2_t diff_of_products(const fq2_t& a, const fq2_t& b, const fq2_t& c, const fq2_t& d) { return a * b - c * d; }
+    // fp2.rs:167-184: (c0 - c1 u) / (c0^2 + 5 c1^2) since u^2 = -5; a != 0
+    SV_HD fq2_t inverse() const {
+        const fq_t ninv = (c0.sqr() + mul5(c1.sqr())).inverse();
+        return {c0 * ninv, (c1 * ninv).neg()};
+    }
     SV_HD static fq2_t load(const void* p) {
         const uint8_t* q = (const uint8_t*)p;
         return {fq_t::load(q), fq_t::load(q + 48)};

@@ -129,6 +129,40 @@ def msm_g2(bases, scalars):
     return out
 
 
+class RegisteredBasesG2:
+    """Device-resident G2 base vector with precomputed tables (snarkvm_hip_register_bases_g2)."""
+
+    def __init__(self, bases, tables=16, window_bits=0):
+        from .layout import G2_AFFINE
+
+        bases = np.ascontiguousarray(bases, dtype=G2_AFFINE).reshape(-1)
+        self.n = bases.shape[0]
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().snarkvm_hip_register_bases_g2(ctypes.byref(self._h), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(self.n),
+                                                           ctypes.c_size_t(G2_AFFINE.itemsize), ctypes.c_int(int(tables)), ctypes.c_int(int(window_bits))))
+
+    def msm(self, scalars, offset=0, window_bits=0):
+        from .layout import G2_PROJECTIVE
+
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(1, dtype=G2_PROJECTIVE)
+        _lib.check(_lib.lib().snarkvm_hip_msm_g2_registered(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(offset),
+                                                           ctypes.c_size_t(scalars.shape[0]), ctypes.c_void_p(scalars.ctypes.data), ctypes.c_int(0),
+                                                           ctypes.c_int(window_bits)))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().snarkvm_hip_free_bases_g2(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def g1_sum(points):
     """Sum of G1Projective records on the device (snarkvm_hip_g1_sum): the combine step of a point-range-split MSM."""
     pts = np.ascontiguousarray(points)

@@ -515,3 +515,28 @@ def test_g1_sum_of_partial_results(golden):
     assert oracle.g1_to_affine(g1_sum(np.concatenate([p, neg])))["infinity"][0] == 1
     assert util.affine_equal(oracle.g1_to_affine(g1_sum(np.concatenate([p, p]))), oracle.g1_to_affine(oracle.g1_add(p, p)))
     rb.close()
+
+
+@pytest.mark.parametrize("tables,window_bits", [(16, 0), (4, 0), (15, 17)])
+def test_g2_registered_tables_vs_oracle(golden, tables, window_bits):
+    """Registered G2 bases with precomputed tables (no Horner chain) equal `standard::msm` on the same inputs."""
+    from snarkvm_amd.msm import RegisteredBasesG2
+
+    n = 3000
+    bases = _g2_bases(golden, n)
+    bases[7]["infinity"] = 1
+    sc = synthetic.random_fr_integers(n, 5150)
+    sc[0] = 0
+    sc[1] = util.limbs(1, 4)
+    sc[2] = util.limbs(pyref.R_MOD - 1, 4)
+    sc[9] = sc[10]
+    rb = RegisteredBasesG2(bases, tables=tables, window_bits=window_bits)
+    from oracle import cpu as o
+
+    want = o.g2_to_affine(o.g2_msm(bases, sc))
+    assert o.g2_to_affine(rb.msm(sc)).tobytes() == want.tobytes()
+    if window_bits:
+        assert o.g2_to_affine(rb.msm(sc, window_bits=window_bits)).tobytes() == want.tobytes()  # wide path over Fq2
+    want2 = o.g2_to_affine(o.g2_msm(bases[100:433], sc[:333]))
+    assert o.g2_to_affine(rb.msm(sc[:333], offset=100)).tobytes() == want2.tobytes()
+    rb.close()

@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 
 from oracle import cpu as oracle  # noqa: E402  (base generation + CPU baseline leg)
 from snarkvm_amd import _lib, synthetic  # noqa: E402
-from snarkvm_amd.msm import msm_g2  # noqa: E402
+from snarkvm_amd.msm import RegisteredBasesG2, msm_g2  # noqa: E402
 
 
 def main():
@@ -29,8 +29,8 @@ def main():
         proj[i] = oracle.g2_mul(gen, s)[0]
     distinct = oracle.g2_to_affine(proj)
     oracle.set_threads(min(64, oracle.max_threads()))
-    print("| lg n | GPU ms (host buffers, PCIe incl.) | pairs/s | kernel phases ms | CPU standard::msm pairs/s |")
-    print("|---|---|---|---|---|")
+    print("| lg n | one-shot GPU ms (host buffers, PCIe incl.) | pairs/s | registered (16 tables) ms | pairs/s | kernel phases ms (one-shot) | CPU standard::msm pairs/s |")
+    print("|---|---|---|---|---|---|---|")
     for lg in (12, 16, 18):
         n = 1 << lg
         bases = np.tile(distinct, n // 1024)
@@ -41,6 +41,14 @@ def main():
         for _ in range(reps):
             msm_g2(bases, sc)
         dt = (time.perf_counter() - t0) / reps
+        rb = RegisteredBasesG2(bases, tables=16)
+        got_r = rb.msm(sc)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rb.msm(sc)
+        dtr = (time.perf_counter() - t0) / reps
+        rb.close()
+        assert oracle.g2_to_affine(got_r).tobytes() == oracle.g2_to_affine(got).tobytes()
         L.snarkvm_hip_set_profiling(1)
         msm_g2(bases, sc)
         ph = {L.snarkvm_hip_get_phase_name(i).decode(): round(L.snarkvm_hip_get_phase_ms(i), 3) for i in range(L.snarkvm_hip_get_phase_count())}
@@ -51,7 +59,7 @@ def main():
             want = oracle.g2_msm(bases, sc)
             cpu = f"{n / (time.perf_counter() - t0):.3e}"
             assert oracle.g2_to_affine(got).tobytes() == oracle.g2_to_affine(want).tobytes()
-        print(f"| {lg} | {dt * 1e3:.3f} | {n / dt:.3e} | {ph} | {cpu} |")
+        print(f"| {lg} | {dt * 1e3:.3f} | {n / dt:.3e} | {dtr * 1e3:.3f} | {n / dtr:.3e} | {ph} | {cpu} |")
 
 
 if __name__ == "__main__":
