@@ -157,6 +157,15 @@ void snarkvm_hip_free_bases_g2(snarkvm_hip_bases_g2_t *handle);
 RustError snarkvm_hip_msm_g2_registered(void *out, const snarkvm_hip_bases_g2_t *handle, size_t offset, size_t npoints,
                                         const void *scalars, int scalars_on_device, int window_bits);
 
+/* Setup-time group operations.  Host buffers.
+ * fixed_base_msm: out[i] (G1Projective, 144 B) = scalars[i] * g for one base `g` (Rust G1Affine, 104 B) and n Fr
+ *   scalars in Montgomery form - FixedBase::msm (msm/fixed_base.rs:33-97; the window table is built on the device).
+ * group_ntt: in-place radix-2 transform of 2^lg G1Projective points with Fr twiddles; inverse = 1 includes the 1/n
+ *   scaling - `EvaluationDomain::ifft` over group elements as used by UniversalParams::lagrange_basis
+ *   (polycommit/kzg10/data_structures.rs:68-72).  Results are group elements: compare after to_affine. */
+RustError snarkvm_hip_g1_fixed_base_msm(void *out_projective, const void *g_affine, const void *scalars, size_t n);
+RustError snarkvm_hip_g1_group_ntt(void *inout_projective, uint32_t lg_domain_size, int inverse);
+
 /* Fr vector helpers on device memory: out[i] = a[i] * b[i] (polynomial_inner_multiply,
  * polynomial.cuh:36-45); Fr::to_bigint / from_bigint over a vector (kzg10/mod.rs:469-474). */
 RustError snarkvm_hip_fr_mul_device(void *d_out, const void *d_a, const void *d_b, size_t n);

@@ -254,3 +254,27 @@ def mul_by_vanishing(poly, domain_size):
     out = np.zeros((poly.shape[0] + domain_size, 4), dtype=np.uint64)
     lib().oracle_fr_mul_by_vanishing(_p(poly), ctypes.c_size_t(poly.shape[0]), ctypes.c_size_t(domain_size), _p(out))
     return out
+
+
+# ---- setup-time group operations ----
+def g1_fixed_base_msm(g_affine, scalars_mont, scalar_size=253, window=None):
+    """FixedBase::msm with the reference's own window rule when `window` is None."""
+    g = np.ascontiguousarray(g_affine, dtype=G1_AFFINE).reshape(1)
+    v = _fr(scalars_mont)
+    if window is None:
+        n = v.shape[0]
+        lg = 0
+        while (1 << lg) < n:
+            lg += 1
+        window = 3 if n < 32 else lg * 69 // 100 + 2
+    out = np.zeros(v.shape[0], dtype=G1_PROJECTIVE)
+    lib().oracle_g1_fixed_base_msm(_p(g), ctypes.c_size_t(scalar_size), ctypes.c_size_t(window), _p(v), ctypes.c_size_t(v.shape[0]), _p(out))
+    return out
+
+
+def g1_group_ntt(points_proj, inverse=False):
+    pts = np.array(points_proj, dtype=G1_PROJECTIVE, copy=True).reshape(-1)
+    lg = pts.shape[0].bit_length() - 1
+    assert 1 << lg == pts.shape[0]
+    lib().oracle_g1_group_ntt(_p(pts), ctypes.c_uint32(lg), ctypes.c_int(1 if inverse else 0))
+    return pts

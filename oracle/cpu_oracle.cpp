@@ -1175,6 +1175,109 @@ static void evaluate_all_lagrange_coefficients(const EvaluationDomain& d, const 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Setup-time group operations
+// ---------------------------------------------------------------------------------------------
+typedef Projective<Fq> G1P;
+static constexpr size_t FR_MODULUS_BITS = 253;  // fr.rs MODULUS_BITS
+// `ProjectiveCurve::mul` by a 256-bit integer: MSB-first double-and-add (projective.rs `mul_bits` over BitIteratorBE)
+static G1P proj_mul(const G1P& base, const uint64_t* k) {
+    G1P out = G1P::zero();
+    bool started = false;
+    for (int w = 3; w >= 0; w--)
+        for (int b = 63; b >= 0; b--) {
+            const bool bit = (k[w] >> b) & 1;
+            if (!started && !bit) continue;
+            started = true;
+            out.double_in_place();
+            if (bit) out.add_assign(base);
+        }
+    return out;
+}
+// FixedBase::get_window_table (msm/fixed_base.rs:33-68)
+static std::vector<std::vector<G1P>> fixed_window_table(size_t scalar_size, size_t window, G1P g) {
+    const size_t in_window = (size_t)1 << window;
+    const size_t outerc = (scalar_size + window - 1) / window;
+    const size_t last_in_window = (size_t)1 << (scalar_size - (outerc - 1) * window);
+    std::vector<std::vector<G1P>> multiples(outerc, std::vector<G1P>(in_window, G1P::zero()));
+    std::vector<G1P> g_outers;
+    G1P g_outer = g;
+    for (size_t o = 0; o < outerc; o++) {
+        g_outers.push_back(g_outer);
+        for (size_t i = 0; i < window; i++) g_outer.double_in_place();
+    }
+#pragma omp parallel for schedule(dynamic)
+    for (size_t outer = 0; outer < outerc; outer++) {
+        const size_t cur = (outer == outerc - 1) ? last_in_window : in_window;
+        G1P g_inner = G1P::zero();
+        for (size_t inner = 0; inner < cur; inner++) {
+            multiples[outer][inner] = g_inner;
+            g_inner.add_assign(g_outers[outer]);
+        }
+    }
+    return multiples;
+}
+// FixedBase::windowed_mul (fixed_base.rs:70-90): bits of scalar.to_bigint(), one table entry per window, + table[0][0]
+static G1P fixed_windowed_mul(size_t outerc, size_t window, const std::vector<std::vector<G1P>>& table, const Fr& scalar) {
+    uint64_t k[4];
+    scalar.to_bigint(k);
+    G1P sum = G1P::zero();
+    for (size_t outer = 0; outer < outerc; outer++) {
+        size_t inner = 0;
+        for (size_t i = 0; i < window; i++) {
+            const size_t bit = outer * window + i;
+            if (bit < FR_MODULUS_BITS && ((k[bit >> 6] >> (bit & 63)) & 1)) inner |= (size_t)1 << i;
+        }
+        sum.add_assign(table[outer][inner]);
+    }
+    sum.add_assign(table[0][0]);
+    return sum;
+}
+// EvaluationDomain::ifft over group elements (fft/domain.rs:177-192 with T = G1Projective): the same linear map as for
+// field elements - bit-reverse, radix-2 decimation-in-time butterflies with powers of group_gen_inv, then * size_inv.
+static void group_ifft(G1P* x, uint32_t lg, bool inverse) {
+    EvaluationDomain d;
+    EvaluationDomain::make((size_t)1 << lg, d);
+    const size_t n = (size_t)1 << lg;
+    for (size_t i = 0; i < n; i++) {
+        const size_t r = lg ? (size_t)bitrev64(i, lg) : 0;
+        if (i < r) std::swap(x[i], x[r]);
+    }
+    const Fr root = inverse ? d.group_gen_inv : d.group_gen;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        uint64_t e[1] = {(uint64_t)(n / len)};
+        const Fr wlen = root.pow(e, 1);
+        const size_t half = len / 2;
+        std::vector<Fr> tw(half);
+        Fr w = Fr::one();
+        for (size_t j = 0; j < half; j++) {
+            tw[j] = w;
+            w *= wlen;
+        }
+#pragma omp parallel for schedule(static)
+        for (size_t t = 0; t < n / 2; t++) {
+            const size_t blk = t / half, j = t % half;
+            const size_t ia = blk * len + j, ib = ia + half;
+            uint64_t k[4];
+            tw[j].to_bigint(k);
+            const G1P v = proj_mul(x[ib], k);
+            G1P u = x[ia];
+            G1P nv = v;
+            nv.y = nv.y.neg();
+            x[ia].add_assign(v);
+            u.add_assign(nv);
+            x[ib] = u;
+        }
+    }
+    if (inverse) {
+        uint64_t k[4];
+        d.size_inv.to_bigint(k);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; i++) x[i] = proj_mul(x[i], k);
+    }
+}
+
 extern "C" {
 int oracle_max_threads() { return (int)max_threads(); }
 void oracle_set_threads(int n) { set_threads(n); }
@@ -1288,6 +1391,21 @@ void oracle_fr_mul_by_vanishing(const uint64_t* poly, size_t len, size_t domain,
     for (size_t i = 0; i < len; i++) o[domain + i] = p[i];
     for (size_t i = 0; i < len; i++) o[i] -= p[i];
 }
+
+// ---- setup-time group operations ----
+// FixedBase::msm (fixed_base.rs:87-97): out[i] = v[i] * g, window table built with get_window_table(scalar_size, window, g)
+void oracle_g1_fixed_base_msm(const void* g_affine, size_t scalar_size, size_t window, const uint64_t* scalars, size_t n, void* out_proj) {
+    const Affine<Fq>& g = *(const Affine<Fq>*)g_affine;
+    G1P gp = G1P::zero();
+    if (!g.is_zero()) gp = {g.x, g.y, Fq::one()};
+    const auto table = fixed_window_table(scalar_size, window, gp);
+    const size_t outerc = (scalar_size + window - 1) / window;
+    G1P* O = (G1P*)out_proj;
+    const Fr* V = (const Fr*)scalars;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) O[i] = fixed_windowed_mul(outerc, window, table, V[i]);
+}
+void oracle_g1_group_ntt(void* inout_proj, uint32_t lg, int inverse) { group_ifft((G1P*)inout_proj, lg, inverse != 0); }
 
 // ---- G1 ----
 // kind: 0 = batched::msm, 1 = standard::msm, 2 = naive (sum of mul_bits)

@@ -21,6 +21,7 @@ SYMBOLS = [
     "snarkvm_hip_fr_mul_by_vanishing",
     "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum",
     "snarkvm_hip_register_bases_g2", "snarkvm_hip_free_bases_g2", "snarkvm_hip_msm_g2_registered",
+    "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize",
     "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_devtest_field",
@@ -64,6 +65,7 @@ def lib():
                    "snarkvm_hip_fr_vec_op", "snarkvm_hip_fr_divide_by_linear", "snarkvm_hip_fr_batch_inversion_and_mul", "snarkvm_hip_fr_distribute_powers", "snarkvm_hip_fr_lagrange_coefficients", "snarkvm_hip_fr_divide_by_vanishing", "snarkvm_hip_fr_mul_by_vanishing",
                    "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum",
                    "snarkvm_hip_register_bases_g2", "snarkvm_hip_msm_g2_registered",
+                   "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
                    "snarkvm_hip_devtest_field"]
         for name in err_fns:
             getattr(L, name).restype = RustError

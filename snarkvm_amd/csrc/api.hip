@@ -20,6 +20,7 @@
 #include "msm.cuh"
 #include "msm_sort.cuh"
 #include "ntt.cuh"
+#include "group.cuh"
 #include "poly.cuh"
 #include "serde.cuh"
 
@@ -1306,6 +1307,76 @@ RustError snarkvm_hip_fr_mul_by_vanishing(void* out, const void* poly, size_t le
         fr_finish_out(dout, out, olen, on_device);
         HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     }
+    API_END
+}
+
+// ---- setup-time group operations (group.cuh) -------------------------------------------------------
+RustError snarkvm_hip_g1_fixed_base_msm(void* out_projective, const void* g_affine, const void* scalars, size_t n) {
+    API_BEGIN
+    if (n) {
+        if (!out_projective || !g_affine || !scalars) throw hip_failure{hipErrorInvalidValue, "g1_fixed_base_msm: null argument", __LINE__};
+        hipStream_t st = g_ctx.stream;
+        // the base in the engine's native form, through the regular conversion kernel
+        g_ctx.bases_tmp.ensure(256 + sizeof(g1_aff_mem_t));
+        HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, g_affine, 104, hipMemcpyHostToDevice, st));
+        g1_aff_mem_t* d_g = (g1_aff_mem_t*)(g_ctx.bases_tmp.as<uint8_t>() + 256);
+        convert_bases<fq_t>(g_ctx, g_ctx.bases_tmp.as<uint8_t>(), 104, 1, d_g);
+        g1_aff_mem_t g_native;
+        HIP_TRY(hipMemcpyAsync(&g_native, d_g, sizeof g_native, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const size_t entries = (size_t)FIXED_OUTER << FIXED_WINDOW;
+        g_ctx.poly[0].ensure(entries * sizeof(g1_aff_mem_t));
+        g_ctx.poly[1].ensure(n * 32);
+        g_ctx.poly[2].ensure(n * 144);
+        hipLaunchKernelGGL(g1_fixed_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, g_native, g_ctx.poly[0].as<g1_aff_mem_t>());
+        HIP_TRY(hipMemcpyAsync(g_ctx.poly[1].p, scalars, n * 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(g1_fixed_msm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g_ctx.poly[0].as<g1_aff_mem_t>(),
+                           g_ctx.poly[1].as<fr_mem_t>(), n, g_ctx.poly[2].as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_projective, g_ctx.poly[2].p, n * 144, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    API_END
+}
+RustError snarkvm_hip_g1_group_ntt(void* inout_projective, uint32_t lg, int inverse) {
+    API_BEGIN
+    if (lg > 24) throw hip_failure{hipErrorInvalidValue, "g1_group_ntt: lg_domain_size > 24", __LINE__};
+    if (!inout_projective) throw hip_failure{hipErrorInvalidValue, "g1_group_ntt: null argument", __LINE__};
+    const size_t n = (size_t)1 << lg;
+    hipStream_t st = g_ctx.stream;
+    g_ctx.poly[0].ensure(n * 144);
+    g_ctx.poly[1].ensure(n * sizeof(g1_xyzz_mem_t));
+    g_ctx.poly[2].ensure((n / 2 + 1) * sizeof(fr_mem_t));
+    uint32_t* d_jac = g_ctx.poly[0].as<uint32_t>();
+    g1_xyzz_mem_t* d_pts = g_ctx.poly[1].as<g1_xyzz_mem_t>();
+    fr_mem_t* d_tw = g_ctx.poly[2].as<fr_mem_t>();
+    HIP_TRY(hipMemcpyAsync(d_jac, inout_projective, n * 144, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(g1_jac_to_xyzz_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_jac, d_pts, n);
+    if (lg > 0) {
+        // twiddles root^k (k < n/2) as canonical integers: ones -> distribute_powers -> to_bigint, all on the device
+        fr_t omega = fr_t::unpack(FR_TWO_ADIC_ROOT_MEM_HOST).from_mem_mont();
+        for (uint32_t i = lg; i < 47; i++) omega = omega.sqr();  // group_gen of the 2^lg domain (fft_field.rs:75-85)
+        if (inverse) omega = omega.inverse();
+        fr_mem_t one_mem, root_mem;
+        fr_t::one().to_mem_mont().store(&one_mem);
+        omega.to_mem_mont().store(&root_mem);
+        const size_t h = n / 2;
+        hipLaunchKernelGGL(fr_fill_kernel, dim3(fr_grid(h)), dim3(256), 0, st, d_tw, h, one_mem);
+        fr_distribute_powers_run(d_tw, h, root_mem, one_mem);
+        hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(fr_grid(h)), dim3(256), 0, st, d_tw, (const fr_mem_t*)d_tw, h, 1);
+        for (size_t half = n / 2; half >= 1; half >>= 1)
+            hipLaunchKernelGGL(g1_ntt_stage_kernel, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, st, d_pts, n, half, (const fr_mem_t*)d_tw, n / (2 * half));
+        hipLaunchKernelGGL(g1_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_pts, n, (int)lg);
+        if (inverse) {  // * size_inv (domain.rs:190)
+            fr_mem_t k_int;
+            fr_t::from_u32((uint32_t)n).inverse().mont_to_int().store(&k_int);
+            hipLaunchKernelGGL(g1_scale_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_pts, n, k_int);
+        }
+    }
+    hipLaunchKernelGGL(g1_xyzz_to_jac_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const g1_xyzz_mem_t*)d_pts, d_jac, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(inout_projective, d_jac, n * 144, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     API_END
 }
 

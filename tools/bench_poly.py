@@ -88,6 +88,36 @@ def main():
             t = time.perf_counter() - t0
             L.snarkvm_hip_free_bases(h_)
             rows.append(f"| SRS bytes -> registered bases ({'compressed' if comp else 'uncompressed'}) | {lg} | {t * 1e3:.3f} | {n / t:.3e} | | |")
+    # setup-time group operations (N4): host buffers in and out
+    from snarkvm_amd import group
+
+    gen = np.zeros(1, dtype=G1_AFFINE)
+    gen["x"] = [1171681672315280277, 6528257384425852712, 7514971432460253787, 2032708395764262463, 12876543207309632302, 107509843840671767]
+    gen["y"] = [13572190014569192121, 15344828677741220784, 17067903700058808083, 10342263224753415805, 1083990386877464092, 21335464879237822]
+    for lg in (16, 20):
+        n = 1 << lg
+        tab = group.FixedBase.get_window_table(253, group.FixedBase.get_mul_window_size(n), gen)
+        group.FixedBase.msm(253, 0, tab, host[:1024])
+        t0 = time.perf_counter()
+        group.FixedBase.msm(253, 0, tab, host[:n])
+        t = time.perf_counter() - t0
+        cn = 1 << 14
+        t0 = time.perf_counter()
+        oracle.g1_fixed_base_msm(gen, host[:cn])
+        ct = time.perf_counter() - t0
+        rows.append(f"| FixedBase::msm (host buffers) | {lg} | {t * 1e3:.3f} | {n / t:.3e} | | {cn / ct:.3e} (2^14 sample) |")
+    for lg in (12, 16):
+        n = 1 << lg
+        proj = group.FixedBase.msm(253, 0, tab, host[:n])
+        group.group_ntt(proj[:16], inverse=True)
+        t0 = time.perf_counter()
+        group.group_ntt(proj, inverse=True)
+        t = time.perf_counter() - t0
+        cn = 1 << 10
+        t0 = time.perf_counter()
+        oracle.g1_group_ntt(proj[:cn], inverse=True)
+        ct = time.perf_counter() - t0
+        rows.append(f"| group-element iFFT (lagrange_basis, host buffers) | {lg} | {t * 1e3:.3f} | {n / t:.3e} | | {cn / ct:.3e} (2^10 sample) |")
     print("| kernel | lg n | ms | elements/s | effective GB/s | CPU oracle elements/s (<= 2^20 sample) |")
     print("|---|---|---|---|---|---|")
     print("\n".join(rows))
