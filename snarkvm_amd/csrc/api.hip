@@ -396,14 +396,16 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
             static const int acc_minw = getenv("SNARKVM_HIP_ACC_MINW") ? atoi(getenv("SNARKVM_HIP_ACC_MINW")) : 1;
+            // timing experiment only (wrong results): restrict the gather to the first 2^k bases to separate ALU time from HBM gather time
+            static const uint32_t dbg_mask = getenv("SNARKVM_HIP_DEBUG_IDX_MASK") ? (uint32_t)strtoul(getenv("SNARKVM_HIP_DEBUG_IDX_MASK"), nullptr, 0) : 0xffffffffu;
             if (acc_minw >= 3 && sizeof(typename F::mem_t) == 48)
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 3>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
                                    d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
             else
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
                                    d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
         } else {
             for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
             hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);

@@ -399,7 +399,8 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
                                                                  const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
                                                                  const uint32_t* __restrict__ start, xyzz_mem_t<F>* __restrict__ partial,
-                                                                 uint32_t nbt, uint32_t S, uint32_t n, size_t table_stride) {
+                                                                 uint32_t nbt, uint32_t S, uint32_t n, size_t table_stride,
+                                                                 uint32_t debug_idx_mask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = boff[nbt];
     const uint64_t lo64 = (uint64_t)t * S;
@@ -421,7 +422,7 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
         const uint32_t e = sorted[pos];
         const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
         const uint32_t tbl = v / n;
-        const uint32_t idx = v - tbl * n;    // bases come in up to two segments
+        const uint32_t idx = (v - tbl * n) & debug_idx_mask;  // bases come in up to two segments (mask: timing experiments only)
         const aff_mem_t<F> raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
         acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
     }
