@@ -226,6 +226,9 @@ int snarkvm_hip_selftest_field(int field, int op, const void *a, const void *b, 
  * exercises every exceptional branch of ec.cuh on the host. */
 int snarkvm_hip_selftest_g1_msm_naive(const void *points_with_infinity, size_t npoints, size_t ffi_affine_sz,
                                       const void *scalars, void *out);
+/* The MSM planner (window width, windows, digit rows, buckets, segment length) evaluated on the host:
+ * out[10] = {c, W, J, digit rows, buckets per window, total buckets, S, S2, L, wide}.  Returns 0 if consistent. */
+int snarkvm_hip_selftest_msm_plan(size_t n, int window_bits, int tables, int table_bits, uint32_t *out);
 /* Same field operations executed by a GPU kernel (one thread per element). */
 RustError snarkvm_hip_devtest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize",
-    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_devtest_field",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_devtest_field",
 ]
 
 
@@ -75,6 +75,7 @@ def lib():
         L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double
         L.snarkvm_hip_selftest_field.restype = ctypes.c_int
         L.snarkvm_hip_selftest_g1_msm_naive.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_msm_plan.restype = ctypes.c_int
         L.snarkvm_hip_free_bases.restype = None
         L.snarkvm_hip_free_bases_g2.restype = None
         L.snarkvm_hip_set_profiling.restype = None

@@ -1445,6 +1445,22 @@ RustError snarkvm_hip_devtest_field(int field, int op, const void* a, const void
     (void)hipFree(dout.p);
     API_END
 }
+// The MSM planner on the host (no device needed): out = {c, W, J, Wd, nb, nbt, S, S2, L, wide}.  Returns 0.
+int snarkvm_hip_selftest_msm_plan(size_t n, int window_bits, int tables, int table_bits, uint32_t* out) {
+    const msm_plan_t p = msm_make_plan(n, window_bits, tables, table_bits);
+    const uint32_t v[10] = {(uint32_t)p.c, (uint32_t)p.W, (uint32_t)p.J, (uint32_t)p.Wd, p.nb, p.nbt, p.S, p.S2, p.L, p.c > 16 ? 1u : 0u};
+    for (int i = 0; i < 10; i++) out[i] = v[i];
+    // bias must place one 2^(c-1) per digit row below 320 bits
+    uint32_t chk[10] = {0};
+    for (int w = 0; w < p.Wd; w++) {
+        const int bit = p.c - 1 + p.c * w;
+        if (bit >= 320) return 1;
+        chk[bit / 32] |= 1u << (bit % 32);
+    }
+    for (int i = 0; i < 10; i++)
+        if (chk[i] != p.bias[i]) return 2;
+    return 0;
+}
 // naive sum_i scalar_i * P_i on the host with the device point arithmetic (scalars: 256-bit, 32 B each)
 int snarkvm_hip_selftest_g1_msm_naive(const void* points, size_t npoints, size_t stride, const void* scalars, void* out) {
     const uint8_t* P = (const uint8_t*)points;

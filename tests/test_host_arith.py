@@ -120,3 +120,34 @@ def test_ntt_lazy_bound():
     """Lazy butterflies keep values below 2^s * r entering local stage s; 8 stages need 256 r < 2^261 (9 x 29 bits)."""
     assert 256 * pyref.R_MOD < 1 << 261
     assert (pyref.R_MOD << 8) >> (29 * 8) < 1 << 29  # top limb of 2^8 r stays a 29-bit limb
+
+
+def _plan(n, window_bits=0, tables=1, table_bits=0):
+    out = (ctypes.c_uint32 * 10)()
+    rc = _lib.lib().snarkvm_hip_selftest_msm_plan(ctypes.c_size_t(n), ctypes.c_int(window_bits), ctypes.c_int(tables), ctypes.c_int(table_bits), out)
+    assert rc == 0
+    keys = ("c", "W", "J", "Wd", "nb", "nbt", "S", "S2", "L", "wide")
+    return dict(zip(keys, list(out)))
+
+
+def test_msm_planner_invariants():
+    """Host-side MSM planner (msm.cuh msm_make_plan): every plan covers the 254 signed-digit bits of a scalar, wide windows
+    exist only as one window per table, and the bench configurations come out as documented."""
+    for n in (1, 31, 1000, 4096, 1 << 16, 1 << 20, 1 << 24):
+        p = _plan(n)  # unregistered bases
+        assert 2 <= p["c"] <= 16 and p["J"] == 1 and p["W"] * p["c"] >= 254 and p["nb"] == 1 << (p["c"] - 1)
+        for tables in (2, 4, 8, 16):
+            p = _plan(n, tables=tables)
+            assert p["J"] == tables and p["W"] * p["c"] == 256 // tables and p["Wd"] == p["W"] * tables and p["c"] <= 16
+    for tables, bits in ((15, 17), (15, 18), (13, 20), (12, 22), (12, 23)):
+        big = _plan(1 << 24, tables=tables, table_bits=bits)
+        assert big["c"] == bits and big["W"] == 1 and big["wide"] == 1 and big["Wd"] == tables and big["nb"] == 1 << (bits - 1)
+        small = _plan(1000, tables=tables, table_bits=bits)   # few points: a divisor of the table width instead of a wide window
+        assert bits % small["c"] == 0 and small["W"] * small["c"] == bits
+        if bits not in (17, 23):  # prime widths have no other divisor >= 2
+            assert small["c"] <= 16 and small["wide"] == 0
+        forced = _plan(1000, window_bits=bits, tables=tables, table_bits=bits)
+        assert forced["c"] == bits and forced["wide"] == 1
+    assert _plan(1 << 24, tables=12, table_bits=22)["S"] == 128 and _plan(1 << 14, tables=16)["S"] == 16
+    d = _plan(1 << 20, window_bits=13, tables=16)  # request that does not divide the table width: largest divisor below
+    assert d["c"] == 8 and d["W"] == 2
