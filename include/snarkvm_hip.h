@@ -59,6 +59,10 @@ RustError snarkvm_polymul(void *out, size_t pcount, const void *polynomials, con
  * stride `ffi_affine_sz` = 104 bytes), `scalars` are npoints canonical 256-bit integers < r. */
 RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoints, const void *scalars,
                       size_t ffi_affine_sz);
+/* Optional, off by default: with the environment variable SNARKVM_HIP_BASE_CACHE=<tables> (1, 2, 4, 8 or 16) snarkvm_msm keeps
+ * the converted bases (+ precomputed tables) of up to four host ranges in HBM and reuses them when a later call passes a
+ * slice of the same range - the reference's callers always pass slices of one long-lived `powers_of_beta_g` vector
+ * (kzg10/mod.rs:117-119).  A hit is verified against raw copies of every 4096th point; results are unchanged. */
 
 /* ---------------------------------------------------------------------------------------------
  * Part 2 - extension ABI (device-resident data, SRS registration, instrumentation)

@@ -740,9 +740,89 @@ RustError snarkvm_polymul(void* out, size_t pcount, const void* polynomials, con
 }
 
 // ---- MSM ---------------------------------------------------------------------------------------
+// ---- optional base cache behind the unmodified FFI -------------------------------------------------
+// The reference's callers pass slices of ONE long-lived vector (`powers_of_beta_g[lz .. lz + len]`, kzg10/mod.rs:117-119)
+// and its GPU path re-uploads them on every call.  With SNARKVM_HIP_BASE_CACHE=<tables> (1, 2, 4, 8 or 16; unset = off) a
+// call whose base range lies inside a range seen before reuses the device copy (with `tables` precomputed multiples):
+// no upload, no conversion, no Horner chain.  A hit is verified against raw copies of every CACHE_STEP-th point of the
+// slice; a mismatch drops the entry.  Host pointers are only compared, never dereferenced outside the call that passed
+// them.  At most CACHE_MAX ranges are kept (least recently used goes first).
+static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables,
+                                int table_bits);
+struct base_cache_entry {
+    const uint8_t* host = nullptr;
+    size_t n = 0, stride = 0;
+    snarkvm_hip_bases* h = nullptr;
+    std::vector<uint8_t> samples;  // 97 bytes (x, y, infinity) of points 0, CACHE_STEP, 2 * CACHE_STEP, ...
+    uint64_t last_use = 0;
+};
+static constexpr size_t CACHE_STEP = 4096, CACHE_MAX = 4;
+static std::vector<base_cache_entry> g_base_cache;
+static uint64_t g_cache_tick = 0;
+static int base_cache_tables() {
+    static const int t = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 0;
+    return (t == 1 || t == 2 || t == 4 || t == 8 || t == 16) ? t : 0;
+}
+static void base_cache_drop(size_t i) {
+    if (g_base_cache[i].h) {
+        if (g_base_cache[i].h->d) (void)hipFree(g_base_cache[i].h->d);
+        delete g_base_cache[i].h;
+    }
+    g_base_cache.erase(g_base_cache.begin() + (long)i);
+}
+// registered handle + offset covering [points, points + npoints * stride), registering the range on a miss
+static const snarkvm_hip_bases* base_cache_lookup(const void* points, size_t npoints, size_t stride, size_t& offset) {
+    const uint8_t* p = (const uint8_t*)points;
+    for (size_t i = 0; i < g_base_cache.size(); i++) {
+        base_cache_entry& e = g_base_cache[i];
+        if (e.stride != stride || p < e.host || p + npoints * stride > e.host + e.n * stride || (size_t)(p - e.host) % stride) continue;
+        const size_t off = (size_t)(p - e.host) / stride;
+        bool same = true;
+        for (size_t k = (off + CACHE_STEP - 1) / CACHE_STEP; k * CACHE_STEP < off + npoints && same; k++)
+            same = memcmp(&e.samples[k * 97], e.host + k * CACHE_STEP * stride, 97) == 0;
+        if (!same) {  // the memory behind a cached range changed: forget it
+            base_cache_drop(i);
+            break;
+        }
+        e.last_use = ++g_cache_tick;
+        offset = off;
+        return e.h;
+    }
+    while (g_base_cache.size() >= CACHE_MAX) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_base_cache.size(); i++)
+            if (g_base_cache[i].last_use < g_base_cache[lru].last_use) lru = i;
+        base_cache_drop(lru);
+    }
+    // a slice of a bigger vector may come first: ranges that the new one contains are superseded
+    for (size_t i = g_base_cache.size(); i-- > 0;)
+        if (g_base_cache[i].stride == stride && g_base_cache[i].host >= p && g_base_cache[i].host + g_base_cache[i].n * stride <= p + npoints * stride)
+            base_cache_drop(i);
+    base_cache_entry e;
+    e.host = p;
+    e.n = npoints;
+    e.stride = stride;
+    register_bases_impl(&e.h, points, npoints, stride, 0, base_cache_tables(), 0);
+    for (size_t k = 0; k * CACHE_STEP < npoints; k++) e.samples.insert(e.samples.end(), p + k * CACHE_STEP * stride, p + k * CACHE_STEP * stride + 97);
+    e.last_use = ++g_cache_tick;
+    g_base_cache.push_back(e);
+    offset = 0;
+    return g_base_cache.back().h;
+}
+
 RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
     API_BEGIN
-    msm_host<fq_t>(g_ctx, out, points, npoints, scalars, ffi_affine_sz);
+    if (base_cache_tables() && npoints > 1024 && ffi_affine_sz >= 104 && !(ffi_affine_sz & 7)) {
+        size_t offset = 0;
+        const snarkvm_hip_bases* h = base_cache_lookup(points, npoints, ffi_affine_sz, offset);
+        g_ctx.scalars_tmp.ensure(npoints * 32);
+        g_ctx.phase_begin("msm_h2d");
+        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, g_ctx.stream));
+        g_ctx.phase_end();
+        msm_run<fq_t>(g_ctx, h->d + offset, g_ctx.scalars_tmp.as<uint4>(), npoints, out, 0, nullptr, ~(size_t)0, 0, h->tables, h->n, 0, true, h->table_bits);
+    } else {
+        msm_host<fq_t>(g_ctx, out, points, npoints, scalars, ffi_affine_sz);
+    }
     API_END
 }
 RustError snarkvm_hip_msm_g2(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
@@ -839,7 +919,7 @@ static void check_tables(int tables, int table_bits, const char* who) {
         throw std::runtime_error(std::string(who) + ": tables must be 1, 2, 4, 8 or 16, or tables * window_bits >= 254 with window_bits in 2..23");
 }
 static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables,
-                                int table_bits = 0) {
+                                int table_bits) {
     if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
     if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
     check_tables(tables, table_bits, "register_bases");
@@ -942,13 +1022,13 @@ RustError snarkvm_hip_g1_serialize(void* out_bytes, const void* affine, size_t n
 }
 RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
     API_BEGIN
-    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, 1);
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, 1, 0);
     API_END
 }
 RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
                                             int tables) {
     API_BEGIN
-    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables);
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables, 0);
     API_END
 }
 RustError snarkvm_hip_register_bases_windowed(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,

@@ -2,6 +2,7 @@
 compared limb for limb (unique Montgomery representation), MSM outputs after affine normalisation (x, y, infinity),
 exactly like the reference's own GPU-vs-CPU tests (fft/domain.rs:1140-1218, msm/variable_base/mod.rs:109-119)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -540,3 +541,38 @@ def test_g2_registered_tables_vs_oracle(golden, tables, window_bits):
     want2 = o.g2_to_affine(o.g2_msm(bases[100:433], sc[:333]))
     assert o.g2_to_affine(rb.msm(sc[:333], offset=100)).tobytes() == want2.tobytes()
     rb.close()
+
+
+def test_ffi_base_cache_is_transparent(tmp_path):
+    """SNARKVM_HIP_BASE_CACHE: the unmodified `snarkvm_msm` FFI reusing device copies of base ranges it has seen - same
+    results for repeated calls, sub-slices with an offset, a superseding bigger range, and memory that changed in place."""
+    import subprocess
+    import sys
+
+    script = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from oracle import cpu as oracle
+from snarkvm_amd import plugin, synthetic
+from tests import util
+n = 20000
+bases = oracle.g1_gen_bases(util.g1_generator_affine(), 3, n)
+sc = synthetic.random_fr_integers(n, 2468)
+def check(b, s):
+    got = oracle.g1_to_affine(plugin.msm(b, s))
+    assert util.affine_equal(got, oracle.g1_to_affine(oracle.g1_msm(b, s))), "mismatch"
+check(bases[:9000], sc[:9000])          # miss: registers [0, 9000)
+check(bases[:9000], sc[:9000])          # hit
+check(bases[100:5100], sc[:5000])       # hit with an offset
+check(bases, sc)                        # bigger range supersedes the first one
+check(bases[4096:12000], sc[:7904])     # hit inside the big range, starting exactly on a sampled point
+bases[8192] = bases[1]                  # the memory changes in place at a sampled position
+check(bases, sc)                        # detected -> re-registered
+bases[8191] = bases[2]                  # an unsampled position: documented limitation, so re-register through a fresh array
+fresh = bases.copy()
+check(fresh, sc)
+print("CACHE_OK")
+''' % util.ROOT
+    env = dict(os.environ, SNARKVM_HIP_BASE_CACHE="4")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+    assert "CACHE_OK" in r.stdout, r.stdout + r.stderr
