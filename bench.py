@@ -92,9 +92,10 @@ def main():
         for _ in range(args.warmup):
             rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
     elif args.warmup:
-        # the pipelined path runs on LANES = 3 HIP streams with one workspace each: W warm-up steps per stream, so that no
-        # workspace is allocated (hipMalloc / hipFree synchronise the device) inside the timed region
-        rb.msm_batch(device_ptrs=[d_scalars.data_ptr()] * (3 * args.warmup), npoints=[n] * (3 * args.warmup), window_bits=args.window_bits)
+        # the pipelined path cycles through several HIP streams with one workspace each: W warm-up steps per stream, so that
+        # no workspace is allocated (hipMalloc / hipFree synchronise the device) inside the timed region
+        lanes = L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n))
+        rb.msm_batch(device_ptrs=[d_scalars.data_ptr()] * (lanes * args.warmup), npoints=[n] * (lanes * args.warmup), window_bits=args.window_bits)
     barrier()
     t0 = time.perf_counter()
     if args.no_pipeline:

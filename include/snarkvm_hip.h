@@ -70,6 +70,10 @@ RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoint
 
 /* Number of visible HIP devices (0 if none).  Never fails. */
 int snarkvm_hip_device_count(void);
+/* Number of HIP streams (each with its own workspace) snarkvm_hip_msm_registered_batch cycles through for instances of
+ * up to `npoints` pairs: 8 below 2^20, 3 above (SNARKVM_HIP_LANES overrides).  A caller that wants allocation-free timed
+ * regions warms up that many instances first. */
+int snarkvm_hip_batch_lanes(size_t npoints);
 /* Select the HIP device used by this process' context (default: device 0 / LOCAL_RANK mapping is the
  * caller's business).  Must be called before the first compute call. */
 RustError snarkvm_hip_set_device(int device);

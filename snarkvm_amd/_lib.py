@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SNARKVM_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 # every symbol include/snarkvm_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm",
-    "snarkvm_hip_device_count", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
+    "snarkvm_hip_device_count", "snarkvm_hip_batch_lanes", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
     "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_free_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2",
     "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_g1_to_affine",
     "snarkvm_hip_fr_mul_device", "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device",
@@ -70,6 +70,7 @@ def lib():
         for name in err_fns:
             getattr(L, name).restype = RustError
         L.snarkvm_hip_device_count.restype = ctypes.c_int
+        L.snarkvm_hip_batch_lanes.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_count.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_name.restype = ctypes.c_char_p
         L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double

@@ -99,8 +99,15 @@ struct context_t {
     dev_buf poly[5];  // staging / scratch of the prover-round vector kernels (poly.cuh)
     // MSM workspaces: lane 0 runs on the main stream; lanes 1.. are used by the batch API so that the latency-bound
     // tail of one MSM (bucket reduction, Horner) overlaps the throughput-bound accumulation of the next
-    static constexpr int LANES = 3;
+    static constexpr int LANES = 8;  // streams + workspaces available to the batch API
     msm_ws_t lane[LANES];
+    // lanes a batch actually cycles through: more lanes hide more of the latency-bound tail of small MSMs, fewer keep the
+    // workspace footprint of big ones down (a 2^24 lane holds ~4 GB)
+    static int batch_lanes(size_t npoints) {
+        static const int env = getenv("SNARKVM_HIP_LANES") ? atoi(getenv("SNARKVM_HIP_LANES")) : 0;
+        int l = env > 0 ? env : (npoints >= ((size_t)1 << 20) ? 3 : LANES);  // measured: 8 lanes +7 % below 2^20, no gain above
+        return l < 1 ? 1 : (l > LANES ? LANES : l);
+    }
     dev_buf bases_tmp, scalars_tmp, gen_pts, gen_prod;
     void* batch_pinned = nullptr;
     size_t batch_pinned_cap = 0;
@@ -381,10 +388,10 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
                            c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
                            (uint8_t*)nullptr, nseg, LBL, 0);
         phase_end();
-        uint32_t max_bucket = 0;
+        static const int seg_mode = getenv("SNARKVM_HIP_SEG") ? atoi(getenv("SNARKVM_HIP_SEG")) : 1;  // 1 = balanced segments (default)
+        uint32_t max_bucket = 0;  // the number of reduce rounds follows the largest bucket (4-byte read-back)
         HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        static const int seg_mode = getenv("SNARKVM_HIP_SEG") ? atoi(getenv("SNARKVM_HIP_SEG")) : 1;  // 1 = balanced segments (default)
         // ---- 5. accumulate
         phase_begin("msm_accumulate");
         if (seg_mode) {
@@ -629,6 +636,7 @@ int snarkvm_hip_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+int snarkvm_hip_batch_lanes(size_t npoints) { return context_t::batch_lanes(npoints); }
 RustError snarkvm_hip_set_device(int device) {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     if (g_ctx.ready && g_ctx.device != device) return fail(1, "snarkvm_hip_set_device: context already initialised on another device");
@@ -1091,9 +1099,12 @@ RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t
         g_ctx.batch_pinned_cap = count * 144 + 144;
     }
     uint8_t* stage = (uint8_t*)g_ctx.batch_pinned;
+    size_t largest = 0;
+    for (size_t k = 0; k < count; k++) largest = npoints[k] > largest ? npoints[k] : largest;
+    const int nlanes = context_t::batch_lanes(largest);
     for (size_t k = 0; k < count; k++) {
         if (offsets[k] + npoints[k] > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
-        const int lane = (int)(k % context_t::LANES);
+        const int lane = (int)(k % (size_t)nlanes);
         msm_ws_t& ws = g_ctx.lane[lane];
         const uint4* d_sc = (const uint4*)scalars[k];
         if (!scalars_on_device && npoints[k]) {

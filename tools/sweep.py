@@ -41,8 +41,9 @@ def main():
         for _ in range(reps):
             rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
         sync_ms = (time.perf_counter() - t0) / reps * 1e3
-        rb.msm_batch(device_ptrs=[d_sc.data_ptr()] * 3, npoints=[n] * 3)
-        k = 8
+        lanes = L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n))
+        rb.msm_batch(device_ptrs=[d_sc.data_ptr()] * lanes, npoints=[n] * lanes)
+        k = 12
         t0 = time.perf_counter()
         rb.msm_batch(device_ptrs=[d_sc.data_ptr()] * k, npoints=[n] * k)
         pipe_ms = (time.perf_counter() - t0) / k * 1e3
