@@ -199,6 +199,24 @@ def main():
     except Exception:
         pmc = {}
 
+    valu = {}
+    try:
+        if pmc:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")) as f:
+                valu = json.load(f)["kernels"]
+    except Exception:
+        valu = {}
+
+    def valu_issue(kernel, ms, launches=1):
+        """VALU issue utilisation: PMC wave-instruction count (committed, same configuration) x the 4-cycle wave64 issue
+        floor of a 16-lane SIMD / (1024 SIMDs x 2.4 GHz x measured kernel time)."""
+        k = valu.get(kernel)
+        if not k or not ms:
+            return None
+        cycles = ms * 1e-3 * 2.4e9 * 1024
+        cpi = cycles / (k["SQ_INSTS_VALU"] * launches)
+        return {"wave_insts_per_launch": k["SQ_INSTS_VALU"], "cycles_per_inst": cpi, "issue_floor_cycles": 4.0, "frac": 4.0 / cpi}
+
     def traffic(kernel, fetch_key, times=1):
         k = pmc.get(kernel)
         return None if not k else (k[fetch_key] + k["write_bytes"]) * times
@@ -241,7 +259,8 @@ def main():
                 "frac": ((n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
                 "traffic": traffic("msm_accumulate_seg_kernel<Fp<FqP> >", "fetch_bytes_raw"),
                 "algorithmic_bytes": n * 100.0 * W,
-                "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d); see roofline_scalar_read for the HBM-bound phase",
+                "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see valu_issue; roofline_scalar_read is the HBM-bound phase",
+                "valu_issue": valu_issue("msm_accumulate_seg_kernel<Fp<FqP>, 1>", acc_ms),
             },
             # the phase north_star scopes the HBM claim to: scalar read + digit extraction, 32 B per scalar
             "roofline_scalar_read": {
@@ -263,6 +282,7 @@ def main():
                 "unit": "GB/s",
                 "frac": ((64.0 * nn) / (ntt_kernel_ms * 1e-3) / 1e9 / 8000.0) if ntt_kernel_ms else None,
                 "traffic": traffic("ntt_pass_kernel_v2", "fetch_bytes_x2", times=3),
+                "valu_issue": valu_issue("ntt_pass_kernel_v2", ntt_kernel_ms, launches=3),
                 "algorithmic_bytes": 64.0 * nn,
             },
             "cpu_baseline": cpu,
