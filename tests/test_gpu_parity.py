@@ -576,3 +576,35 @@ print("CACHE_OK")
     env = dict(os.environ, SNARKVM_HIP_BASE_CACHE="4")
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
     assert "CACHE_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_msm_randomized_configurations(golden):
+    """Differential sweep over deterministic pseudo-random configurations: size, base-table geometry, forced window width
+    and scalar distribution (uniform / tiny / sparse / all-equal / near r), registered and plain FFI, against `batched::msm`."""
+    rng = np.random.default_rng(20240924)
+    pool = _srs(golden, 30000)
+    geometries = [(1, 0), (4, 0), (16, 0), (15, 17), (13, 20), (12, 22)]
+    for case in range(24):
+        n = int(rng.choice([1, 2, 17, 255, 1000, 4097, 12345, 30000]))
+        off = int(rng.integers(0, 30000 - n + 1))
+        tables, bits = geometries[int(rng.integers(0, len(geometries)))]
+        kind = int(rng.integers(0, 5))
+        sc = synthetic.random_fr_integers(n, 5000 + case)
+        if kind == 1:
+            sc[:, 1:] = 0
+            sc[:, 0] &= np.uint64(0xFFFF)
+        elif kind == 2:
+            sc[rng.random(n) < 0.7] = 0
+        elif kind == 3:
+            sc[:] = sc[0]
+        elif kind == 4:
+            sc[:] = util.limbs(pyref.R_MOD - 1 - case, 4)
+        bases = pool[off : off + n]
+        want = oracle.g1_to_affine(oracle.g1_msm(bases, sc))
+        rb = RegisteredBases(pool, tables=tables, window_bits=bits)
+        forced = bits if (bits and case % 2 == 0) else 0
+        got = rb.msm(sc, offset=off, window_bits=forced)
+        assert util.affine_equal(oracle.g1_to_affine(got), want), (case, n, off, tables, bits, kind, forced)
+        rb.close()
+        if case % 4 == 0:
+            assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(bases, sc)), want), ("ffi", case, n, kind)
