@@ -257,7 +257,7 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
-                "traffic": traffic("msm_accumulate_seg_kernel<Fp<FqP> >", "fetch_bytes_raw"),
+                "traffic": traffic("msm_accumulate_seg_kernel<Fp<FqP>, 1>", "fetch_bytes_raw"),
                 "algorithmic_bytes": n * 100.0 * W,
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see valu_issue; roofline_scalar_read is the HBM-bound phase",
                 "valu_issue": valu_issue("msm_accumulate_seg_kernel<Fp<FqP>, 1>", acc_ms),

@@ -96,6 +96,7 @@ struct ntt_pass_t {
     int coset_pre;   // multiply input j by g^j        (forward coset, first pass)
     int scale_post;  // last pass: 0 none, 1 * n^-1, 2 * g^-k n^-1   (inverse / coset inverse)
     int tw_shift;    // non-last: twiddle exponent = (inner * k) << tw_shift
+    const fr_mem_t* tw_full;  // non-last, optional: the closing twiddles of this pass, tw_full[(k << s) + inner] (one product instead of two)
 };
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -403,10 +404,14 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tabl
                 fr_t y;
                 if (!p.last) {
                     g = in_base + ((size_t)k << p.s) + col;
-                    const uint32_t expo = (uint32_t)(((inner0 + col) * (size_t)k) << p.tw_shift);
-                    y = x[m].mul_lazy(fr_t::load(&tb.pow_lo[p.dir][expo & (NTT_TW_SIZE - 1)]));
-                    const uint32_t h = expo >> NTT_TW_BITS;
-                    if (h) y = y.mul_lazy(fr_t::load(&tb.pow_hi[p.dir][h]));
+                    if (p.tw_full) {
+                        y = x[m].mul_lazy(fr_t::load(&p.tw_full[((size_t)k << p.s) + inner0 + col]));
+                    } else {
+                        const uint32_t expo = (uint32_t)(((inner0 + col) * (size_t)k) << p.tw_shift);
+                        y = x[m].mul_lazy(fr_t::load(&tb.pow_lo[p.dir][expo & (NTT_TW_SIZE - 1)]));
+                        const uint32_t h = expo >> NTT_TW_BITS;
+                        if (h) y = y.mul_lazy(fr_t::load(&tb.pow_hi[p.dir][h]));
+                    }
                 } else {
                     g = (d1_0 + col) + (((size_t)mid + ((size_t)k << p.lg_mid)) << p.a1);
                     if (p.scale_post == 0) {
@@ -498,6 +503,41 @@ static inline ntt_plan_t ntt_make_plan(int lg) {
     return pl;
 }
 
+// ---- full closing-twiddle tables ----------------------------------------------------------------------------------
+// The closing multiplication of a non-last pass needs W^((inner * k) << tw_shift); composing it from the two 4096-entry
+// tables costs a second Fr product per element, and the NTT sits on the VALU issue floor: skipping that
+// product is worth 9 % of a 2^24 transform.  So the composed twiddles of every pass shape (a, s, direction) are
+// materialised once in HBM, in exactly the order the pass stores its outputs (coalesced 32-byte reads next to the
+// 32-byte stores): 2^(a+s) entries - 512 MiB for the first pass of a 2^24 transform, 2 MiB for its second pass; ~2 GiB if
+// every size from 2^17 to 2^24 is used in both directions.  SNARKVM_HIP_NTT_FULL_TW=0 falls back to the composition.
+struct ntt_full_tw_t {
+    fr_mem_t* ptr[2][NTT_MAX_RADIX_LG + 1][NTT_LG_MAX + 1] = {};
+};
+static ntt_full_tw_t g_ntt_full_tw;  // guarded by the API mutex (api.hip)
+__global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a, int s, int tw_shift, const fr_mem_t* __restrict__ lo,
+                                        const fr_mem_t* __restrict__ hi) {
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)1 << (a + s))) return;
+    const uint32_t k = (uint32_t)(idx >> s), inner = (uint32_t)(idx & (((size_t)1 << s) - 1));
+    tw_lookup(lo, hi, (inner * k) << tw_shift).store(&out[idx]);
+}
+static inline const fr_mem_t* ntt_get_full_tw(hipStream_t st, const ntt_tables_t& tb, int a, int s, int tw_shift, int dir) {
+    static const int enabled = getenv("SNARKVM_HIP_NTT_FULL_TW") ? atoi(getenv("SNARKVM_HIP_NTT_FULL_TW")) : 1;
+    if (!enabled || a + s > NTT_LG_MAX || a > NTT_MAX_RADIX_LG) return nullptr;
+    fr_mem_t*& slot = g_ntt_full_tw.ptr[dir][a][a + s];
+    if (!slot) {
+        const size_t n = (size_t)1 << (a + s);
+        if (hipMalloc((void**)&slot, n * sizeof(fr_mem_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            slot = nullptr;
+            return nullptr;  // out of memory: compose on the fly
+        }
+        hipLaunchKernelGGL(ntt_fill_full_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slot, a, s, tw_shift, tb.pow_lo[dir], tb.pow_hi[dir]);
+        (void)hipStreamSynchronize(st);  // other streams may use the table from now on
+    }
+    return slot;
+}
+
 static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb) {
     const size_t E = (size_t)1 << (p.a + p.lgT);
     const size_t ntiles = ((size_t)1 << p.lg_n) / E;
@@ -538,10 +578,12 @@ static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* 
         p.last = (k == pl.npass - 1);
         p.scale_post = p.last ? scale_post : 0;
         p.a1 = p.lg_mid = p.s = p.tw_shift = 0;
+        p.tw_full = nullptr;
         if (!p.last) {
             p.s = lg - consumed - p.a;
             p.lgT = p.s < 3 ? p.s : 3;
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
+            p.tw_full = ntt_get_full_tw(st, tb, p.a, p.s, p.tw_shift, dir);
         } else {
             p.a1 = (pl.npass >= 2) ? pl.a[0] : 0;
             p.lg_mid = (pl.npass == 3) ? pl.a[1] : 0;
