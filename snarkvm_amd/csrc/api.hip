@@ -519,8 +519,13 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         c.fold_idx.ensure((size_t)slots * 8);
         uint32_t* fstart = c.fold_idx.as<uint32_t>();
         uint32_t* fcnt = fstart + slots;
-        hipLaunchKernelGGL((msm_fold_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, pin,
-                           start_in, cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
+        static const int fold_wg = getenv("SNARKVM_HIP_FOLD_WG") ? atoi(getenv("SNARKVM_HIP_FOLD_WG")) : 64;  // 64: one wave per output
+        if (fold_wg == 64)
+            hipLaunchKernelGGL((msm_fold_wave_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(64), 0, st, pin, start_in, cnt_in,
+                               c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
+        else
+            hipLaunchKernelGGL((msm_fold_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st,
+                               pin, start_in, cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
         tail_sums = c.fold_sums.as<xyzz_mem_t<F>>();
         tail_start = fstart;
         tail_cnt = fcnt;

@@ -647,6 +647,58 @@ __global__ void __launch_bounds__(256) msm_fold_kernel(const xyzz_mem_t<F>* __re
             }
     }
 }
+// The same fold with ONE wave per output and a shuffle butterfly instead of the LDS tree: a 256-thread workgroup spends as
+// long in its 8 tree levels (half the lanes idle, a barrier each) as in its 8 serial additions; a single wave does 16-32
+// serial additions per lane and 6 all-lane exchange levels, needs no LDS, and ~3 of them fit a SIMD (1.79 -> ~0.8 ms at 2^21
+// buckets).
+__device__ __forceinline__ fq_t shfl_xor_field(const fq_t& a, int mask) {
+    fq_t r;
+#pragma unroll
+    for (int i = 0; i < fq_t::N; i++) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], mask);
+    return r;
+}
+__device__ __forceinline__ fq2_t shfl_xor_field(const fq2_t& a, int mask) { return {shfl_xor_field(a.c0, mask), shfl_xor_field(a.c1, mask)}; }
+template <class F>
+__global__ void __launch_bounds__(64) msm_fold_wave_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
+                                                           const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out_sums,
+                                                           uint32_t* __restrict__ out_start, uint32_t* __restrict__ out_cnt, int m, int hb) {
+    const uint32_t nlo = 1u << m, nhi = 1u << hb;
+    const bool column = blockIdx.x < nlo;
+    const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
+    const uint32_t slot = column ? fixed : nlo + fixed - 1;  // H_0 has weight 0 and no slot
+    if (!column && fixed == 0) {
+        if (threadIdx.x == 0) {
+            out_start[2 * nlo - 1] = 2 * nlo - 1;
+            out_cnt[2 * nlo - 1] = 0;
+        }
+        return;
+    }
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    const uint32_t cntv = column ? nhi : nlo;
+    for (uint32_t i = threadIdx.x; i < cntv; i += 64) {
+        const uint32_t k = column ? (i << m) + fixed : (fixed << m) + i;
+        for (uint32_t q = 0; q < cnt[k]; q++) acc.add(load_xyzz<F>(&sums[start[k] + q]));
+    }
+#pragma unroll 1
+    for (int off = 32; off > 0; off >>= 1) {
+        xyzz_t<F> o;
+        o.x = shfl_xor_field(acc.x, off);
+        o.y = shfl_xor_field(acc.y, off);
+        o.zz = shfl_xor_field(acc.zz, off);
+        o.zzz = shfl_xor_field(acc.zzz, off);
+        acc.add(o);  // every lane ends with the full sum
+    }
+    if (threadIdx.x == 0) {
+        store_xyzz<F>(&out_sums[slot], acc);
+        out_start[slot] = slot;
+        out_cnt[slot] = 1;
+        if (!column && nhi < nlo + 1 && fixed == nhi - 1)  // slots of window 1 beyond the last H stay empty
+            for (uint32_t s2 = nlo + nhi - 1; s2 < 2 * nlo - 1; s2++) {
+                out_start[s2] = s2;
+                out_cnt[s2] = 0;
+            }
+    }
+}
 // 9. Horner across windows (batched.rs:404-413) and conversion to the reference's Jacobian memory image
 template <class F>
 __global__ void __launch_bounds__(64) msm_final_kernel(const xyzz_mem_t<F>* __restrict__ wsum, jac_mem_t<F>* out, int W, int c) {
