@@ -608,3 +608,36 @@ def test_msm_randomized_configurations(golden):
         rb.close()
         if case % 4 == 0:
             assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(bases, sc)), want), ("ffi", case, n, kind)
+
+
+def test_extension_abi_rejects_bad_arguments(golden):
+    """Every extension entry point answers a malformed request with a non-zero RustError (never a crash, never a silent
+    result): the caller's fallback logic depends on it (variable_base/mod.rs:39-43)."""
+    L = _lib.lib()
+    bases = _srs(golden, 64)
+    h = ctypes.c_void_p()
+
+    def err(e):
+        with pytest.raises(_lib.HipError):
+            _lib.check(e)
+
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    err(L.snarkvm_hip_register_bases_windowed(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 11, 22))   # 11 * 22 < 254
+    err(L.snarkvm_hip_register_bases_windowed(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 12, 24))   # window > 23
+    err(L.snarkvm_hip_register_bases_tables(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 3))         # not a power of two
+    err(L.snarkvm_hip_register_bases_tables(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(100), 0, 4))         # stride < 104
+    rb = RegisteredBases(bases, tables=4)
+    sc = synthetic.random_fr_integers(64, 1)
+    out = np.zeros(1, dtype=G1_PROJECTIVE)
+    err(L.snarkvm_hip_msm_registered(P(out), rb._h, ctypes.c_size_t(1), ctypes.c_size_t(64), P(sc), 0, 0))     # range past the end
+    err(L.snarkvm_hip_msm_registered(P(out), rb._h, ctypes.c_size_t(0), ctypes.c_size_t(64), P(sc), 0, 24))    # window_bits > 23
+    rb.close()
+    x = np.zeros((8, 4), dtype=np.uint64)
+    err(L.snarkvm_hip_fr_vec_op(99, P(x), P(x), P(x), None, None, ctypes.c_size_t(8), 0))                      # unknown op
+    err(L.snarkvm_hip_fr_vec_op(4, P(x), P(x), None, None, None, ctypes.c_size_t(8), 0))                       # scale without a scalar
+    err(L.snarkvm_hip_fr_divide_by_vanishing(P(x), P(x), P(x), ctypes.c_size_t(8), ctypes.c_size_t(0), 0))    # empty domain
+    err(L.snarkvm_hip_fr_lagrange_coefficients(P(x), ctypes.c_uint32(31), P(x), 0))                            # lg > 30
+    err(L.snarkvm_hip_g1_group_ntt(P(out), ctypes.c_uint32(25), 0))                                            # lg > 24
+    err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(25), 0, 0, 0))                       # lg > 24: caller falls back
+    err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(4), 7, 0, 0))                        # bad enum
+    err(L.snarkvm_hip_g1_serialize(P(x), P(bases), ctypes.c_size_t(1), ctypes.c_size_t(96), 0))                # stride < 104
