@@ -391,6 +391,31 @@ struct Fp {
         }
         return r;
     }
+    // Montgomery reduction alone: x * 2^(-29N) for any x < 2^(29N) with normalised limbs, result < 2p.  Half the
+    // multiply-adds of mul_lazy(one()) (the a*b columns are just the limbs of x); the caller has folded the missing factor
+    // 2^(29N) into an earlier constant (ntt.cuh: closing twiddles of the pass before the last).
+    SV_HD Fp mont_reduce_lazy() const {
+        uint32_t m[N];
+        Fp r;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) {
+            if (k < N) acc += v[k];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 1 && j < N && i < k) acc += (uint64_t)m[i] * P::MOD[j];
+            }
+            if (k < N) {
+                m[k] = (0u - (uint32_t)acc) & LIMB_MASK;
+                acc += m[k];
+            } else {
+                r.v[k - N] = (k == 2 * N - 1) ? (uint32_t)acc : ((uint32_t)acc & LIMB_MASK);
+            }
+            acc >>= 29;
+        }
+        return r;
+    }
     // value < 2p with normalised limbs -> canonical
     SV_HD Fp reduce_lazy() const { return cond_sub(v); }
 

@@ -97,6 +97,8 @@ struct ntt_pass_t {
     int scale_post;  // last pass: 0 none, 1 * n^-1, 2 * g^-k n^-1   (inverse / coset inverse)
     int tw_shift;    // non-last: twiddle exponent = (inner * k) << tw_shift
     const fr_mem_t* tw_full;  // non-last, optional: the closing twiddles of this pass, tw_full[(k << s) + inner] (one product instead of two)
+    int reduce_only; // last pass: the previous pass' closing table already carries 2^261 (and n^-1 when inverse): the final
+                     // multiplication by one / n^-1 shrinks to a bare Montgomery reduction
 };
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -414,7 +416,15 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tabl
                     }
                 } else {
                     g = (d1_0 + col) + (((size_t)mid + ((size_t)k << p.lg_mid)) << p.a1);
-                    if (p.scale_post == 0) {
+                    if (p.reduce_only) {
+                        y = x[m];
+                        if (p.scale_post == 2) {
+                            y = y.mul_lazy(fr_t::load(&tb.g_lo[1][(uint32_t)g & (NTT_TW_SIZE - 1)]));
+                            const uint32_t h = (uint32_t)g >> NTT_TW_BITS;
+                            if (h) y = y.mul_lazy(fr_t::load(&tb.g_hi[1][h]));
+                        }
+                        y = y.mont_reduce_lazy();
+                    } else if (p.scale_post == 0) {
                         y = x[m].mul_lazy(fr_t::one());
                     } else {
                         y = x[m].mul_lazy(fr_t::load(&tb.size_inv[p.lg_n]));
@@ -512,19 +522,33 @@ static inline ntt_plan_t ntt_make_plan(int lg) {
 // every size from 2^17 to 2^24 is used in both directions.  SNARKVM_HIP_NTT_FULL_TW=0 falls back to the composition.
 struct ntt_full_tw_t {
     fr_mem_t* ptr[2][NTT_MAX_RADIX_LG + 1][NTT_LG_MAX + 1] = {};
+    // the table of the pass BEFORE the last one, with 2^261 (forward) or 2^261 / n (inverse) folded in, per transform size:
+    // the last pass then ends with Fp::mont_reduce_lazy() instead of a product by one / by n^-1
+    fr_mem_t* prelast[2][NTT_LG_MAX + 1] = {};
 };
 static ntt_full_tw_t g_ntt_full_tw;  // guarded by the API mutex (api.hip)
+// fold: 0 plain, 1 times 2^261, 2 times 2^261 * size_inv (size_inv points at the Montgomery form of n^-1)
 __global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a, int s, int tw_shift, const fr_mem_t* __restrict__ lo,
-                                        const fr_mem_t* __restrict__ hi) {
+                                        const fr_mem_t* __restrict__ hi, int fold, const fr_mem_t* __restrict__ size_inv) {
     const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (idx >= ((size_t)1 << (a + s))) return;
     const uint32_t k = (uint32_t)(idx >> s), inner = (uint32_t)(idx & (((size_t)1 << s) - 1));
-    tw_lookup(lo, hi, (inner * k) << tw_shift).store(&out[idx]);
+    fr_t t = tw_lookup(lo, hi, (inner * k) << tw_shift);
+    if (fold) {
+        t = t * fr_t::from_table(FrP::R2);  // Montgomery form of (2^261 mod r): the stored word becomes t * 2^522
+        if (fold == 2) t = t * fr_t::load(size_inv);
+    }
+    t.store(&out[idx]);
 }
-static inline const fr_mem_t* ntt_get_full_tw(hipStream_t st, const ntt_tables_t& tb, int a, int s, int tw_shift, int dir) {
+// prelast_lg != 0: this is the pass before the last one of a 2^prelast_lg transform -> the folded variant (see ntt_full_tw_t)
+static inline const fr_mem_t* ntt_get_full_tw(hipStream_t st, const ntt_tables_t& tb, int a, int s, int tw_shift, int dir, int prelast_lg = 0,
+                                              bool* folded = nullptr) {
+    if (folded) *folded = false;
     static const int enabled = getenv("SNARKVM_HIP_NTT_FULL_TW") ? atoi(getenv("SNARKVM_HIP_NTT_FULL_TW")) : 1;
     if (!enabled || a + s > NTT_LG_MAX || a > NTT_MAX_RADIX_LG) return nullptr;
-    fr_mem_t*& slot = g_ntt_full_tw.ptr[dir][a][a + s];
+    static const int fold_enabled = getenv("SNARKVM_HIP_NTT_FOLD") ? atoi(getenv("SNARKVM_HIP_NTT_FOLD")) : 1;
+    if (prelast_lg && !fold_enabled) prelast_lg = 0;
+    fr_mem_t*& slot = prelast_lg ? g_ntt_full_tw.prelast[dir][prelast_lg] : g_ntt_full_tw.ptr[dir][a][a + s];
     if (!slot) {
         const size_t n = (size_t)1 << (a + s);
         if (hipMalloc((void**)&slot, n * sizeof(fr_mem_t)) != hipSuccess) {
@@ -532,9 +556,12 @@ static inline const fr_mem_t* ntt_get_full_tw(hipStream_t st, const ntt_tables_t
             slot = nullptr;
             return nullptr;  // out of memory: compose on the fly
         }
-        hipLaunchKernelGGL(ntt_fill_full_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slot, a, s, tw_shift, tb.pow_lo[dir], tb.pow_hi[dir]);
+        const int fold = !prelast_lg ? 0 : (dir == NTT_INVERSE ? 2 : 1);
+        hipLaunchKernelGGL(ntt_fill_full_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slot, a, s, tw_shift, tb.pow_lo[dir], tb.pow_hi[dir],
+                           fold, (const fr_mem_t*)(tb.size_inv + (prelast_lg ? prelast_lg : 0)));
         (void)hipStreamSynchronize(st);  // other streams may use the table from now on
     }
+    if (folded) *folded = prelast_lg != 0;
     return slot;
 }
 
@@ -569,6 +596,7 @@ static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* 
     const int scale_post = (dir == NTT_INVERSE) ? (type == NTT_COSET ? 2 : 1) : 0;
     const int coset_pre = (dir == NTT_FORWARD && type == NTT_COSET) ? 1 : 0;
     int consumed = 0;
+    bool folded = false;  // the pass before the last one used a table with 2^261 [/ n] folded in
     for (int k = 0; k < pl.npass; k++) {
         ntt_pass_t p;
         p.lg_n = lg;
@@ -579,12 +607,18 @@ static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* 
         p.scale_post = p.last ? scale_post : 0;
         p.a1 = p.lg_mid = p.s = p.tw_shift = 0;
         p.tw_full = nullptr;
+        p.reduce_only = 0;
         if (!p.last) {
             p.s = lg - consumed - p.a;
             p.lgT = p.s < 3 ? p.s : 3;
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
-            p.tw_full = ntt_get_full_tw(st, tb, p.a, p.s, p.tw_shift, dir);
+            static const int use_v1_kernel = getenv("SNARKVM_HIP_NTT_V1") ? atoi(getenv("SNARKVM_HIP_NTT_V1")) : 0;
+            const bool prelast = (k == pl.npass - 2) && !use_v1_kernel;
+            bool f = false;
+            p.tw_full = ntt_get_full_tw(st, tb, p.a, p.s, p.tw_shift, dir, prelast ? lg : 0, &f);
+            folded = f;
         } else {
+            p.reduce_only = folded ? 1 : 0;
             p.a1 = (pl.npass >= 2) ? pl.a[0] : 0;
             p.lg_mid = (pl.npass == 3) ? pl.a[1] : 0;
             p.lgT = p.a1 < 3 ? p.a1 : 3;
