@@ -331,3 +331,28 @@ def g1_deserialize(b, compressed, validate=False):
     if validate and not (g1_is_on_curve(p) and g1_mul(p, R_MOD) is None):
         raise SerializationError("InvalidData")
     return p
+
+
+def g2_serialize(p):
+    """Uncompressed G2 point ((x0, x1), (y0, y1)) or None: c0 plain, c1 with the SWFlags on the last coordinate
+    (fields/src/fp2.rs:425-455; curves/src/templates/macros.rs:86-95)."""
+    (x0, x1), (y0, y1), flags = (((0, 0), (1, 0), 1 << 6) if p is None else (p[0], p[1], 0))
+    b = bytearray(b"".join(v.to_bytes(48, "little") for v in (x0, x1, y0, y1)))
+    b[191] |= flags
+    return bytes(b)
+
+
+def g2_deserialize(b, validate=False):
+    vals = []
+    for k in range(3):
+        v = int.from_bytes(b[48 * k : 48 * k + 48], "little")
+        if v >= Q_MOD:
+            raise SerializationError("coordinate >= q")
+        vals.append(v)
+    y1, _, inf = _read_fq_with_flags(b[144:192])
+    if inf:
+        return None
+    p = ((vals[0], vals[1]), (vals[2], y1))
+    if validate and not (g2_is_on_curve(p) and g2_mul(p, R_MOD) is None):
+        raise SerializationError("InvalidData")
+    return p

@@ -1016,6 +1016,50 @@ RustError snarkvm_hip_g1_deserialize(void* out_affine, const void* bytes, size_t
     }
     API_END
 }
+RustError snarkvm_hip_g2_deserialize(void* out_affine, const void* bytes, size_t n, int validate) {
+    API_BEGIN
+#ifdef SV_NO_G2
+    throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
+#else
+    if (n) {
+        if (!out_affine || !bytes) throw hip_failure{hipErrorInvalidValue, "g2_deserialize: null argument", __LINE__};
+        g_ctx.bases_tmp.ensure(n * 192);
+        g_ctx.poly[0].ensure(n * 200);
+        g_ctx.serde_status.ensure(4);
+        HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, bytes, n * 192, hipMemcpyHostToDevice, g_ctx.stream));
+        HIP_TRY(hipMemsetAsync(g_ctx.serde_status.p, 0, 4, g_ctx.stream));
+        hipLaunchKernelGGL(g2_deserialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, g_ctx.bases_tmp.as<uint8_t>(), n, validate,
+                           g_ctx.poly[0].as<uint8_t>(), g_ctx.serde_status.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        uint32_t st = 0;
+        HIP_TRY(hipMemcpyAsync(&st, g_ctx.serde_status.p, 4, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipMemcpyAsync(out_affine, g_ctx.poly[0].p, n * 200, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        serde_throw_on_status(st, "g2_deserialize");
+    }
+#endif
+    API_END
+}
+RustError snarkvm_hip_g2_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz) {
+    API_BEGIN
+#ifdef SV_NO_G2
+    throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
+#else
+    if (n) {
+        if (!out_bytes || !affine) throw hip_failure{hipErrorInvalidValue, "g2_serialize: null argument", __LINE__};
+        if (ffi_affine_sz < 200 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "g2_serialize: bad stride", __LINE__};
+        g_ctx.bases_tmp.ensure(n * ffi_affine_sz);
+        g_ctx.poly[0].ensure(n * 192);
+        HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, affine, n * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
+        hipLaunchKernelGGL(g2_serialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, g_ctx.bases_tmp.as<uint8_t>(), ffi_affine_sz, n,
+                           g_ctx.poly[0].as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_bytes, g_ctx.poly[0].p, n * 192, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+#endif
+    API_END
+}
 RustError snarkvm_hip_g1_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz, int compressed) {
     API_BEGIN
     if (n) {

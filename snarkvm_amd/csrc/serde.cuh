@@ -204,4 +204,70 @@ __global__ void g1_serialize_kernel(const uint8_t* __restrict__ affine, size_t s
     }
 }
 
+// ---- G2 (uncompressed only): x.c0, x.c1, y.c0, y.c1 as 48-byte little-endian canonical integers, SWFlags in the top bits
+// of the last one (fields/src/fp2.rs:425-455: c0 plain, c1 with the flags); 192 bytes, e.g. `beta-h.usrs`.
+// G2 curve constant b' = (0, b1) (curves/src/bls12_377/g2.rs:92-113), canonical integer words of b1
+__device__ static const uint32_t G2_B_C1_INT[12] = {0x9999999au, 0x1c9ed999u, 0x1ccccccdu, 0x0dd39e5cu, 0x3c6bf800u, 0x129207b6u,
+                                                   0xcd5fd889u, 0xdc7b4f91u, 0x7460c589u, 0x43bd0373u, 0xdb0fd6f3u, 0x010222f6u};
+__device__ inline bool g2_is_on_curve(const aff_t<fq2_t>& p) {
+    uint32_t bw[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) bw[k] = G2_B_C1_INT[k];
+    const fq2_t b = {fq_t::zero(), fq_t::unpack(bw).int_to_mont()};
+    return p.y.sqr() == p.x.sqr() * p.x + b;
+}
+__device__ inline bool g2_is_in_subgroup(const aff_t<fq2_t>& p) {
+    xyzz_t<fq2_t> acc = xyzz_t<fq2_t>::inf();
+    for (int w = 7; w >= 0; w--) {
+        const uint32_t word = FR_MODULUS_WORDS[w];
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = acc.dbl();
+            if ((word >> bit) & 1) acc.add_affine(p);
+        }
+    }
+    return acc.is_inf();
+}
+__global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int validate, uint8_t* __restrict__ out_rust, uint32_t* status) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* src = bytes + i * 192;
+    const uint8_t fb = src[191];
+    const bool f_pos = (fb >> 7) & 1, f_inf = (fb >> 6) & 1;
+    uint32_t st = 0;
+    if (f_pos && f_inf) st |= SERDE_BAD_FLAGS;
+    fq_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (!fq_from_le_bytes(src + 48 * k, k == 3 ? 0x3fffffffu : 0xffffffffu, c[k])) st |= SERDE_NOT_CANONICAL;
+    aff_t<fq2_t> p = {{c[0].int_to_mont(), c[1].int_to_mont()}, {c[2].int_to_mont(), c[3].int_to_mont()}};
+    if (validate && !f_inf && !st) {
+        if (!g2_is_on_curve(p))
+            st |= SERDE_NOT_ON_CURVE;
+        else if (!g2_is_in_subgroup(p))
+            st |= SERDE_NOT_IN_SUBGROUP;
+    }
+    if (st) atomicOr(status, st);
+    uint32_t* dst = (uint32_t*)(out_rust + i * 200);  // Rust G2Affine: x (c0, c1), y (c0, c1), infinity, pad
+    p.x.c0.to_raw_words(dst);
+    p.x.c1.to_raw_words(dst + 12);
+    p.y.c0.to_raw_words(dst + 24);
+    p.y.c1.to_raw_words(dst + 36);
+    dst[48] = f_inf ? 1u : 0u;
+    dst[49] = 0;
+}
+__global__ void g2_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, uint8_t* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = (const uint32_t*)(affine + i * stride);
+    const bool inf = (src[48] & 0xffu) != 0;
+    uint8_t* dst = out + i * 192;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t w[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) w[j] = src[12 * k + j];
+        fq_to_le_bytes(fq_t::from_raw_words(w).mont_to_int(), (k == 3 && inf) ? (uint8_t)(1u << 6) : (uint8_t)0, dst + 48 * k);
+    }
+}
+
 }  // namespace sv

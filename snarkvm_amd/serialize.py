@@ -68,3 +68,30 @@ def register_bases_serialized(data, npoints, compressed=False, validate=False, t
     _check(_lib.lib().snarkvm_hip_register_bases_serialized(ctypes.byref(h), ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(npoints),
                                                            ctypes.c_int(int(compressed)), ctypes.c_int(int(validate)), ctypes.c_int(int(tables))))
     return h
+
+
+G2_UNCOMPRESSED_SIZE = 192
+
+
+def g2_deserialize(data, validate=False):
+    """bytes -> G2_AFFINE record array (uncompressed encoding only, e.g. `beta-h.usrs`)."""
+    from .layout import G2_AFFINE
+
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    if buf.shape[0] % G2_UNCOMPRESSED_SIZE:
+        raise SerializationError("truncated input")
+    n = buf.shape[0] // G2_UNCOMPRESSED_SIZE
+    out = np.zeros(n, dtype=G2_AFFINE)
+    _check(_lib.lib().snarkvm_hip_g2_deserialize(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(n),
+                                                ctypes.c_int(int(validate))))
+    return out
+
+
+def g2_serialize(points):
+    from .layout import G2_AFFINE
+
+    points = np.ascontiguousarray(points, dtype=G2_AFFINE).reshape(-1)
+    out = np.zeros(points.shape[0] * G2_UNCOMPRESSED_SIZE, dtype=np.uint8)
+    _check(_lib.lib().snarkvm_hip_g2_serialize(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(points.ctypes.data), ctypes.c_size_t(points.shape[0]),
+                                              ctypes.c_size_t(G2_AFFINE.itemsize)))
+    return out.tobytes()

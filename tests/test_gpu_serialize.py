@@ -81,3 +81,34 @@ def test_msm_over_bases_registered_from_bytes(golden, compressed):
         rb.close()
     count, body = serialize.split_usrs(len(pts).to_bytes(8, "little") + raw)
     assert count == n and bytes(body) == raw
+
+
+def test_g2_uncompressed_on_device(golden):
+    """`beta-h.usrs` and synthetic G2 points through the device decoder / encoder, against the Python oracle."""
+    from tests.test_gpu_parity import _g2_bases
+
+    raw = bytes(golden["beta_h_g2"])
+    got = serialize.g2_deserialize(raw, validate=True)
+    assert util.g2_affine_to_ints(got) == [pyref.g2_deserialize(raw)]
+    assert serialize.g2_serialize(got) == raw
+    pts = _g2_bases(golden, 40)
+    pts[3]["infinity"] = 1
+    ints = util.g2_affine_to_ints(pts)
+    enc = serialize.g2_serialize(pts)
+    # the encoder writes the coordinates of an infinity record as they are; the oracle writes (0, 1): compare the others
+    for i, p in enumerate(ints):
+        if p is not None:
+            assert enc[192 * i : 192 * i + 192] == pyref.g2_serialize(p)
+        else:
+            assert enc[192 * i + 191] >> 6 == 1
+    back = serialize.g2_deserialize(enc)
+    assert util.g2_affine_to_ints(back) == ints
+    bad = bytearray(enc[:192])
+    bad[191] |= 0xC0
+    with pytest.raises(serialize.SerializationError):
+        serialize.g2_deserialize(bytes(bad))
+    off = bytearray(enc[:192])
+    off[0] ^= 1  # no longer on the curve
+    assert len(serialize.g2_deserialize(bytes(off))) == 1
+    with pytest.raises(serialize.SerializationError):
+        serialize.g2_deserialize(bytes(off), validate=True)

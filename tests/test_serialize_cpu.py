@@ -76,3 +76,12 @@ def test_decode_errors():
     assert pyref.g1_deserialize(enc, compressed=False) == (x, y)
     with pytest.raises(pyref.SerializationError):
         pyref.g1_deserialize(enc, compressed=False, validate=True)
+
+
+def test_g2_beta_h_bytes_decode(golden):
+    """`beta-h.usrs` (one uncompressed G2 point): on the curve, in the prime-order subgroup, re-encoding is the identity."""
+    raw = bytes(golden["beta_h_g2"])
+    p = pyref.g2_deserialize(raw, validate=True)
+    assert p is not None and pyref.g2_is_on_curve(p)
+    assert pyref.g2_serialize(p) == raw
+    assert pyref.g2_deserialize(pyref.g2_serialize(None)) is None
