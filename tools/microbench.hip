@@ -174,6 +174,63 @@ __host__ __device__ __forceinline__ F13 mul29(const F13& a, const F13& b) {
     return r;
 }
 
+// (C) 28-bit limbs (14), Montgomery radix 2^392: q / R = 2^-15, so the product of operands < 128 q comes out < 1.001 q
+// WITHOUT a conditional subtraction ("almost reduced" arithmetic; DESIGN.md 8, next levers).  +16 % multiply-adds.
+struct F14 { uint32_t v[14]; };
+static constexpr uint32_t M28 = (1u << 28) - 1;
+__host__ __device__ constexpr uint32_t q28(int i) {
+    int bit = 28 * i, w = bit / 32, s = bit % 32;
+    uint64_t lo = (w < 12) ? QMOD[w] : 0, hi = (w + 1 < 12) ? QMOD[w + 1] : 0;
+    return (uint32_t)(((lo | (hi << 32)) >> s) & M28);
+}
+__host__ __device__ __forceinline__ F14 mul28_lazy(const F14& a, const F14& b) {
+    constexpr int N = 14;
+    uint32_t m[N];
+    F14 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) {
+#pragma unroll
+        for (int i = 0; i < N; i++) { int j = k - i; if (j >= 0 && j < N) acc += (uint64_t)a.v[i] * b.v[j]; }
+#pragma unroll
+        for (int i = 0; i < N; i++) { int j = k - i; if (j >= 1 && j < N && i < k) acc += (uint64_t)m[i] * q28(j); }
+        if (k < N) { m[k] = (0u - (uint32_t)acc) & M28; acc += m[k]; }
+        else r.v[k - N] = (k == 2 * N - 1) ? (uint32_t)acc : ((uint32_t)acc & M28);
+        acc >>= 28;
+    }
+    return r;
+}
+__global__ void k_mulbench28(F14* out, const F14* in, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    F14 a = in[tid & 1023], b = in[(tid + 1) & 1023];
+    for (int it = 0; it < iters; it++) a = mul28_lazy(a, b);
+    out[tid] = a;
+}
+// (B') the 29-bit product without its conditional subtraction (timing only: isolates what that step costs)
+__host__ __device__ __forceinline__ F13 mul29_nosub(const F13& a, const F13& b) {
+    constexpr int N = 13;
+    uint32_t m[N];
+    F13 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) {
+#pragma unroll
+        for (int i = 0; i < N; i++) { int j = k - i; if (j >= 0 && j < N) acc += (uint64_t)a.v[i] * b.v[j]; }
+#pragma unroll
+        for (int i = 0; i < N; i++) { int j = k - i; if (j >= 1 && j < N && i < k) acc += (uint64_t)m[i] * q29(j); }
+        if (k < N) { m[k] = (0u - (uint32_t)acc) & M29; acc += m[k]; }
+        else r.v[k - N] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    return r;
+}
+__global__ void k_mulbench29_nosub(F13* out, const F13* in, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    F13 a = in[tid & 1023], b = in[(tid + 1) & 1023];
+    for (int it = 0; it < iters; it++) a = mul29_nosub(a, b);
+    out[tid] = a;
+}
+
 template <int V>
 __global__ void k_mulbench(F12* out, const F12* in, int iters) {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,6 +333,27 @@ int main() {
         int bad = 0;
         for (int t = 0; t < 64; t++) { F13 a = h13[t & 1023], b = h13[(t + 1) & 1023]; for (int it = 0; it < iters; it++) a = mul29(a, b); if (memcmp(&a, &g13[t], sizeof a)) bad++; }
         printf("%-34s %8.3f ms  %7.2f Gmul/s  device-vs-host mismatches: %d / 64\n", "mont29 (13x29-bit) plain C++", ms, (double)grid * block * iters / ms * 1e-6, bad);
+    }
+    {
+        for (int rep = 0; rep < 2; rep++) { CHECK(hipEventRecord(e0)); hipLaunchKernelGGL(k_mulbench29_nosub, dim3(grid), dim3(block), 0, 0, d_o13, d_in13, iters); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); }
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-34s %8.3f ms  %7.2f Gmul/s  (timing only)\n", "mont29 without the cond. subtract", ms, (double)grid * block * iters / ms * 1e-6);
+        // 14 x 28-bit limbs, lazy: operands = the 13 x 29 inputs re-sliced (any value < 2^392 is a valid operand)
+        std::vector<F14> h14(1024);
+        for (int t = 0; t < 1024; t++) {
+            for (int i = 0; i < 14; i++) h14[t].v[i] = 0;
+            for (int bit = 0; bit < 377; bit++) if ((h13[t].v[bit / 29] >> (bit % 29)) & 1) h14[t].v[bit / 28] |= 1u << (bit % 28);
+        }
+        F14 *d_in14, *d_o14;
+        CHECK(hipMalloc(&d_in14, sizeof(F14) * 1024)); CHECK(hipMalloc(&d_o14, sizeof(F14) * (size_t)grid * block));
+        CHECK(hipMemcpy(d_in14, h14.data(), sizeof(F14) * 1024, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; rep++) { CHECK(hipEventRecord(e0)); hipLaunchKernelGGL(k_mulbench28, dim3(grid), dim3(block), 0, 0, d_o14, d_in14, iters); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); }
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<F14> g14(64);
+        CHECK(hipMemcpy(g14.data(), d_o14, sizeof(F14) * 64, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int t = 0; t < 64; t++) { F14 a = h14[t & 1023], b = h14[(t + 1) & 1023]; for (int it = 0; it < iters; it++) a = mul28_lazy(a, b); if (memcmp(&a, &g14[t], sizeof a)) bad++; }
+        printf("%-34s %8.3f ms  %7.2f Gmul/s  device-vs-host mismatches: %d / 64\n", "mont28 (14x28-bit) lazy, no sub", ms, (double)grid * block * iters / ms * 1e-6, bad);
     }
     // ---- memory probes
     {
