@@ -52,7 +52,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        backend = os.environ.get("SNARKVM_BENCH_BACKEND", "nccl")  # "gloo": smoke-testing the N > 1 path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
 

@@ -641,3 +641,21 @@ def test_extension_abi_rejects_bad_arguments(golden):
     err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(25), 0, 0, 0))                       # lg > 24: caller falls back
     err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(4), 7, 0, 0))                        # bad enum
     err(L.snarkvm_hip_g1_serialize(P(x), P(bases), ctypes.c_size_t(1), ctypes.c_size_t(96), 0))                # stride < 104
+
+
+def test_bench_two_rank_path_on_one_gpu():
+    """bench.py's N > 1 code path (rendezvous, barriers, max-over-ranks timing, rank-0 JSON) with two ranks sharing this
+    GPU over gloo (RCCL refuses two ranks on one device; the collective semantics are the same)."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SNARKVM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--lg-msm", "16", "--lg-ntt", "16", "--ntt-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=util.ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 2 * (1 << 16) / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
