@@ -29,6 +29,19 @@ def golden():
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _native_libraries_built():
+    """A fresh checkout has no built artefacts (they are git-ignored): compile the HIP backend (hipcc cross-compiles
+    without a GPU, a few minutes once) and the CPU oracle before the first test needs them."""
+    from snarkvm_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        from snarkvm_amd import build as hip_build
+
+        hip_build.build()
+    yield
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _oracle_threads():
     """The CPU oracle parallelises with OpenMP; on a many-core GPU host (256 hardware threads) the fork/join cost of
     hundreds of tiny parallel regions dominates small transforms, so the checker is capped at 16 threads."""
