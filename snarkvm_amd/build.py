@@ -11,31 +11,46 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsnarkvm_hip.so")
-SOURCES = ["api.hip"]
-HEADERS = ["ff.cuh", "ec.cuh", "ntt.cuh", "msm.cuh", os.path.join("..", "..", "include", "snarkvm_hip.h")]
+SOURCES = ["api.hip", "api_fr.hip", "api_g2.hip"]  # compiled in parallel (the Fq2 instantiations are half of the compile time), then linked
+
+
+def _inputs():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh"))]
+    files.append(os.path.join(HERE, "..", "include", "snarkvm_hip.h"))
+    return files
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+    return any(os.path.getmtime(f) > t for f in _inputs())
 
 
 def build(force=False, verbose=False, fast=False):
-    """fast=True (development only) compiles without the G2 / Fq2 instantiations (about half the compile time)."""
+    """fast=True (development only) compiles without the G2 / Fq2 instantiations."""
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-           "-o", LIB] + (["-DSV_NO_G2"] if fast else []) + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DSV_NO_G2"] if fast else [])
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
+    for o in objs:
+        os.remove(o)
     return LIB
 
 

@@ -28,14 +28,14 @@ __device__ inline g1_xyzz_t g1_mul_words(const g1_xyzz_t& p, const uint32_t* k) 
 __device__ __forceinline__ g1_xyzz_t g1_neg(const g1_xyzz_t& p) { return {p.x, p.y.neg(), p.zz, p.zzz}; }
 
 // Jacobian memory image (144 B, R = 2^384) <-> XYZZ record
-__global__ void g1_jac_to_xyzz_kernel(const uint32_t* __restrict__ in, g1_xyzz_mem_t* __restrict__ out, size_t n) {
+static __global__ void g1_jac_to_xyzz_kernel(const uint32_t* __restrict__ in, g1_xyzz_mem_t* __restrict__ out, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = in + 36 * i;
     const g1_jac_t j = {fq_t::from_raw_words(src), fq_t::from_raw_words(src + 12), fq_t::from_raw_words(src + 24)};
     g1_store_xyzz(&out[i], g1_xyzz_t::from_jacobian(j));
 }
-__global__ void g1_xyzz_to_jac_kernel(const g1_xyzz_mem_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+static __global__ void g1_xyzz_to_jac_kernel(const g1_xyzz_mem_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const g1_jac_t j = g1_load_xyzz(&in[i]).to_jacobian();
@@ -49,7 +49,7 @@ __global__ void g1_xyzz_to_jac_kernel(const g1_xyzz_mem_t* __restrict__ in, uint
 static constexpr int FIXED_WINDOW = 8;                                  // bits per window of the device table
 static constexpr int FIXED_OUTER = (253 + FIXED_WINDOW - 1) / FIXED_WINDOW;  // windows over the 253-bit scalar field
 // table[outer][inner] = inner * 2^(FIXED_WINDOW * outer) * g, affine (fixed_base.rs:42-68); thread (outer, inner)
-__global__ void __launch_bounds__(256) g1_fixed_table_kernel(g1_aff_mem_t g_mem, g1_aff_mem_t* __restrict__ table) {
+static __global__ void __launch_bounds__(256) g1_fixed_table_kernel(g1_aff_mem_t g_mem, g1_aff_mem_t* __restrict__ table) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint32_t)FIXED_OUTER << FIXED_WINDOW) return;
     const uint32_t outer = t >> FIXED_WINDOW, inner = t & ((1u << FIXED_WINDOW) - 1);
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) g1_fixed_table_kernel(g1_aff_mem_t g_mem,
     store_aff<fq_t>(&table[t], q);
 }
 // out_i = sum_outer table[outer][digit_outer(v_i)] (fixed_base.rs:70-97); v_i are Fr elements in Montgomery form
-__global__ void __launch_bounds__(256) g1_fixed_msm_kernel(const g1_aff_mem_t* __restrict__ table, const fr_mem_t* __restrict__ scalars, size_t n,
+static __global__ void __launch_bounds__(256) g1_fixed_msm_kernel(const g1_aff_mem_t* __restrict__ table, const fr_mem_t* __restrict__ scalars, size_t n,
                                                            uint32_t* __restrict__ out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) g1_fixed_msm_kernel(const g1_aff_mem_t* _
 // One decimation-in-frequency stage over XYZZ points, in place: for the pair (i, i + half) of a block of 2 * half points
 //     a' = a + b,   b' = (a - b) * tw[j * stride],  j = index inside the half block, tw[k] = root^k as canonical integers.
 // log2(n) stages leave the result in bit-reversed order (g1_bitrev_kernel restores natural order).
-__global__ void __launch_bounds__(64) g1_ntt_stage_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, size_t half, const fr_mem_t* __restrict__ tw,
+static __global__ void __launch_bounds__(64) g1_ntt_stage_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, size_t half, const fr_mem_t* __restrict__ tw,
                                                           size_t stride) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= n / 2) return;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64) g1_ntt_stage_kernel(g1_xyzz_mem_t* __restr
     g1_store_xyzz(&pts[ia], s);
     g1_store_xyzz(&pts[ib], d);
 }
-__global__ void g1_bitrev_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, int lg) {
+static __global__ void g1_bitrev_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, int lg) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     size_t r = 0;
@@ -130,7 +130,7 @@ __global__ void g1_bitrev_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, int 
     }
 }
 // pts[i] <- k * pts[i] (the 1/n of the inverse transform)
-__global__ void __launch_bounds__(64) g1_scale_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, fr_mem_t k_int) {
+static __global__ void __launch_bounds__(64) g1_scale_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, fr_mem_t k_int) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k[8];

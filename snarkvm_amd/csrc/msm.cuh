@@ -141,7 +141,7 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
 // generic exclusive scan (u32), tiles of 2048 per 256-thread block, recursive over block sums
 // ------------------------------------------------------------------------------------------
 static constexpr int SCAN_TILE = 2048;
-__global__ void scan_tile_kernel(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n) {
+static __global__ void scan_tile_kernel(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n) {
     __shared__ uint32_t sh[256];
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
     uint32_t v[8], s = 0;
@@ -166,7 +166,7 @@ __global__ void scan_tile_kernel(const uint32_t* in, uint32_t* out, uint32_t* bl
     }
     if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = sh[255];
 }
-__global__ void scan_add_kernel(uint32_t* out, const uint32_t* block_offsets, size_t n) {
+static __global__ void scan_add_kernel(uint32_t* out, const uint32_t* block_offsets, size_t n) {
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
     const uint32_t add = block_offsets[blockIdx.x];
 #pragma unroll
@@ -298,7 +298,7 @@ __device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ d, s
     }
 }
 // counts[w][chunk][b] (contiguous per workgroup: no write amplification)
-__global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts,
+static __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts,
                                                         msm_sort_params_t p) {
     extern __shared__ uint32_t hist[];
     const uint32_t chunk = blockIdx.x, w = blockIdx.y;
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restri
 }
 // Per bucket k = (w, b): turn the per-chunk counts into ranks (exclusive prefix over chunks, in place) and the
 // bucket size.  Threads adjacent in b -> coalesced.
-__global__ void msm_bucket_rank_kernel(uint32_t* __restrict__ counts_to_rank, uint32_t* __restrict__ size, uint32_t nb,
+static __global__ void msm_bucket_rank_kernel(uint32_t* __restrict__ counts_to_rank, uint32_t* __restrict__ size, uint32_t nb,
                                        uint32_t nchunks, uint32_t nbt, uint32_t* __restrict__ max_size) {
     __shared__ uint32_t blk_max;
     if (threadIdx.x == 0) blk_max = 0;
@@ -344,7 +344,7 @@ __global__ void msm_bucket_rank_kernel(uint32_t* __restrict__ counts_to_rank, ui
 // all partial-line writes of a region come from one workgroup, so they merge in its L2 (the bucket-major layout
 // measured 8x write amplification, profiles/r01_rocprofv3_pmc_hbm_bytes.txt).  loc_off[w][chunk][b] = offset of
 // bucket b inside the region.
-__global__ void __launch_bounds__(1024) msm_locoff_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ size,
+static __global__ void __launch_bounds__(1024) msm_locoff_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ size,
                                                           uint32_t* __restrict__ loc_off, msm_sort_params_t p) {
     extern __shared__ uint32_t cursor[];  // nb counters followed by 1024 scan slots
     uint32_t* part = cursor + p.nb;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(1024) msm_locoff_kernel(const uint32_t* __rest
 // entries (every 4-byte store leaves the write-through L2 as its own 32-byte sector write); splitting the bucket
 // range into passes was tried to let the stores merge in L2 and does not help beyond 2 passes (1: 4.13 ms, 2: 3.92,
 // 4: 5.21, 8: 4.94 at 2^24) - the real fix is an LDS-staged two-level radix partition (known weak spots).
-__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
+static __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
                                                            const uint32_t* __restrict__ loc_off, uint32_t* __restrict__ sorted,
                                                            msm_sort_params_t p, uint32_t npass) {
     extern __shared__ uint32_t cursor[];  // nb / npass cursors
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
 // 5./6. accumulate + reduce rounds
 // ------------------------------------------------------------------------------------------
 // cnt_out[k] = ceil(cnt_in[k] / S)   (level 0: cnt_in = bucket sizes)
-__global__ void msm_alloc_kernel(const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t nbt, uint32_t S) {
+static __global__ void msm_alloc_kernel(const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t nbt, uint32_t S) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > nbt) return;
     cnt_out[k] = (k == nbt) ? 0u : (cnt_in[k] + S - 1) / S;
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256) precompute_table_kernel(const aff_mem_t<F
 // Projective -> Affine (affine.rs:331-353 `From<Projective> for Affine`; batch form projective.rs:172-219)
 // in: Jacobian memory images (144 B), out: Rust G1Affine (104 B).  One Fermat inversion per point.
 // ------------------------------------------------------------------------------------------
-__global__ void g1_to_affine_kernel(const uint32_t* in, uint32_t* out, size_t n) {
+static __global__ void g1_to_affine_kernel(const uint32_t* in, uint32_t* out, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = in + 36 * i;
@@ -778,7 +778,7 @@ __global__ void g1_to_affine_kernel(const uint32_t* in, uint32_t* out, size_t n)
 // Sum of a few Jacobian points (the per-device partial results of a point-range-split MSM: replaces the host `dadd`
 // loop of algorithms/cuda/cuda/snarkvm.cu:290-295).  One workgroup; lane t adds points t, t + 64, ..., then an LDS tree.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) g1_sum_kernel(const uint32_t* in, size_t n, uint32_t* out) {
+static __global__ void __launch_bounds__(64) g1_sum_kernel(const uint32_t* in, size_t n, uint32_t* out) {
     __shared__ g1_xyzz_mem_t part[64];
     g1_xyzz_t acc = g1_xyzz_t::inf();
     for (size_t i = threadIdx.x; i < n; i += 64) {
@@ -808,7 +808,7 @@ __global__ void __launch_bounds__(64) g1_sum_kernel(const uint32_t* in, size_t n
 // Synthetic base generation (benchmark / test utility): out[i] = (start + i) * G in the Rust layout
 // ------------------------------------------------------------------------------------------
 static constexpr int GEN_RUN = 32;
-__global__ void __launch_bounds__(256) g1_generate_bases_kernel(g1_aff_mem_t gen, uint64_t start, size_t n, uint8_t* out,
+static __global__ void __launch_bounds__(256) g1_generate_bases_kernel(g1_aff_mem_t gen, uint64_t start, size_t n, uint8_t* out,
                                                                 size_t stride, g1_xyzz_mem_t* scratch_pts,
                                                                 fq_mem_t* scratch_prod) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

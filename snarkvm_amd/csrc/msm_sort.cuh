@@ -184,13 +184,13 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* 
 }
 
 // ---- level 2 tiling: bin q = w * B1 + bin covers [binstart[q], binstart[q+1]) of v1/l1 and gets ceil(size / TILE) tiles
-__global__ void radix_bin_layout_kernel(const uint32_t* __restrict__ off1, const uint32_t* __restrict__ counts1, size_t ncounts1,
+static __global__ void radix_bin_layout_kernel(const uint32_t* __restrict__ off1, const uint32_t* __restrict__ counts1, size_t ncounts1,
                                         uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t TPW) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nbins) return;
     binstart[q] = (q < nbins) ? off1[(size_t)q * TPW] : off1[ncounts1 - 1] + counts1[ncounts1 - 1];
 }
-__global__ void radix_bin_tiles_kernel(const uint32_t* __restrict__ binstart, uint32_t* __restrict__ ntiles, uint32_t nbins) {
+static __global__ void radix_bin_tiles_kernel(const uint32_t* __restrict__ binstart, uint32_t* __restrict__ ntiles, uint32_t nbins) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nbins) return;
     ntiles[q] = (q == nbins) ? 0u : (binstart[q + 1] - binstart[q] + SORT_TILE - 1) / SORT_TILE;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist2_kernel(const RIN* __
     for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) counts2[(size_t)t2 * B2 + i] = hist[i];
 }
 // ---- per bucket k = q * B2 + low: exclusive prefix of its counts over the tiles of bin q + bucket size
-__global__ void radix_colscan2_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
+static __global__ void radix_colscan2_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
                                       const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ bsize, uint32_t nbins, int LB,
                                       uint32_t* __restrict__ max_size) {
     __shared__ uint32_t blk_max;
@@ -244,7 +244,7 @@ __global__ void radix_colscan2_kernel(const uint32_t* __restrict__ counts2, uint
 }
 // Same result, one workgroup per SEGMENT (few segments with many tiles each: the per-key loop over ~100 tiles is split
 // over 8 slices of 128 key lanes).  blockDim.x must be 1024.
-__global__ void __launch_bounds__(1024) radix_colscan2_seg_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
+static __global__ void __launch_bounds__(1024) radix_colscan2_seg_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
                                                                   const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ bsize,
                                                                   uint32_t nbins, int LB, uint32_t* __restrict__ max_size) {
     __shared__ uint32_t part[8][128];
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_bm_kernel(const aff_mem_t<
 // so small or uneven buckets (wide windows: ~100 entries each) cost no SIMD idle time.  Bucket k receives one partial from
 // each of the threads tS in [boff[k] / S, (boff[k+1] - 1) / S]: cnt[k] = that count, slot = start[k] + (t - boff[k] / S),
 // the (cnt, start, partial) triple the reduce rounds consume.
-__global__ void msm_alloc_seg_kernel(const uint32_t* __restrict__ boff, uint32_t* __restrict__ cnt, uint32_t nbt, uint32_t S) {
+static __global__ void msm_alloc_seg_kernel(const uint32_t* __restrict__ boff, uint32_t* __restrict__ cnt, uint32_t nbt, uint32_t S) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > nbt) return;
     uint32_t c = 0;

@@ -50,7 +50,7 @@ __device__ static const uint32_t FR_TWO_ADIC_ROOT_MEM[8] = {0xda3ad648u, 0xaf80d
                                                              0xb2f92525u, 0x03ba0666u, 0x3befb0ceu, 0x0f906c5bu};
 
 // consts[0] = W, [1] = W^-1, [2] = g, [3] = g^-1, then size_inv[0..24]
-__global__ void ntt_setup_consts(ntt_tables_t t) {
+static __global__ void ntt_setup_consts(ntt_tables_t t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t w8[8];
     for (int i = 0; i < 8; i++) w8[i] = FR_TWO_ADIC_ROOT_MEM[i];
@@ -69,7 +69,7 @@ __global__ void ntt_setup_consts(ntt_tables_t t) {
     }
 }
 // lo[i] = b^i, hi[i] = b^(4096 i) for the four bases; local[dir][i] = (W^+-1)^(65536 i)
-__global__ void ntt_fill_tables(ntt_tables_t t) {
+static __global__ void ntt_fill_tables(ntt_tables_t t) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NTT_TW_SIZE) return;
     for (int which = 0; which < 4; which++) {
@@ -111,7 +111,7 @@ __device__ __forceinline__ fr_t tw_lookup(const fr_mem_t* lo, const fr_mem_t* hi
 }
 
 // LDS tile: element e = rho * T + col, stored as two 16-byte planes (conflict-free b128 accesses).
-__global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_tables_t tb) {
+static __global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_tables_t tb) {
     extern __shared__ uint4 lds[];
     const int R = 1 << p.a, T = 1 << p.lgT, E = R << p.lgT;
     uint4* lo_plane = lds;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void dif_group(fr_t* x, int s, int a, int lo, const n
     }
 }
 
-__global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tables_t tb) {
+static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tables_t tb) {
     extern __shared__ uint32_t lds32[];
     const int R = 1 << p.a, T = 1 << p.lgT, E = R << p.lgT;
     ntt_lds_t L;
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tabl
 }
 
 // out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.cuh:128,189; domain.rs:797-804 derange)
-__global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
+static __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= ((size_t)1 << lg_n)) return;
     size_t r = lg_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - lg_n)) : 0;
@@ -457,7 +457,7 @@ __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
 // polynomial_inner_multiply (polynomial.cuh:36-45): out[i] = a[i] * b[i] (memory Montgomery form, R = 2^256).
 // mont261(x, y) = x y 2^-261 = (a b 2^256) 2^-5, so `fix` = 2^(5 + 261) mod r restores the form (see ff.cuh);
 // with fix_later the factor is left for the caller to fold into a later constant.
-__global__ void fr_pointwise_mul_kernel(fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, size_t n, int fix_now) {
+static __global__ void fr_pointwise_mul_kernel(fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, size_t n, int fix_now) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) {
@@ -467,7 +467,7 @@ __global__ void fr_pointwise_mul_kernel(fr_mem_t* out, const fr_mem_t* a, const 
     }
 }
 // Fr::to_bigint (fp_256.rs:380-413) / from_bigint (fp_256.rs:362-377) over a vector: kzg10 convert_to_bigints
-__global__ void fr_to_bigint_kernel(fr_mem_t* out, const fr_mem_t* in, size_t n, int to_bigint) {
+static __global__ void fr_to_bigint_kernel(fr_mem_t* out, const fr_mem_t* in, size_t n, int to_bigint) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) {
@@ -528,7 +528,7 @@ struct ntt_full_tw_t {
 };
 static ntt_full_tw_t g_ntt_full_tw;  // guarded by the API mutex (api.hip)
 // fold: 0 plain, 1 times 2^261, 2 times 2^261 * size_inv (size_inv points at the Montgomery form of n^-1)
-__global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a, int s, int tw_shift, const fr_mem_t* __restrict__ lo,
+static __global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a, int s, int tw_shift, const fr_mem_t* __restrict__ lo,
                                         const fr_mem_t* __restrict__ hi, int fold, const fr_mem_t* __restrict__ size_inv) {
     const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (idx >= ((size_t)1 << (a + s))) return;

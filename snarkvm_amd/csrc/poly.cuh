@@ -21,7 +21,7 @@ namespace sv {
 
 enum { FR_OP_ADD = 0, FR_OP_SUB = 1, FR_OP_MUL = 2, FR_OP_MUL_SUB = 3, FR_OP_SCALE = 4, FR_OP_SUB_SCALAR = 5, FR_OP_AXPY = 6, FR_OP_RSUB_SCALAR = 7 };
 
-__global__ void fr_vec_op_kernel(int op, fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, const fr_mem_t* c, fr_mem_t s_mem, size_t n) {
+static __global__ void fr_vec_op_kernel(int op, fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, const fr_mem_t* c, fr_mem_t s_mem, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     const fr_t s_shift = fr_t::load(&s_mem);
@@ -52,7 +52,7 @@ __global__ void fr_vec_op_kernel(int op, fr_mem_t* out, const fr_mem_t* a, const
 static constexpr int POLY_CHUNK = 32;
 
 // mult[k] = m^(POLY_CHUNK^k), memory form, k < levels (single thread: a handful of multiplications)
-__global__ void fr_horner_multipliers_kernel(fr_mem_t m_mem, fr_mem_t* mult, int levels) {
+static __global__ void fr_horner_multipliers_kernel(fr_mem_t m_mem, fr_mem_t* mult, int levels) {
     if (blockIdx.x | threadIdx.x) return;
     fr_t m = fr_t::load(&m_mem).from_mem_mont();
     for (int k = 0; k < levels; k++) {
@@ -60,7 +60,7 @@ __global__ void fr_horner_multipliers_kernel(fr_mem_t m_mem, fr_mem_t* mult, int
         m = m.pow_u64(POLY_CHUNK);
     }
 }
-__global__ void fr_horner_up_kernel(const fr_mem_t* __restrict__ in, size_t n, const fr_mem_t* __restrict__ m_mem, fr_mem_t* __restrict__ cv,
+static __global__ void fr_horner_up_kernel(const fr_mem_t* __restrict__ in, size_t n, const fr_mem_t* __restrict__ m_mem, fr_mem_t* __restrict__ cv,
                                     size_t T) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -74,7 +74,7 @@ __global__ void fr_horner_up_kernel(const fr_mem_t* __restrict__ in, size_t n, c
 // carry[t + 1] = h at the first index of chunk t + 1 (nullptr when there is a single chunk).  Writes out[i - shift] = h_i
 // for i >= shift and *first = h_0 when shift == 1 (quotient by X - m: q_(i-1) = h_i, remainder = h_0).
 // in == out is allowed when shift == 0.
-__global__ void fr_horner_down_kernel(const fr_mem_t* in, size_t n, const fr_mem_t* __restrict__ m_mem, const fr_mem_t* __restrict__ carry,
+static __global__ void fr_horner_down_kernel(const fr_mem_t* in, size_t n, const fr_mem_t* __restrict__ m_mem, const fr_mem_t* __restrict__ carry,
                                       size_t T, fr_mem_t* out, int shift, fr_mem_t* first) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -95,7 +95,7 @@ __global__ void fr_horner_down_kernel(const fr_mem_t* in, size_t n, const fr_mem
 // Montgomery's trick per thread over the strided set {t, t + T, t + 2T, ...} (any partition gives the same values; a
 // strided one keeps every access coalesced).  Prefix products are parked in `scratch` (n elements, internal form); one
 // Fermat inversion per thread is amortised over ceil(n / T) elements.
-__global__ void fr_batch_inverse_kernel(fr_mem_t* __restrict__ v, size_t n, fr_mem_t coeff_mem, fr_mem_t* __restrict__ scratch, size_t T) {
+static __global__ void fr_batch_inverse_kernel(fr_mem_t* __restrict__ v, size_t n, fr_mem_t coeff_mem, fr_mem_t* __restrict__ scratch, size_t T) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= T) return;
     fr_t tmp = fr_t::one();
@@ -122,7 +122,7 @@ __global__ void fr_batch_inverse_kernel(fr_mem_t* __restrict__ v, size_t n, fr_m
 }
 
 // v_i <- v_i * c * g^i; thread t owns i = t, t + T, ... with running power c g^t (g^T)^k
-__global__ void fr_distribute_powers_kernel(fr_mem_t* __restrict__ v, size_t n, fr_mem_t g_mem, fr_mem_t c_mem, size_t T) {
+static __global__ void fr_distribute_powers_kernel(fr_mem_t* __restrict__ v, size_t n, fr_mem_t g_mem, fr_mem_t c_mem, size_t T) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= T || t >= n) return;
     const fr_t g = fr_t::load(&g_mem).from_mem_mont();
@@ -133,13 +133,13 @@ __global__ void fr_distribute_powers_kernel(fr_mem_t* __restrict__ v, size_t n, 
         pw = pw * step;
     }
 }
-__global__ void fr_fill_kernel(fr_mem_t* v, size_t n, fr_mem_t x) {
+static __global__ void fr_fill_kernel(fr_mem_t* v, size_t n, fr_mem_t x) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) v[i] = x;
 }
 // v_i <- (v_i == x) ? one : zero   (the tau-in-domain branch of evaluate_all_lagrange_coefficients, domain.rs:265-275)
-__global__ void fr_onehot_kernel(fr_mem_t* v, size_t n, fr_mem_t x_mem, fr_mem_t one_mem) {
+static __global__ void fr_onehot_kernel(fr_mem_t* v, size_t n, fr_mem_t x_mem, fr_mem_t one_mem) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     const fr_t x = fr_t::load(&x_mem);
@@ -151,7 +151,7 @@ __global__ void fr_onehot_kernel(fr_mem_t* v, size_t n, fr_mem_t x_mem, fr_mem_t
 // ---- X^D - 1 -------------------------------------------------------------------------------------------------------
 // Long division of a (len coefficients) by X^D - 1 folds the coefficient classes mod D:
 //   quotient_i = sum_{k >= 1} a_(i + kD)   (i < len - D),   remainder_i = sum_{k >= 0} a_(i + kD)   (i < min(D, len)).
-__global__ void fr_fold_vanishing_kernel(const fr_mem_t* __restrict__ a, size_t len, size_t D, fr_mem_t* __restrict__ quot,
+static __global__ void fr_fold_vanishing_kernel(const fr_mem_t* __restrict__ a, size_t len, size_t D, fr_mem_t* __restrict__ quot,
                                          fr_mem_t* __restrict__ rem) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t qlen = len > D ? len - D : 0;
@@ -165,7 +165,7 @@ __global__ void fr_fold_vanishing_kernel(const fr_mem_t* __restrict__ a, size_t 
     if (i < rlen) (acc + fr_t::load(&a[i])).store(&rem[i]);
 }
 // out (len + D elements) = a * (X^D - 1)
-__global__ void fr_mul_vanishing_kernel(const fr_mem_t* __restrict__ a, size_t len, size_t D, fr_mem_t* __restrict__ out) {
+static __global__ void fr_mul_vanishing_kernel(const fr_mem_t* __restrict__ a, size_t len, size_t D, fr_mem_t* __restrict__ out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= len + D) return;
     const fr_t hi = (i >= D) ? fr_t::load(&a[i - D]) : fr_t::zero();

@@ -120,7 +120,7 @@ __device__ inline bool g1_is_in_subgroup(const g1_aff_t& p) {
 
 // One thread per point.  out_native (MSM base slots, infinity = all zero) and out_rust (Rust `G1Affine` memory image,
 // 104-byte stride) are both optional.  status accumulates SERDE_* bits over all points.
-__global__ void g1_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int compressed, int validate, g1_aff_mem_t* out_native,
+static __global__ void g1_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int compressed, int validate, g1_aff_mem_t* out_native,
                                       uint8_t* out_rust, uint32_t* status) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -176,7 +176,7 @@ __global__ void g1_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t 
 }
 
 // Rust `G1Affine` records (stride bytes) -> canonical encoding
-__global__ void g1_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, int compressed, uint8_t* __restrict__ out) {
+static __global__ void g1_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, int compressed, uint8_t* __restrict__ out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = (const uint32_t*)(affine + i * stride);
@@ -227,7 +227,7 @@ __device__ inline bool g2_is_in_subgroup(const aff_t<fq2_t>& p) {
     }
     return acc.is_inf();
 }
-__global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int validate, uint8_t* __restrict__ out_rust, uint32_t* status) {
+static __global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int validate, uint8_t* __restrict__ out_rust, uint32_t* status) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* src = bytes + i * 192;
@@ -255,7 +255,7 @@ __global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t 
     dst[48] = f_inf ? 1u : 0u;
     dst[49] = 0;
 }
-__global__ void g2_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, uint8_t* __restrict__ out) {
+static __global__ void g2_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, uint8_t* __restrict__ out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = (const uint32_t*)(affine + i * stride);

@@ -84,7 +84,8 @@ def test_limb_tables_match_reference_constants(golden):
     m = re.search(r"FR_TWO_ADIC_ROOT_MEM\[8\] = \{(.*?)\}", ntt, re.S)
     words = [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
     assert sum(w << (32 * i) for i, w in enumerate(words)) == pyref.from_limbs(golden["constants"]["fr"]["TWO_ADIC_ROOT_OF_UNITY"])
-    api = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "api.hip")).read()
+    csrc = os.path.join(util.ROOT, "snarkvm_amd", "csrc")
+    api = "".join(open(os.path.join(csrc, f)).read() for f in ("api.hip", "api_fr.hip", "api_g2.hip", "runtime.cuh"))
     for name, key in (("G1_GEN_X", "GENERATOR_X_MONT"), ("G1_GEN_Y", "GENERATOR_Y_MONT")):
         m = re.search(name + r"\[6\] = \{(.*?)\}", api, re.S)
         assert [int(x) for x in re.findall(r"(\d+)ull", m.group(1))] == golden["constants"]["g1"][key]
