@@ -252,18 +252,18 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_
 //     canonical again before it is stored.
 // ------------------------------------------------------------------------------------------
 struct ntt_lds_t {
-    uint32_t* data;  // 9 planes of E limbs
+    uint32_t* data;  // E elements of 9 limbs each (stride 9 words is coprime to the bank count; the limb offsets are immediates)
     uint32_t* tw;    // 9 planes of 128 limbs (w_256 powers, internal form)
     int E;
     __device__ __forceinline__ fr_t get(int e) const {
         fr_t x;
 #pragma unroll
-        for (int l = 0; l < 9; l++) x.v[l] = data[l * E + e];
+        for (int l = 0; l < 9; l++) x.v[l] = data[e * 9 + l];
         return x;
     }
     __device__ __forceinline__ void put(int e, const fr_t& x) const {
 #pragma unroll
-        for (int l = 0; l < 9; l++) data[l * E + e] = x.v[l];
+        for (int l = 0; l < 9; l++) data[e * 9 + l] = x.v[l];
     }
     __device__ __forceinline__ fr_t twiddle(int idx) const {
         fr_t x;
