@@ -244,7 +244,7 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_
 // v2 pass kernel: radix-4 butterflies in registers + lazy reduction.
 //   * two DIF stages per LDS round trip (a = 8: 4 groups, 3 round trips instead of 8), the first group reads
 //     straight from global memory and the last one writes straight back;
-//   * the tile lives in LDS as 9 planes of 29-bit limbs (no pack / unpack between stages);
+//   * the tile lives in LDS as 29-bit limbs, 9 consecutive words per element (no pack / unpack between stages);
 //   * butterflies use lazy arithmetic (ff.cuh): sums are only carry-normalised, differences add 2^s * r, products
 //     skip the conditional subtraction.  Bound: entering local stage s every value is < 2^s * r (inputs canonical),
 //     so after a <= 8 stages values are < 256 r < 2^261 (9 limbs).  The closing multiplication (inter-pass twiddle,
