@@ -230,13 +230,13 @@ RustError snarkvm_hip_synchronize(void);
  * Part 3 - test hooks
  * ------------------------------------------------------------------------------------------- */
 
-/* The device arithmetic (ff.cuh / ec.cuh) compiled for the host and run on the CPU, so that the
+/* The device arithmetic (ff.hip.h / ec.hip.h) compiled for the host and run on the CPU, so that the
  * limb arithmetic can be checked without a GPU.  field: 0 = Fr, 1 = Fq.  op: 0 add, 1 sub, 2 mul,
  * 3 sqr, 4 inverse, 5 neg, 6 from_bigint, 7 to_bigint.  Operands / results are in the reference's
  * memory form (Montgomery R = 2^256 / 2^384), n elements of 32 / 48 bytes. */
 int snarkvm_hip_selftest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
 /* op: 0 = out(Jacobian 144 B) = sum_i (xyzz) points[i] * small_scalars[i] via mixed adds and doublings;
- * exercises every exceptional branch of ec.cuh on the host. */
+ * exercises every exceptional branch of ec.hip.h on the host. */
 int snarkvm_hip_selftest_g1_msm_naive(const void *points_with_infinity, size_t npoints, size_t ffi_affine_sz,
                                       const void *scalars, void *out);
 /* The MSM planner (window width, windows, digit rows, buckets, segment length) evaluated on the host:

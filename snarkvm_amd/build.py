@@ -15,7 +15,7 @@ SOURCES = ["api.hip", "api_fr.hip", "api_g2.hip"]  # compiled in parallel (the F
 
 
 def _inputs():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh"))]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     files.append(os.path.join(HERE, "..", "include", "snarkvm_hip.h"))
     return files
 

@@ -1,10 +1,10 @@
 // api.hip - C ABI (include/snarkvm_hip.h) of the gfx950 MSM / NTT backend: the G1 / Fr entry points.
 //
-// Host runtime (runtime.cuh) = what algorithms/cuda/cuda/snarkvm.cu:73-312 (snarkvm_t) and snarkvm_api.cu:23-84 are in the
+// Host runtime (runtime.hip.h) = what algorithms/cuda/cuda/snarkvm.cu:73-312 (snarkvm_t) and snarkvm_api.cu:23-84 are in the
 // reference: a lazily constructed per-process context (device arenas, streams, twiddle tables), staging of the caller's host
 // buffers, error reporting as RustError, serialisation of concurrent callers.  The G2 entry points live in api_g2.hip.
 #define SV_TU_MSM_G1
-#include "runtime.cuh"
+#include "runtime.hip.h"
 
 context_t g_ctx;
 
@@ -154,7 +154,7 @@ static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points
     *handle = h;
 }
 
-// ---- canonical (de)serialisation of G1 points (serde.cuh) ---------------------------------------
+// ---- canonical (de)serialisation of G1 points (serde.hip.h) ---------------------------------------
 // bytes (host) -> native base slots and / or Rust-layout records (both device); returns the SERDE_* status bits
 static uint32_t g1_deserialize_run(const void* bytes, size_t n, int compressed, int validate, g1_aff_mem_t* d_native, uint8_t* d_rust) {
     const size_t psz = compressed ? 48 : 96;

@@ -2,7 +2,7 @@
 // prover-round polynomial kernels and the setup-time group operations that are built on them.  A separate translation unit so
 // that build.py can compile it next to api.hip (G1 MSM) and api_g2.hip.
 #define SV_TU_NTT
-#include "runtime.cuh"
+#include "runtime.hip.h"
 
 extern "C" {
 
@@ -118,7 +118,7 @@ RustError snarkvm_hip_fr_convert_device(void* d_out, const void* d_in, size_t n,
     API_END
 }
 
-// ---- prover-round polynomial kernels (poly.cuh) ---------------------------------------------------
+// ---- prover-round polynomial kernels (poly.hip.h) ---------------------------------------------------
 static fr_mem_t fr_mem_from_host(const void* p) {
     fr_mem_t m;
     memcpy(&m, p, sizeof m);
@@ -274,7 +274,7 @@ RustError snarkvm_hip_fr_distribute_powers(void* inout, size_t n, const void* g,
     API_END
 }
 
-// TWO_ADIC_ROOT_OF_UNITY (fr.rs:115-120), memory form - the host copy of ntt.cuh's device table
+// TWO_ADIC_ROOT_OF_UNITY (fr.rs:115-120), memory form - the host copy of ntt.hip.h's device table
 static const uint32_t FR_TWO_ADIC_ROOT_MEM_HOST[8] = {0xda3ad648u, 0xaf80da4du, 0xfc381dacu, 0x5e223adbu,
                                                       0xb2f92525u, 0x03ba0666u, 0x3befb0ceu, 0x0f906c5bu};
 RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const void* tau, int on_device) {
@@ -345,7 +345,7 @@ RustError snarkvm_hip_fr_mul_by_vanishing(void* out, const void* poly, size_t le
     API_END
 }
 
-// ---- setup-time group operations (group.cuh) -------------------------------------------------------
+// ---- setup-time group operations (group.hip.h) -------------------------------------------------------
 RustError snarkvm_hip_g1_fixed_base_msm(void* out_projective, const void* g_affine, const void* scalars, size_t n) {
     API_BEGIN
     if (n) {

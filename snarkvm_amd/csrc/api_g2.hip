@@ -1,7 +1,7 @@
 // api_g2.hip - the G2 (Fq2) entry points of the C ABI: the MSM engine, table precomputation and point encoding instantiated
 // over fq2_t.  A separate translation unit only because these instantiations are half of the compile time: build.py compiles
 // both units in parallel.
-#include "runtime.cuh"
+#include "runtime.hip.h"
 
 extern "C" {
 

@@ -1,4 +1,4 @@
-// ec.cuh - short-Weierstrass (a = 0) point arithmetic for the MSM kernels, templated on the base
+// ec.hip.h - short-Weierstrass (a = 0) point arithmetic for the MSM kernels, templated on the base
 // field so that G1 (Fq) and G2 (Fq2) share one implementation.
 //
 // Device-side representations
@@ -13,7 +13,7 @@
 // https://hyperelliptic.org/EFD/g1p/auto-shortw-xyzz.html) is used here.  All exceptional cases of
 // affine.rs:224-273 / projective.rs:222-291 are handled: either operand infinity, P + P, P + (-P).
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace sv {
 

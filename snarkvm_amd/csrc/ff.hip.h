@@ -1,4 +1,4 @@
-// ff.cuh - BLS12-377 prime-field arithmetic for gfx950 (CDNA4).
+// ff.hip.h - BLS12-377 prime-field arithmetic for gfx950 (CDNA4).
 //
 // Representation (chosen from measurements on MI355X, profiles/r01_microbench_instruction_rates.txt):
 // gfx950 has no 64-bit multiplier but v_mad_u64_u32 (32x32+64 -> 64) issues at ~57 % of the plain
@@ -333,7 +333,7 @@ struct Fp {
 
     // ---- lazy arithmetic (NTT butterflies).  Valid only for a field with spare bits in 29N (Fr: 261 - 253 = 8):
     // operands are arbitrary integers < 2^(29N) with normalised limbs, results likewise; nothing is reduced mod p
-    // until reduce_lazy().  Bounds are tracked by the caller (ntt.cuh).
+    // until reduce_lazy().  Bounds are tracked by the caller (ntt.hip.h).
     SV_HD static Fp add_lazy(const Fp& a, const Fp& b) {  // a + b  (must stay < 2^(29N))
         Fp r;
         uint32_t c = 0;
@@ -393,7 +393,7 @@ struct Fp {
     }
     // Montgomery reduction alone: x * 2^(-29N) for any x < 2^(29N) with normalised limbs, result < 2p.  Half the
     // multiply-adds of mul_lazy(one()) (the a*b columns are just the limbs of x); the caller has folded the missing factor
-    // 2^(29N) into an earlier constant (ntt.cuh: closing twiddles of the pass before the last).
+    // 2^(29N) into an earlier constant (ntt.hip.h: closing twiddles of the pass before the last).
     SV_HD Fp mont_reduce_lazy() const {
         uint32_t m[N];
         Fp r;
@@ -480,7 +480,7 @@ static_assert(sizeof(fr_mem_t) == 32 && sizeof(fq_mem_t) == 48, "field element s
 
 // ------------------------------------------------------------------------------------------
 // Fq2 = Fq[u] / (u^2 + 5)   (fields/src/fp2.rs:57-60, curves/src/bls12_377/fq2.rs:58-69: NONRESIDUE = -5)
-// Same interface as Fp so that ec.cuh / msm.cuh work for G2.
+// Same interface as Fp so that ec.hip.h / msm.hip.h work for G2.
 // ------------------------------------------------------------------------------------------
 struct fq2_t {
     fq_t c0, c1;

@@ -1,4 +1,4 @@
-// group.cuh - the two setup-time group operations of SURVEY.md §8f N4, built from the MSM engine's point arithmetic:
+// group.hip.h - the two setup-time group operations of SURVEY.md §8f N4, built from the MSM engine's point arithmetic:
 //
 //   FixedBase::msm (algorithms/src/msm/fixed_base.rs:33-97): out_i = v_i * g for one base g and many scalars, by a window
 //       table of multiples of g (`get_window_table`) and one table lookup + addition per window (`windowed_mul`).
@@ -9,8 +9,8 @@
 //
 // Points travel between kernels as XYZZ records (192 B); the API converts from / to the reference's Jacobian memory image.
 #pragma once
-#include "ec.cuh"
-#include "ff.cuh"
+#include "ec.hip.h"
+#include "ff.hip.h"
 
 namespace sv {
 
@@ -76,7 +76,7 @@ static __global__ void __launch_bounds__(256) g1_fixed_msm_kernel(const g1_aff_m
     uint32_t k[9];
     {
         fr_t c32 = fr_t::zero();
-        c32.v[0] = 32;  // memory Montgomery -> canonical integer (see ntt.cuh fr_to_bigint_kernel)
+        c32.v[0] = 32;  // memory Montgomery -> canonical integer (see ntt.hip.h fr_to_bigint_kernel)
         (fr_t::load(&scalars[i]) * c32).pack(k);
         k[8] = 0;
     }

@@ -1,4 +1,4 @@
-// msm.cuh - Pippenger variable-base MSM over BLS12-377 G1 for gfx950.
+// msm.hip.h - Pippenger variable-base MSM over BLS12-377 G1 for gfx950.
 //
 // Replaces (behaviour, not code): sppark's msm_t::invoke as called from
 // algorithms/cuda/cuda/snarkvm.cu:249-311, and the CPU algorithms VariableBase::msm /
@@ -27,7 +27,7 @@
 #pragma once
 #include <stdlib.h>
 
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace sv {
 
@@ -60,6 +60,7 @@ static inline int msm_pick_c(size_t n) {
 // c > 16 ("wide" windows, one bucket window per table: c == part) needs J * c >= 254 and runs the three-level sort and the
 // two-axis bucket fold; it pays when every bucket still receives tens of points (J * n >> 2^(c-1)).
 static constexpr int MSM_C_MAX = 23;
+static constexpr int MSM_BIAS_BITS = 288;  // digit rows * window bits never exceed this (bias[10] = 320 bits, one word of headroom for the carry)
 static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables = 1, int table_bits = 0) {
     msm_plan_t p;
     p.n = n;
@@ -132,6 +133,7 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     for (int i = 0; i < 10; i++) p.bias[i] = 0;
     for (int w = 0; w < p.Wd; w++) {
         int bit = p.c - 1 + p.c * w;
+        if (bit >= MSM_BIAS_BITS) break;  // unreachable for geometries check_tables() admits; never write past bias[]
         p.bias[bit / 32] |= 1u << (bit % 32);  // bits are distinct: no carries while building the constant
     }
     return p;
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict
             const uint4 lo = stage[2 * threadIdx.x], hi = stage[2 * threadIdx.x + 1];
             uint32_t s[11] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u, 0u, 0u};
             if (p.montgomery) {
-                // a*2^256 read as internal a*2^-5 (see ff.cuh): one Montgomery product by the integer 2^5 gives a
+                // a*2^256 read as internal a*2^-5 (see ff.hip.h): one Montgomery product by the integer 2^5 gives a
                 fr_t c32 = fr_t::zero();
                 c32.v[0] = 32;
                 (fr_t::unpack(s) * c32).pack(s);
@@ -269,172 +271,6 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint4* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// 2./4. histogram and scatter, one workgroup per (chunk, window); LDS holds nb counters
-// ------------------------------------------------------------------------------------------
-struct msm_sort_params_t {
-    size_t n;
-    uint32_t chunk, nchunks, nb;
-    int c;
-    int W, J;  // bucket windows and base tables: digit row j*W + w feeds window w with base table j
-};
-// Visit the digits of scalars [lo, hi) of one window; 8 digits per 16-byte load when the rows are 16-byte aligned.
-template <class Fn>
-__device__ __forceinline__ void for_each_digit(const uint16_t* __restrict__ d, size_t n, size_t lo, size_t hi, Fn fn) {
-    if ((n & 7) == 0 && (lo & 7) == 0 && ((hi - lo) & 7) == 0) {
-        const uint4* d4 = (const uint4*)(d + lo);
-        const size_t nvec = (hi - lo) >> 3;
-        for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
-            const uint4 q = d4[v];
-            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-            const size_t i = lo + (v << 3);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                fn(wds[k] & 0xffffu, i + 2 * k);
-                fn(wds[k] >> 16, i + 2 * k + 1);
-            }
-        }
-    } else {
-        for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) fn((uint32_t)d[i], i);
-    }
-}
-// counts[w][chunk][b] (contiguous per workgroup: no write amplification)
-static __global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts,
-                                                        msm_sort_params_t p) {
-    extern __shared__ uint32_t hist[];
-    const uint32_t chunk = blockIdx.x, w = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const size_t lo = (size_t)chunk * p.chunk;
-    const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
-    const int half = 1 << (p.c - 1);
-    for (int j = 0; j < p.J; j++)
-        for_each_digit(digits + (size_t)(j * p.W + w) * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
-            const int v = (int)u - half;
-            if (v != 0) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
-        });
-    __syncthreads();
-    uint32_t* dst = counts + ((size_t)w * p.nchunks + chunk) * p.nb;
-    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) dst[b] = hist[b];
-}
-// Per bucket k = (w, b): turn the per-chunk counts into ranks (exclusive prefix over chunks, in place) and the
-// bucket size.  Threads adjacent in b -> coalesced.
-static __global__ void msm_bucket_rank_kernel(uint32_t* __restrict__ counts_to_rank, uint32_t* __restrict__ size, uint32_t nb,
-                                       uint32_t nchunks, uint32_t nbt, uint32_t* __restrict__ max_size) {
-    __shared__ uint32_t blk_max;
-    if (threadIdx.x == 0) blk_max = 0;
-    __syncthreads();
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t run = 0;
-    if (k < nbt) {
-        const uint32_t w = k / nb, b = k - w * nb;
-        for (uint32_t ch = 0; ch < nchunks; ch++) {
-            const size_t idx = ((size_t)w * nchunks + ch) * nb + b;
-            const uint32_t c = counts_to_rank[idx];
-            counts_to_rank[idx] = run;
-            run += c;
-        }
-    }
-    if (k <= nbt) size[k] = run;
-    // the host sizes the number of reduce rounds from the largest bucket: one global atomic per block
-    if (run) atomicMax(&blk_max, run);
-    __syncthreads();
-    if (threadIdx.x == 0 && blk_max) atomicMax(max_size, blk_max);
-}
-// Scatter into the workgroup's PRIVATE region sorted[(w*nchunks + chunk)*chunk ...], grouped by bucket:
-// all partial-line writes of a region come from one workgroup, so they merge in its L2 (the bucket-major layout
-// measured 8x write amplification, profiles/r01_rocprofv3_pmc_hbm_bytes.txt).  loc_off[w][chunk][b] = offset of
-// bucket b inside the region.
-static __global__ void __launch_bounds__(1024) msm_locoff_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ size,
-                                                          uint32_t* __restrict__ loc_off, msm_sort_params_t p) {
-    extern __shared__ uint32_t cursor[];  // nb counters followed by 1024 scan slots
-    uint32_t* part = cursor + p.nb;
-    const uint32_t chunk = blockIdx.x, w = blockIdx.y;
-    const size_t row = ((size_t)w * p.nchunks + chunk) * p.nb;
-    // this chunk's count per bucket = next rank - rank
-    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) {
-        const uint32_t nxt = (chunk + 1 < p.nchunks) ? rank[row + p.nb + b] : size[(size_t)w * p.nb + b];
-        cursor[b] = nxt - rank[row + b];
-    }
-    __syncthreads();
-    // exclusive scan over the nb counters: per-thread segments + Hillis-Steele over the 1024 segment sums
-    const uint32_t seg = (p.nb + blockDim.x - 1) / blockDim.x;
-    const uint32_t b0 = threadIdx.x * seg;
-    uint32_t s = 0;
-    for (uint32_t b = b0; b < b0 + seg && b < p.nb; b++) s += cursor[b];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
-        const uint32_t t = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t b = b0; b < b0 + seg && b < p.nb; b++) {
-        const uint32_t c = cursor[b];
-        cursor[b] = run;
-        run += c;
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < p.nb; b += blockDim.x) loc_off[row + b] = cursor[b];
-}
-// One workgroup per (chunk, window, bucket-range pass).  A pass covers nb / npass consecutive buckets, i.e. a
-// contiguous 1/npass slice of the (chunk, window) region.  rocprofv3 WRITE_SIZE shows 8.7 GB written for 1 GiB of
-// entries (every 4-byte store leaves the write-through L2 as its own 32-byte sector write); splitting the bucket
-// range into passes was tried to let the stores merge in L2 and does not help beyond 2 passes (1: 4.13 ms, 2: 3.92,
-// 4: 5.21, 8: 4.94 at 2^24) - the real fix is an LDS-staged two-level radix partition (known weak spots).
-static __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits,
-                                                           const uint32_t* __restrict__ loc_off, uint32_t* __restrict__ sorted,
-                                                           msm_sort_params_t p, uint32_t npass) {
-    extern __shared__ uint32_t cursor[];  // nb / npass cursors
-    const uint32_t chunk = blockIdx.x, w = blockIdx.y, pass = blockIdx.z;
-    const size_t row = ((size_t)w * p.nchunks + chunk) * p.nb;
-    const uint32_t nbp = p.nb / npass, blo = pass * nbp;
-    for (uint32_t b = threadIdx.x; b < nbp; b += blockDim.x) cursor[b] = loc_off[row + blo + b];
-    __syncthreads();
-    const size_t lo = (size_t)chunk * p.chunk;
-    const size_t hi = (lo + p.chunk < p.n) ? lo + p.chunk : p.n;
-    const int half = 1 << (p.c - 1);
-    uint32_t* region = sorted + ((size_t)w * p.nchunks + chunk) * p.chunk * p.J;
-    const bool vec = (p.n & 7) == 0 && (lo & 7) == 0 && ((hi - lo) & 7) == 0;
-    for (int j = 0; j < p.J; j++) {
-        const uint32_t voff = (uint32_t)((size_t)j * p.n);  // virtual index = table * n + scalar index
-        const uint16_t* d = digits + (size_t)(j * p.W + w) * p.n;
-        if (vec) {
-            // 8 digits per 16-byte load; all 8 LDS cursor atomics are issued before the first dependent store
-            const uint4* d4 = (const uint4*)(d + lo);
-            const size_t nvec = (hi - lo) >> 3;
-            for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
-                const uint4 q = d4[v];
-                const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-                const uint32_t i0 = (uint32_t)(lo + (v << 3));
-                uint32_t pos[8], val[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const uint32_t u = (k & 1) ? (wds[k >> 1] >> 16) : (wds[k >> 1] & 0xffffu);
-                    const int dv = (int)u - half;
-                    val[k] = (voff + i0 + k) | (dv < 0 ? 0x80000000u : 0u);
-                    const uint32_t bl = (uint32_t)((dv < 0 ? -dv : dv) - 1) - blo;  // digit 0 wraps to a huge value
-                    pos[k] = bl < nbp ? atomicAdd(&cursor[bl], 1u) : 0xffffffffu;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (pos[k] != 0xffffffffu) region[pos[k]] = val[k];
-            }
-        } else {
-            for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-                const int dv = (int)d[i] - half;
-                const uint32_t bl = (uint32_t)((dv < 0 ? -dv : dv) - 1) - blo;
-                if (bl < nbp) {
-                    const uint32_t pos = atomicAdd(&cursor[bl], 1u);
-                    region[pos] = (voff + (uint32_t)i) | (dv < 0 ? 0x80000000u : 0u);
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // 5./6. accumulate + reduce rounds
 // ------------------------------------------------------------------------------------------
 // cnt_out[k] = ceil(cnt_in[k] / S)   (level 0: cnt_in = bucket sizes)
@@ -454,84 +290,6 @@ __device__ __forceinline__ uint32_t find_bucket(const uint32_t* start, uint32_t 
             hi = mid;
     }
     return lo;
-}
-// MINW = minimum waves per SIMD requested from the register allocator (G1: 4 -> <= 128 VGPRs with a few
-// spills vs 3 -> 165 VGPRs; one wave alone issues only every ~5 ticks, see profiles/r01_microbench_*).
-template <class F, int MINW>
-__global__ void __launch_bounds__(256, MINW) msm_accumulate_kernel(const aff_mem_t<F>* __restrict__ bases,
-                                                                   const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
-                                                                   const uint32_t* __restrict__ sorted,
-                                                                   const uint32_t* __restrict__ rank,
-                                                                   const uint32_t* __restrict__ loc_off,
-                                                                   const uint32_t* __restrict__ size,
-                                                                   const uint32_t* __restrict__ start,
-                                                                   xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S,
-                                                                   uint32_t nb, uint32_t nchunks, uint32_t chunk, uint32_t n,
-                                                                   size_t table_stride, uint32_t debug_idx_mask) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= start[nbt]) return;
-    const uint32_t k = find_bucket(start, nbt, t);
-    const uint32_t j = t - start[k];
-    const uint32_t w = k / nb, b = k - w * nb;
-    const size_t chunk_stride = chunk;  // entries reserved per (window, chunk) region (chunk * tables)
-    const uint32_t sz = size[k];
-    uint32_t r = j * S;  // rank range [r, r1) inside bucket k
-    uint32_t r1 = r + S;
-    if (r1 > sz) r1 = sz;
-    // the bucket's entries live in nchunks runs: run ch covers ranks [rank[w][ch][b], rank[w][ch+1][b])
-    const size_t col = (size_t)w * nchunks * nb + b;
-    uint32_t lo = 0, hi = nchunks;  // largest ch with rank(ch) <= r
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (rank[col + (size_t)mid * nb] <= r)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    uint32_t ch = lo;
-    uint32_t re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
-    size_t phys = ((size_t)w * nchunks + ch) * chunk_stride + loc_off[col + (size_t)ch * nb] + (r - rank[col + (size_t)ch * nb]);
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    // next sorted entry + the raw image of its base (software prefetch: the gather of point k+1 is in flight while
-    // point k is being added; MINW == 2 selects this variant)
-    auto fetch = [&](uint32_t& e_out, aff_mem_t<F>& raw) {
-        while (r == re) {  // run exhausted: next non-empty run (ranks are contiguous across runs)
-            ch++;
-            re = (ch + 1 < nchunks) ? rank[col + (size_t)(ch + 1) * nb] : sz;
-            phys = ((size_t)w * nchunks + ch) * chunk_stride + loc_off[col + (size_t)ch * nb];
-        }
-        const uint32_t e = sorted[phys++];
-        r++;
-        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
-        const uint32_t tbl = v / n;
-        uint32_t idx = v - tbl * n;          // bases come in up to two segments
-        idx &= debug_idx_mask;               // all ones; narrowed only by the gather-locality experiment
-        raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
-        e_out = e;
-    };
-    if (MINW == 2) {
-        if (r < r1) {
-            uint32_t e_cur, e_nxt = 0;
-            aff_mem_t<F> raw_cur, raw_nxt;
-            fetch(e_cur, raw_cur);
-            while (true) {
-                const bool more = r < r1;
-                if (more) fetch(e_nxt, raw_nxt);
-                acc.add_affine(load_aff<F>(&raw_cur), (e_cur >> 31) != 0);
-                if (!more) break;
-                e_cur = e_nxt;
-                raw_cur = raw_nxt;
-            }
-        }
-    } else {
-        while (r < r1) {
-            uint32_t e;
-            aff_mem_t<F> raw;
-            fetch(e, raw);
-            acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
-        }
-    }
-    store_xyzz<F>(&partial[t], acc);
 }
 template <class F>
 __global__ void __launch_bounds__(256) msm_reduce_kernel(const xyzz_mem_t<F>* __restrict__ in,
@@ -603,54 +361,8 @@ __global__ void __launch_bounds__(256) msm_window_sum_kernel(const xyzz_mem_t<F>
 //     so 2 additions per bucket, all independent, replace the long running sums; what is left are two small "windows" of
 //     2^m entries (L at index lo, weight lo + 1; H_hi at index hi - 1, weight hi) combined by the regular tail with c = m.
 //     Workgroups [0, 2^m) fold columns (fixed lo), workgroups [2^m, 2^m + 2^hb) fold rows (fixed hi).
-template <class F>
-__global__ void __launch_bounds__(256) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
-                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out_sums,
-                                                       uint32_t* __restrict__ out_start, uint32_t* __restrict__ out_cnt, int m, int hb) {
-    extern __shared__ uint4 sh_raw[];
-    xyzz_mem_t<F>* sh = (xyzz_mem_t<F>*)sh_raw;
-    const uint32_t nlo = 1u << m, nhi = 1u << hb;
-    const bool column = blockIdx.x < nlo;
-    const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
-    const uint32_t slot = column ? fixed : nlo + fixed - 1;  // H_0 has weight 0 and no slot
-    if (!column && fixed == 0) {
-        if (threadIdx.x == 0) {  // the one unused slot at the top of window 1
-            out_start[2 * nlo - 1] = 2 * nlo - 1;
-            out_cnt[2 * nlo - 1] = 0;
-        }
-        return;
-    }
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    const uint32_t cntv = column ? nhi : nlo;
-    for (uint32_t i = threadIdx.x; i < cntv; i += blockDim.x) {
-        const uint32_t k = column ? (i << m) + fixed : (fixed << m) + i;
-        for (uint32_t q = 0; q < cnt[k]; q++) acc.add(load_xyzz<F>(&sums[start[k] + q]));
-    }
-    store_xyzz<F>(&sh[threadIdx.x], acc);
-    __syncthreads();
-    for (int off = (int)blockDim.x / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            xyzz_t<F> a = load_xyzz<F>(&sh[threadIdx.x]);
-            a.add(load_xyzz<F>(&sh[threadIdx.x + off]));
-            store_xyzz<F>(&sh[threadIdx.x], a);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out_sums[slot] = sh[0];
-        out_start[slot] = slot;
-        out_cnt[slot] = 1;
-        if (!column && nhi < nlo + 1 && fixed == nhi - 1)  // slots of window 1 beyond the last H stay empty
-            for (uint32_t s2 = nlo + nhi - 1; s2 < 2 * nlo - 1; s2++) {
-                out_start[s2] = s2;
-                out_cnt[s2] = 0;
-            }
-    }
-}
-// The same fold with ONE wave per output and a shuffle butterfly instead of the LDS tree: a 256-thread workgroup spends as
-// long in its 8 tree levels (half the lanes idle, a barrier each) as in its 8 serial additions; a single wave does 16-32
-// serial additions per lane and 6 all-lane exchange levels, needs no LDS, and ~3 of them fit a SIMD (1.79 -> ~0.8 ms at 2^21
-// buckets).
+// ONE wave per output and a shuffle butterfly (a 256-thread LDS tree spent as long in its 8 levels - half the lanes idle, a
+// barrier each - as in its serial additions): 16-32 serial additions per lane, then 6 all-lane exchange levels.
 __device__ __forceinline__ fq_t shfl_xor_field(const fq_t& a, int mask) {
     fq_t r;
 #pragma unroll

@@ -1,4 +1,4 @@
-// msm_sort.cuh - bucket sort of the MSM digit matrix by a multi-level, LDS-staged radix partition.
+// msm_sort.hip.h - bucket sort of the MSM digit matrix by a multi-level, LDS-staged radix partition.
 //
 // Why: the first sort scattered 4-byte entries with per-bucket cursors straight into HBM.  On MI355X the L2 is
 // write-through for such stores, so every entry left the chip as its own 32-byte sector: rocprofv3 WRITE_SIZE showed
@@ -16,7 +16,7 @@
 // Each level is histogram -> exclusive scan -> staged scatter; all positions are deterministic functions of the
 // histograms except the order inside a (tile, bin) run (LDS cursor order), which does not change any bucket's content.
 #pragma once
-#include "msm.cuh"
+#include "msm.hip.h"
 
 namespace sv {
 
@@ -351,32 +351,6 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
         sorted[dst] = sv_[pos];
         if (rem_out) rem_out[dst] = srem_[pos];
     }
-}
-
-// ---- accumulate over bucket-major entries: bucket k owns sorted[boff[k], boff[k+1])
-template <class F>
-__global__ void __launch_bounds__(256) msm_accumulate_bm_kernel(const aff_mem_t<F>* __restrict__ bases,
-                                                                const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
-                                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
-                                                                const uint32_t* __restrict__ start, xyzz_mem_t<F>* __restrict__ partial,
-                                                                uint32_t nbt, uint32_t S, uint32_t n, size_t table_stride) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= start[nbt]) return;
-    const uint32_t k = find_bucket(start, nbt, t);
-    const uint32_t j = t - start[k];
-    const uint32_t lo = boff[k] + j * S;
-    uint32_t hi = lo + S;
-    if (hi > boff[k + 1]) hi = boff[k + 1];
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    for (uint32_t pos = lo; pos < hi; pos++) {
-        const uint32_t e = sorted[pos];
-        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
-        const uint32_t tbl = v / n;
-        const uint32_t idx = v - tbl * n;    // bases come in up to two segments
-        const aff_mem_t<F> raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
-        acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
-    }
-    store_xyzz<F>(&partial[t], acc);
 }
 
 // ---- balanced ("segmented") accumulate: thread t owns the S consecutive entries sorted[tS, (t+1)S) whatever buckets they

@@ -1,7 +1,7 @@
-// ntt.cuh - radix-2 NTT / iNTT over BLS12-377 Fr for gfx950.
+// ntt.hip.h - radix-2 NTT / iNTT over BLS12-377 Fr for gfx950.
 //
 // Replaces (behaviour, not code): sppark's NTT::Base / NTT_internal / bit_rev as called from
-// algorithms/cuda/cuda/snarkvm.cu:154-186 and polynomial.cuh:104-266, and the CPU transforms of
+// algorithms/cuda/cuda/snarkvm.cu:154-186 and polynomial.hip.h:104-266, and the CPU transforms of
 // algorithms/src/fft/domain.rs:374-443 (in_order_fft / ifft / coset_ifft), :691-773 (io/oi helpers).
 //
 // Structure (MI355X-first): a 2^lg transform is split into at most three passes of radix <= 2^8
@@ -17,10 +17,10 @@
 // passes * 2 * 32 * n bytes (algorithmic minimum 2 * 32 * n: SURVEY.md 8d).  Twiddles are never
 // streamed from HBM: per-stage twiddles come from a 128-entry table of w_256 powers staged in LDS.
 //
-// Data stays in the reference's memory form (Montgomery, R = 2^256) throughout; see ff.cuh for why the
+// Data stays in the reference's memory form (Montgomery, R = 2^256) throughout; see ff.hip.h for why the
 // 29-bit-limb arithmetic needs no conversion on this (linear) path.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace sv {
 
@@ -110,142 +110,12 @@ __device__ __forceinline__ fr_t tw_lookup(const fr_mem_t* lo, const fr_mem_t* hi
     return a * fr_t::load(&hi[h]);
 }
 
-// LDS tile: element e = rho * T + col, stored as two 16-byte planes (conflict-free b128 accesses).
-static __global__ void __launch_bounds__(512) ntt_pass_kernel(ntt_pass_t p, ntt_tables_t tb) {
-    extern __shared__ uint4 lds[];
-    const int R = 1 << p.a, T = 1 << p.lgT, E = R << p.lgT;
-    uint4* lo_plane = lds;
-    uint4* hi_plane = lds + E;
-    uint4* tw_plane = lds + 2 * E;  // 128 local twiddles, 2 x uint4 each
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const size_t tile = blockIdx.x;
-
-    // ---- addressing
-    size_t in_base, in_rho_stride, in_col_stride;
-    size_t inner0 = 0;
-    size_t d1_0 = 0, mid = 0;
-    if (!p.last) {
-        const size_t tiles_per_outer = (size_t)1 << (p.s - p.lgT);
-        const size_t outer = tile / tiles_per_outer;
-        inner0 = (tile % tiles_per_outer) << p.lgT;
-        in_base = (outer << (p.a + p.s)) + inner0;
-        in_rho_stride = (size_t)1 << p.s;
-        in_col_stride = 1;
-    } else {
-        const size_t tiles_per_mid = (size_t)1 << (p.a1 - p.lgT);
-        mid = tile / tiles_per_mid;
-        d1_0 = (tile % tiles_per_mid) << p.lgT;
-        in_base = (d1_0 << (p.lg_n - p.a1)) + (mid << p.a);
-        in_rho_stride = 1;
-        in_col_stride = (size_t)1 << (p.lg_n - p.a1);
-    }
-
-    // ---- load (and optional coset pre-scale by g^j, j = natural input index)
-    for (int i = tid; i < 128; i += nthr) {
-        const uint4* src = (const uint4*)&tb.local[p.dir][i];
-        tw_plane[2 * i] = src[0];
-        tw_plane[2 * i + 1] = src[1];
-    }
-    for (int e = tid; e < E; e += nthr) {
-        int rho, col;
-        if (!p.last) {
-            rho = e >> p.lgT;
-            col = e & (T - 1);
-        } else {
-            col = e >> p.a;
-            rho = e & (R - 1);
-        }
-        const size_t g = in_base + rho * in_rho_stride + col * in_col_stride;
-        const uint4* src = (const uint4*)&p.in[g];
-        uint4 x0 = src[0], x1 = src[1];
-        if (p.coset_pre) {
-            uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            fr_t x = fr_t::unpack(w) * tw_lookup(tb.g_lo[0], tb.g_hi[0], (uint32_t)g);
-            x.pack(w);
-            x0 = make_uint4(w[0], w[1], w[2], w[3]);
-            x1 = make_uint4(w[4], w[5], w[6], w[7]);
-        }
-        const int le = rho * T + col;
-        lo_plane[le] = x0;
-        hi_plane[le] = x1;
-    }
-    __syncthreads();
-
-    // ---- a radix-2 DIF stages: (u, v) <- (u + v, (u - v) * w_R^(pos << st))
-    const int nb = E >> 1;
-    for (int st = 0; st < p.a; st++) {
-        const int lg_half = p.a - 1 - st;
-        for (int b = tid; b < nb; b += nthr) {
-            const int col = b & (T - 1);
-            const int q = b >> p.lgT;
-            const int pos = q & ((1 << lg_half) - 1);
-            const int i0 = ((q >> lg_half) << (lg_half + 1)) + pos;
-            const int e0 = i0 * T + col, e1 = e0 + (T << lg_half);
-            uint4 a0 = lo_plane[e0], a1 = hi_plane[e0], b0 = lo_plane[e1], b1 = hi_plane[e1];
-            uint32_t wu[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            uint32_t wv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            fr_t u = fr_t::unpack(wu), v = fr_t::unpack(wv);
-            fr_t sum = u + v, dif = u - v;
-            const int tw_idx = (pos << st) << (NTT_MAX_RADIX_LG - p.a);  // index into w_256 powers
-            if (tw_idx != 0) {
-                uint4 t0 = tw_plane[2 * tw_idx], t1 = tw_plane[2 * tw_idx + 1];
-                uint32_t ww[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                dif = dif * fr_t::unpack(ww);
-            }
-            sum.pack(wu);
-            dif.pack(wv);
-            lo_plane[e0] = make_uint4(wu[0], wu[1], wu[2], wu[3]);
-            hi_plane[e0] = make_uint4(wu[4], wu[5], wu[6], wu[7]);
-            lo_plane[e1] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-            hi_plane[e1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
-        }
-        __syncthreads();
-    }
-
-    // ---- store: row rho holds output digit k = bitrev_a(rho)
-    for (int e = tid; e < E; e += nthr) {
-        const int rho = e >> p.lgT, col = e & (T - 1);
-        const uint32_t k = bitrev32((uint32_t)rho, p.a);
-        uint4 x0 = lo_plane[e], x1 = hi_plane[e];
-        size_t g;
-        bool need_mul = false;
-        fr_t f;
-        if (!p.last) {
-            g = in_base + ((size_t)k << p.s) + col;
-            const uint32_t expo = (uint32_t)(((inner0 + col) * (size_t)k) << p.tw_shift);
-            if (expo != 0) {
-                f = tw_lookup(tb.pow_lo[p.dir], tb.pow_hi[p.dir], expo);
-                need_mul = true;
-            }
-        } else {
-            g = (d1_0 + col) + (((size_t)mid + ((size_t)k << p.lg_mid)) << p.a1);
-            if (p.scale_post == 1) {
-                f = fr_t::load(&tb.size_inv[p.lg_n]);
-                need_mul = true;
-            } else if (p.scale_post == 2) {
-                f = tw_lookup(tb.g_lo[1], tb.g_hi[1], (uint32_t)g) * fr_t::load(&tb.size_inv[p.lg_n]);
-                need_mul = true;
-            }
-        }
-        if (need_mul) {
-            uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            fr_t x = fr_t::unpack(w) * f;
-            x.pack(w);
-            x0 = make_uint4(w[0], w[1], w[2], w[3]);
-            x1 = make_uint4(w[4], w[5], w[6], w[7]);
-        }
-        uint4* dst = (uint4*)&p.out[g];
-        dst[0] = x0;
-        dst[1] = x1;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // v2 pass kernel: radix-4 butterflies in registers + lazy reduction.
 //   * two DIF stages per LDS round trip (a = 8: 4 groups, 3 round trips instead of 8), the first group reads
 //     straight from global memory and the last one writes straight back;
 //   * the tile lives in LDS as 29-bit limbs, 9 consecutive words per element (no pack / unpack between stages);
-//   * butterflies use lazy arithmetic (ff.cuh): sums are only carry-normalised, differences add 2^s * r, products
+//   * butterflies use lazy arithmetic (ff.hip.h): sums are only carry-normalised, differences add 2^s * r, products
 //     skip the conditional subtraction.  Bound: entering local stage s every value is < 2^s * r (inputs canonical),
 //     so after a <= 8 stages values are < 256 r < 2^261 (9 limbs).  The closing multiplication (inter-pass twiddle,
 //     1/n scaling, or the constant one) brings the value below 2r and one conditional subtraction makes it
@@ -444,7 +314,7 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, n
     }
 }
 
-// out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.cuh:128,189; domain.rs:797-804 derange)
+// out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.hip.h:128,189; domain.rs:797-804 derange)
 static __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= ((size_t)1 << lg_n)) return;
@@ -454,8 +324,8 @@ static __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int 
     d[0] = s[0];
     d[1] = s[1];
 }
-// polynomial_inner_multiply (polynomial.cuh:36-45): out[i] = a[i] * b[i] (memory Montgomery form, R = 2^256).
-// mont261(x, y) = x y 2^-261 = (a b 2^256) 2^-5, so `fix` = 2^(5 + 261) mod r restores the form (see ff.cuh);
+// polynomial_inner_multiply (polynomial.hip.h:36-45): out[i] = a[i] * b[i] (memory Montgomery form, R = 2^256).
+// mont261(x, y) = x y 2^-261 = (a b 2^256) 2^-5, so `fix` = 2^(5 + 261) mod r restores the form (see ff.hip.h);
 // with fix_later the factor is left for the caller to fold into a later constant.
 static __global__ void fr_pointwise_mul_kernel(fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, size_t n, int fix_now) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -568,14 +438,7 @@ static inline const fr_mem_t* ntt_get_full_tw(hipStream_t st, const ntt_tables_t
 static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb) {
     const size_t E = (size_t)1 << (p.a + p.lgT);
     const size_t ntiles = ((size_t)1 << p.lg_n) / E;
-    static const int use_v1 = getenv("SNARKVM_HIP_NTT_V1") ? atoi(getenv("SNARKVM_HIP_NTT_V1")) : 0;
-    if (use_v1) {
-        int threads = (int)(E / 2);
-        if (threads < 64) threads = 64;
-        if (threads > 512) threads = 512;
-        const size_t shmem = (2 * E + 256) * sizeof(uint4);
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
-    } else {
+    {
         int threads = (int)(E / 4);  // one radix-4 group per thread
         if (threads < 64) threads = 64;
         if (threads > 512) threads = 512;
@@ -612,8 +475,7 @@ static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* 
             p.s = lg - consumed - p.a;
             p.lgT = p.s < 3 ? p.s : 3;
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
-            static const int use_v1_kernel = getenv("SNARKVM_HIP_NTT_V1") ? atoi(getenv("SNARKVM_HIP_NTT_V1")) : 0;
-            const bool prelast = (k == pl.npass - 2) && !use_v1_kernel;
+            const bool prelast = (k == pl.npass - 2);
             bool f = false;
             p.tw_full = ntt_get_full_tw(st, tb, p.a, p.s, p.tw_shift, dir, prelast ? lg : 0, &f);
             folded = f;

@@ -1,4 +1,4 @@
-// poly.cuh - the prover-round Fr vector kernels that sit between the NTTs and the MSMs (SURVEY.md §8 N2 and the
+// poly.hip.h - the prover-round Fr vector kernels that sit between the NTTs and the MSMs (SURVEY.md §8 N2 and the
 // `open` half of row a15).  All of them are O(n) streaming passes over 32-byte Fr elements in the reference's memory
 // form (a * 2^256 mod r), so that data produced by an NTT can feed a commitment without leaving HBM:
 //
@@ -10,12 +10,12 @@
 //   fr_fold_vanishing_kernel    quotient / remainder by X^D - 1                  dense.rs:161-169 (divide_by_vanishing_poly)
 //   fr_mul_vanishing_kernel     p * (X^D - 1)                                    dense.rs:153-159
 //
-// Representation note (ff.cuh): the raw memory limbs of a, read as an internal value, are the internal Montgomery form of
+// Representation note (ff.hip.h): the raw memory limbs of a, read as an internal value, are the internal Montgomery form of
 // a * 2^-5 ("shifted").  Sums and differences of shifted values are shifted values; the product of a TRUE internal
 // value (x.from_mem_mont()) with a shifted value is the shifted product.  So a kernel converts only its broadcast
 // operand (z, g, c, coeff) and streams the vectors untouched; only a product of two vector elements needs one fix-up.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace sv {
 

@@ -1,5 +1,5 @@
 #pragma once
-// runtime.cuh - host runtime shared by the translation units of the backend (api.hip: G1 / Fr entry points, api_g2.hip: the Fq2
+// runtime.hip.h - host runtime shared by the translation units of the backend (api.hip: G1 / Fr entry points, api_g2.hip: the Fq2
 // instantiations, compiled in parallel by snarkvm_amd/build.py).  Everything here is header-only (static / inline / templates)
 // except the one context object, which api.hip defines.
 //
@@ -18,14 +18,14 @@
 #include <vector>
 
 #include "../../include/snarkvm_hip.h"
-#include "ec.cuh"
-#include "ff.cuh"
-#include "msm.cuh"
-#include "msm_sort.cuh"
-#include "ntt.cuh"
-#include "group.cuh"
-#include "poly.cuh"
-#include "serde.cuh"
+#include "ec.hip.h"
+#include "ff.hip.h"
+#include "msm.hip.h"
+#include "msm_sort.hip.h"
+#include "ntt.hip.h"
+#include "group.hip.h"
+#include "poly.hip.h"
+#include "serde.hip.h"
 
 using namespace sv;
 
@@ -78,7 +78,7 @@ struct dev_buf {
 struct msm_ws_t {
     hipStream_t stream = nullptr;
     dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, contrib, wsum, result;
-    dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.cuh)
+    dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
     dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
     dev_buf fold_sums, fold_idx;                                              // two-axis bucket fold (wide windows)
 };
@@ -98,8 +98,8 @@ struct context_t {
     dev_buf tables_mem;
     // NTT staging
     dev_buf ntt_data, ntt_scratch, ntt_acc;
-    dev_buf serde_status;  // one u32 of SERDE_* bits (serde.cuh)
-    dev_buf poly[5];  // staging / scratch of the prover-round vector kernels (poly.cuh)
+    dev_buf serde_status;  // one u32 of SERDE_* bits (serde.hip.h)
+    dev_buf poly[5];  // staging / scratch of the prover-round vector kernels (poly.hip.h)
     // MSM workspaces: lane 0 runs on the main stream; lanes 1.. are used by the batch API so that the latency-bound
     // tail of one MSM (bucket reduction, Horner) overlaps the throughput-bound accumulation of the next
     static constexpr int LANES = 8;  // streams + workspaces available to the batch API
@@ -279,11 +279,9 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
             hipLaunchKernelGGL((msm_digits_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
     }
     phase_end();
-    static const int sort_mode = getenv("SNARKVM_HIP_SORT") ? atoi(getenv("SNARKVM_HIP_SORT")) : 1;  // 1 = radix partition, 0 = chunk-major
     int rounds = 0;
-    constexpr bool LEGACY = sizeof(typename F::mem_t) == 48;  // the A/B paths kept from earlier in the round exist for G1 only
-    if (sort_mode == 1 || wide || !LEGACY) {
-        // ---- 2.-4. LDS-staged radix partition (msm_sort.cuh) -> bucket-major `sorted` + boff; two levels, three when wide
+    {
+        // ---- 2.-4. LDS-staged radix partition (msm_sort.hip.h) -> bucket-major `sorted` + boff; two levels, three when wide
         msm_radix_params_t rp;
         rp.n = n;
         rp.c = pl.c;
@@ -387,13 +385,12 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
                            c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
                            (uint8_t*)nullptr, nseg, LBL, 0);
         phase_end();
-        static const int seg_mode = getenv("SNARKVM_HIP_SEG") ? atoi(getenv("SNARKVM_HIP_SEG")) : 1;  // 1 = balanced segments (default)
         uint32_t max_bucket = 0;  // the number of reduce rounds follows the largest bucket (4-byte read-back)
         HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         // ---- 5. accumulate
         phase_begin("msm_accumulate");
-        if (seg_mode || !LEGACY) {
+        {
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
             // (the tail kernels add up to TAIL_PARTIALS leftover partials per bucket themselves: one reduce round less)
             static const size_t tail_partials = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 4;
@@ -407,71 +404,8 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
             hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
                                d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
                                c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
-        } else if constexpr (LEGACY) {
-            for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
-            hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
-            exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-            hipLaunchKernelGGL((msm_accumulate_bm_kernel<F>), dim3((unsigned)((T0_max + 255) / 256)), dim3(256), 0, st, d_bases,
-                               d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                               c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride);
         }
         phase_end();
-    } else if constexpr (LEGACY) {
-    // 2.-4. counting sort by (window, bucket), chunk-major layout
-    {
-        const size_t ncounts = (size_t)nbt * pl.nchunks;
-        c.counts.ensure(ncounts * 4);
-        c.offsets.ensure(ncounts * 4);
-        c.scan_tmp.ensure((scan_tmp_elems(ncounts > nbt + 1 ? ncounts : nbt + 1)) * 4);
-        c.sorted.ensure((size_t)pl.W * pl.nchunks * pl.chunk * pl.J * 4);
-    }
-    msm_sort_params_t sp;
-    sp.n = n;
-    sp.chunk = pl.chunk;
-    sp.nchunks = pl.nchunks;
-    sp.nb = pl.nb;
-    sp.c = pl.c;
-    sp.W = pl.W;
-    sp.J = pl.J;
-    const size_t lds = (size_t)pl.nb * 4;
-    uint32_t* rank = c.counts.as<uint32_t>();      // counts, turned into ranks in place
-    uint32_t* loc_off = c.offsets.as<uint32_t>();  // offset of each bucket inside its (window, chunk) region
-    uint32_t* bsize = c.boff.as<uint32_t>();       // bucket sizes
-    phase_begin("msm_histogram");
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds, st, c.digits.as<uint16_t>(), rank, sp);
-    phase_end();
-    phase_begin("msm_bucket_rank");
-    uint32_t* d_max = bsize + nbt + 1;  // one extra word behind the sizes
-    HIP_TRY(hipMemsetAsync(d_max, 0, 4, st));
-    hipLaunchKernelGGL(msm_bucket_rank_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, rank, bsize, pl.nb, pl.nchunks, nbt, d_max);
-    phase_end();
-    phase_begin("msm_scatter");
-    hipLaunchKernelGGL(msm_locoff_kernel, dim3(pl.nchunks, pl.W), dim3(1024), lds + 4096, st, rank, bsize, loc_off, sp);
-    static const int env_passes = getenv("SNARKVM_HIP_SCATTER_PASSES") ? atoi(getenv("SNARKVM_HIP_SCATTER_PASSES")) : 0;
-    uint32_t npass = env_passes > 0 ? (uint32_t)env_passes : (pl.nb >= 8192 ? 2u : 1u);  // measured: 1: 4.13, 2: 3.92, 4: 5.21, 8: 4.94 ms (2^24)
-    while (pl.nb % npass) npass--;
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.nchunks, pl.W, npass), dim3(1024), lds / npass, st, c.digits.as<uint16_t>(), loc_off,
-                       c.sorted.as<uint32_t>(), sp, npass);
-    phase_end();
-    // the largest bucket decides how many reduce rounds are needed (4-byte read-back; worst-case sizing would run
-    // up to 7 mostly idle rounds)
-    uint32_t max_bucket = 0;
-    HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (size_t m = ((size_t)max_bucket + pl.S - 1) / pl.S; m > 1; m = (m + pl.S2 - 1) / pl.S2) rounds++;
-    // 5. accumulate
-    phase_begin("msm_accumulate");
-    hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, bsize, c.cnt_a.as<uint32_t>(), nbt, pl.S);
-    exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-    {
-        const dim3 grid((unsigned)((T0_max + 255) / 256));
-        // timing experiment only (wrong results): restrict the gather to the first 2^k bases to separate ALU time from HBM gather time
-        static const uint32_t dbg_mask = getenv("SNARKVM_HIP_DEBUG_IDX_MASK") ? (uint32_t)strtoul(getenv("SNARKVM_HIP_DEBUG_IDX_MASK"), nullptr, 0) : 0xffffffffu;
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, 1>), grid, dim3(256), 0, st, d_bases, d_bases1 ? d_bases1 : d_bases, (uint32_t)n0,
-                           c.sorted.as<uint32_t>(), rank, loc_off, bsize, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S,
-                           pl.nb, pl.nchunks, pl.chunk * (uint32_t)pl.J, (uint32_t)n, table_stride, dbg_mask);
-    }
-    phase_end();
     }
     // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
     phase_begin("msm_reduce_partials");
@@ -502,13 +436,8 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         c.fold_idx.ensure((size_t)slots * 8);
         uint32_t* fstart = c.fold_idx.as<uint32_t>();
         uint32_t* fcnt = fstart + slots;
-        static const int fold_wg = getenv("SNARKVM_HIP_FOLD_WG") ? atoi(getenv("SNARKVM_HIP_FOLD_WG")) : 64;  // 64: one wave per output
-        if (fold_wg == 64)
-            hipLaunchKernelGGL((msm_fold_wave_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(64), 0, st, pin, start_in, cnt_in,
-                               c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
-        else
-            hipLaunchKernelGGL((msm_fold_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st,
-                               pin, start_in, cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
+        hipLaunchKernelGGL((msm_fold_wave_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(64), 0, st, pin, start_in, cnt_in,
+                           c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
         tail_sums = c.fold_sums.as<xyzz_mem_t<F>>();
         tail_start = fstart;
         tail_cnt = fcnt;
@@ -565,13 +494,7 @@ static void tu_kernel_attributes() {
     static bool done = false;
     if (done) return;
 #ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
-    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-#endif
-#ifdef SV_TU_MSM_G1  // the unit that instantiates the legacy chunk-major sort of the G1 MSM (api.hip)
-    HIP_TRY(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)msm_locoff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
 #endif
     done = true;
 }
@@ -637,9 +560,11 @@ static __global__ void devtest_field_kernel(int field, int op, const uint32_t* a
 // ---- helpers shared by the G1 and G2 entry points
 static void check_tables(int tables, int table_bits, const char* who) {
     const bool legacy = table_bits == 0 && (tables == 1 || tables == 2 || tables == 4 || tables == 8 || tables == 16);
-    const bool windowed = table_bits >= 2 && table_bits <= MSM_C_MAX && tables >= 1 && tables <= 127 && tables * table_bits >= 254;
+    // upper bound: the recoding bias holds one bit per digit row below MSM_BIAS_BITS (msm_plan_t::bias, the digit kernels' 11-word scalar)
+    const bool windowed = table_bits >= 2 && table_bits <= MSM_C_MAX && tables >= 1 && tables <= 127 && tables * table_bits >= 254 &&
+                          tables * table_bits <= MSM_BIAS_BITS;
     if (!legacy && !windowed)
-        throw std::runtime_error(std::string(who) + ": tables must be 1, 2, 4, 8 or 16, or tables * window_bits >= 254 with window_bits in 2..23");
+        throw std::runtime_error(std::string(who) + ": tables must be 1, 2, 4, 8 or 16, or 254 <= tables * window_bits <= 288 with window_bits in 2..23");
 }
 static void serde_throw_on_status(uint32_t st, const char* who) {
     if (!st) return;

@@ -1,4 +1,4 @@
-// serde.cuh - the reference's canonical wire / on-disk encoding of G1 points, decoded and encoded on the device
+// serde.hip.h - the reference's canonical wire / on-disk encoding of G1 points, decoded and encoded on the device
 // (SURVEY.md §8f N3), so that an SRS file or a serialised committer key goes from its bytes straight into the MSM
 // engine's base slots without a CPU pass.
 //
@@ -11,8 +11,8 @@
 //   Both bits set is rejected (flags.rs:90-93); coordinates >= q are rejected (read_le -> from_bigint == None).
 // `.usrs` files (parameters/src/mainnet/resources) are a u64 count followed by uncompressed points.
 #pragma once
-#include "ec.cuh"
-#include "ff.cuh"
+#include "ec.hip.h"
+#include "ff.hip.h"
 
 namespace sv {
 

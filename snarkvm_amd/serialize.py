@@ -3,7 +3,7 @@
 Mirror of `CanonicalSerialize / CanonicalDeserialize for Affine<P>` (curves/src/templates/macros.rs:66-140) and of the
 `.usrs` universal-SRS files (parameters/src/mainnet/resources: a u64 point count, then uncompressed points; loaded by
 `PowersOfBetaG::load`, parameters/src/mainnet/powers.rs).  Points decoded here never pass through a CPU field
-implementation: the bytes are copied to HBM and converted by one kernel (snarkvm_amd/csrc/serde.cuh)."""
+implementation: the bytes are copied to HBM and converted by one kernel (snarkvm_amd/csrc/serde.hip.h)."""
 import ctypes
 import struct
 

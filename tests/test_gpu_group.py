@@ -1,4 +1,4 @@
-"""Setup-time group operations on the device (snarkvm_amd/csrc/group.cuh through the C ABI) against the oracle:
+"""Setup-time group operations on the device (snarkvm_amd/csrc/group.hip.h through the C ABI) against the oracle:
 FixedBase::msm and the group-element iFFT behind UniversalParams::lagrange_basis."""
 import numpy as np
 import pytest

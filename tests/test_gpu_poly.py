@@ -1,4 +1,4 @@
-"""Parity of the prover-round polynomial kernels (snarkvm_amd/csrc/poly.cuh through the C ABI) and of KZG10::open
+"""Parity of the prover-round polynomial kernels (snarkvm_amd/csrc/poly.hip.h through the C ABI) and of KZG10::open
 against the oracle, on a real MI355X.  Bit-exact: Fr results are unique Montgomery residues."""
 import ctypes
 

@@ -1,4 +1,4 @@
-"""Device (de)serialisation of G1 points (snarkvm_amd/csrc/serde.cuh through the C ABI) against the Python oracle and
+"""Device (de)serialisation of G1 points (snarkvm_amd/csrc/serde.hip.h through the C ABI) against the Python oracle and
 the real SRS bytes, on an MI355X."""
 import numpy as np
 import pytest

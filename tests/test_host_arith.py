@@ -1,4 +1,4 @@
-"""The gfx950 device arithmetic (snarkvm_amd/csrc/ff.cuh, ec.cuh: 29-bit limbs) compiled for the host and
+"""The gfx950 device arithmetic (snarkvm_amd/csrc/ff.hip.h, ec.hip.h: 29-bit limbs) compiled for the host and
 executed on the CPU through the snarkvm_hip_selftest_* hooks, compared with the oracle.  No GPU needed."""
 import ctypes
 import re
@@ -60,8 +60,8 @@ def test_device_field_arithmetic_on_host_matches_oracle(field):
 
 
 def test_limb_tables_match_reference_constants(golden):
-    """Every 29-bit table in ff.cuh is re-derived from the reference's constants."""
-    src = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "ff.cuh")).read()
+    """Every 29-bit table in ff.hip.h is re-derived from the reference's constants."""
+    src = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "ff.hip.h")).read()
 
     def table(struct, name):
         body = src[src.index("struct " + struct):]
@@ -79,13 +79,13 @@ def test_limb_tables_match_reference_constants(golden):
         assert table(struct, "MEM2INT") == pow(2, 2 * B - membits, mod)
         assert table(struct, "INT2MEM") == pow(2, membits, mod)
         assert pyref.from_limbs(golden["constants"][key]["R"]) == pow(2, membits, mod)
-    # two-adic root and generator constants used by ntt.cuh / api.hip
-    ntt = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "ntt.cuh")).read()
+    # two-adic root and generator constants used by ntt.hip.h / api.hip
+    ntt = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "ntt.hip.h")).read()
     m = re.search(r"FR_TWO_ADIC_ROOT_MEM\[8\] = \{(.*?)\}", ntt, re.S)
     words = [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
     assert sum(w << (32 * i) for i, w in enumerate(words)) == pyref.from_limbs(golden["constants"]["fr"]["TWO_ADIC_ROOT_OF_UNITY"])
     csrc = os.path.join(util.ROOT, "snarkvm_amd", "csrc")
-    api = "".join(open(os.path.join(csrc, f)).read() for f in ("api.hip", "api_fr.hip", "api_g2.hip", "runtime.cuh"))
+    api = "".join(open(os.path.join(csrc, f)).read() for f in ("api.hip", "api_fr.hip", "api_g2.hip", "runtime.hip.h"))
     for name, key in (("G1_GEN_X", "GENERATOR_X_MONT"), ("G1_GEN_Y", "GENERATOR_Y_MONT")):
         m = re.search(name + r"\[6\] = \{(.*?)\}", api, re.S)
         assert [int(x) for x in re.findall(r"(\d+)ull", m.group(1))] == golden["constants"]["g1"][key]
@@ -132,7 +132,7 @@ def _plan(n, window_bits=0, tables=1, table_bits=0):
 
 
 def test_msm_planner_invariants():
-    """Host-side MSM planner (msm.cuh msm_make_plan): every plan covers the 254 signed-digit bits of a scalar, wide windows
+    """Host-side MSM planner (msm.hip.h msm_make_plan): every plan covers the 254 signed-digit bits of a scalar, wide windows
     exist only as one window per table, and the bench configurations come out as documented."""
     for n in (1, 31, 1000, 4096, 1 << 16, 1 << 20, 1 << 24):
         p = _plan(n)  # unregistered bases

@@ -1,5 +1,5 @@
 """Canonical G1 encoding: the Python oracle (oracle/pyref.py) against the real SRS bytes committed under tests/golden,
-and the constants of snarkvm_amd/csrc/serde.cuh re-derived from the reference's field parameters."""
+and the constants of snarkvm_amd/csrc/serde.hip.h re-derived from the reference's field parameters."""
 import os
 import re
 
@@ -16,7 +16,7 @@ def _words(src, name):
 
 
 def test_serde_constants_match_reference(golden):
-    src = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "serde.cuh")).read()
+    src = open(os.path.join(util.ROOT, "snarkvm_amd", "csrc", "serde.hip.h")).read()
     fq = golden["constants"]["fq"]
     q = pyref.from_limbs(fq["MODULUS"])
     t = pyref.from_limbs(fq["T"])

@@ -1,0 +1,99 @@
+// tools/ecbench.hip - wall-clock ALU ceilings of the product's own field / curve arithmetic (ff.hip.h, ec.hip.h) on the whole chip.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ecbench.hip -o tools/ecbench
+// Every kernel is a register-resident dependent chain per lane (no memory traffic in the loop), launched with enough blocks
+// for k waves per SIMD (k = the __launch_bounds__ request), timed with HIP events.  Prints G operations/s chip-wide; the
+// accumulate kernel's `alu_roofline` in bench.py is (mixed additions per launch) / (time) / (the madd ceiling printed here).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../snarkvm_amd/csrc/ec.hip.h"
+
+using namespace sv;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ fq_t seed_fq(uint32_t s) {
+    fq_t a;
+    for (int i = 0; i < 13; i++) {
+        s = s * 1664525u + 1013904223u;
+        a.v[i] = s & LIMB_MASK;
+    }
+    a.v[12] &= 0x00ffffffu;  // < q
+    return a;
+}
+
+// op: 0 mul, 1 sqr, 2 add+sub pair, 3 diff_of_products
+template <int MINW, int op>
+__global__ void __launch_bounds__(256, MINW) k_field(uint32_t* out, int iters, int) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    fq_t a = seed_fq(tid * 3 + 1), b = seed_fq(tid * 7 + 5);
+    for (int it = 0; it < iters; it++) {
+        if (op == 0) a = a * b;
+        else if (op == 1) a = a.sqr();
+        else if (op == 2) { a = a + b; b = b - a; }
+        else a = fq_t::diff_of_products(a, b, b, a);
+    }
+    uint32_t x = 0;
+    for (int i = 0; i < 13; i++) x ^= a.v[i] ^ b.v[i];
+    out[tid] = x;
+}
+// op: 0 add_affine (madd), 1 add (xyzz + xyzz), 2 dbl
+template <int MINW, int op>
+__global__ void __launch_bounds__(256, MINW) k_point(uint32_t* out, int iters, int) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    g1_aff_t p = {seed_fq(tid * 3 + 1), seed_fq(tid * 7 + 5)};  // not on the curve: the formulas do not care
+    g1_xyzz_t acc = {seed_fq(tid + 11), seed_fq(tid + 13), seed_fq(tid + 17), seed_fq(tid + 19)};
+    g1_xyzz_t q = acc;
+    q.x = q.x + p.x;
+    for (int it = 0; it < iters; it++) {
+        if (op == 0) acc.add_affine(p, (it & 1) != 0);
+        else if (op == 1) acc.add(q);
+        else acc = acc.dbl();
+    }
+    uint32_t x = 0;
+    for (int i = 0; i < 13; i++) x ^= acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+    out[tid] = x;
+}
+
+template <class K>
+static double run(K kern, int blocks, int iters, int op, uint32_t* d_out, hipEvent_t e0, hipEvent_t e1) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d_out, 4, op);  // warm-up
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d_out, iters, op);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return (double)blocks * 256 * iters / (ms * 1e-3) * 1e-9;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    uint32_t* d_out;
+    CHECK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4 * 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    printf("ecbench on %s, %d CUs: G operations/s chip-wide at k resident waves per SIMD (grid = CUs * k blocks of 256, x4 rounds)\n", prop.gcnArchName, cus);
+    const char* fnames[4] = {"Fq mul", "Fq sqr", "Fq add+sub pair", "Fq diff_of_products"};
+    printf("%-24s %10s %10s %10s %10s\n", "op", "k=1", "k=2", "k=3", "k=4");
+#define ROW_F(OP, IT) printf("%-24s %10.2f %10.2f %10.2f %10.2f\n", fnames[OP], run(k_field<1, OP>, cus * 1 * 4, IT, OP, d_out, e0, e1), \
+                             run(k_field<2, OP>, cus * 2 * 4, IT, OP, d_out, e0, e1), run(k_field<3, OP>, cus * 3 * 4, IT, OP, d_out, e0, e1), \
+                             run(k_field<4, OP>, cus * 4 * 4, IT, OP, d_out, e0, e1));
+    ROW_F(0, 2000) ROW_F(1, 2000) ROW_F(2, 2000) ROW_F(3, 2000)
+    const char* pnames[3] = {"G1 madd (xyzz+affine)", "G1 add (xyzz+xyzz)", "G1 dbl (xyzz)"};
+#define ROW_P(OP, IT) printf("%-24s %10.3f %10.3f %10.3f %10.3f\n", pnames[OP], run(k_point<1, OP>, cus * 1 * 4, IT, OP, d_out, e0, e1), \
+                             run(k_point<2, OP>, cus * 2 * 4, IT, OP, d_out, e0, e1), run(k_point<3, OP>, cus * 3 * 4, IT, OP, d_out, e0, e1), \
+                             run(k_point<4, OP>, cus * 4 * 4, IT, OP, d_out, e0, e1));
+    ROW_P(0, 400) ROW_P(1, 400) ROW_P(2, 400)
+    // single-wave latency of one dependent group operation (the tails of a small MSM): one block of 64 threads
+#define LAT(OP) { const int it = 200; hipLaunchKernelGGL((k_point<1, OP>), dim3(1), dim3(64), 0, 0, d_out, 4, OP); CHECK(hipEventRecord(e0)); \
+        hipLaunchKernelGGL((k_point<1, OP>), dim3(1), dim3(64), 0, 0, d_out, it, OP); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); \
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); printf("single wave, dependent chain: %-24s %.2f us per operation\n", pnames[OP], ms * 1e3 / it); }
+    LAT(0) LAT(1) LAT(2)
+    return 0;
+}

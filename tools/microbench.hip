@@ -67,6 +67,21 @@ PROBE_KERNEL(k_mul_f64, DECL_F64, B8(MUL64), (uint64_t)(d0 + d1 + d2 + d3 + d4 +
 #define FMA32(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a##i) : "v"(b));
 PROBE_KERNEL(k_fma_f32, DECL_U32, B8(FMA32), a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
 
+#define AND32(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+PROBE_KERNEL(k_and_b32, DECL_U32, B8(AND32), a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
+#define MADI64(i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(c##i) : "v"(a), "v"(b) : "vcc");
+PROBE_KERNEL(k_mad_i64_i32, DECL_U64, B8(MADI64), c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7)
+#define ASHR(i) asm volatile("v_ashrrev_i32 %0, 29, %0" : "+v"(a##i));
+PROBE_KERNEL(k_ashrrev_i32, DECL_U32, B8(ASHR), a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ b)
+#define BFE(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(a##i));
+PROBE_KERNEL(k_bfe_u32, DECL_U32, B8(BFE), a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ b)
+#define ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a##i) : "v"(b));
+PROBE_KERNEL(k_add3_u32, DECL_U32, B8(ADD3), a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
+#define CNDM(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(b) : "vcc");
+PROBE_KERNEL(k_cndmask_b32, DECL_U32, B8(CNDM), a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
+#define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(c##i) : "v"(c7));
+PROBE_KERNEL(k_pk_fma_f32, DECL_U64, PKFMA(0) PKFMA(1) PKFMA(2) PKFMA(3) PKFMA(4) PKFMA(5) PKFMA(6) PKFMA(0), c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7 ^ a ^ b)
+
 typedef void (*probe_fn)(uint64_t*, uint32_t);
 struct Probe { const char* name; probe_fn fn; };
 
@@ -288,6 +303,35 @@ int main() {
             res[c] = (double)cyc / (ITERS * 64.0) / waves_per_simd;  // per wave-instruction per SIMD
         }
         printf("%-28s %10.2f %10.2f %10.2f\n", p.name, res[0], res[1], res[2]);
+    }
+    // ---- wall-clock, whole-chip calibration: wave-instructions per second with every CU loaded at 1/2/4/8 waves per SIMD.
+    // No cycle counter involved: HIP events around a grid of (CUs * k) blocks of 256 threads, each lane issuing ITERS * 64
+    // instructions.  "cyc/SIMD" = 1024 SIMDs * 2.4 GHz * time / wave-instructions (nominal clock; DVFS may run lower).
+    {
+        hipEvent_t c0, c1; CHECK(hipEventCreate(&c0)); CHECK(hipEventCreate(&c1));
+        Probe cal[] = {{"v_fma_f32", k_fma_f32}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_fma_f64", k_fma_f64}, {"v_add_u32", k_add_u32}, {"v_and_b32", k_and_b32},
+                       {"v_add3_u32", k_add3_u32}, {"v_cndmask_b32", k_cndmask_b32}, {"v_ashrrev_i32", k_ashrrev_i32}, {"v_bfe_u32", k_bfe_u32},
+                       {"v_alignbit_b32", k_alignbit_b32}, {"v_lshrrev_b64", k_lshrrev_b64}, {"v_lshl_add_u64", k_lshl_add_u64},
+                       {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mad_u32_u24", k_mad_u32_u24},
+                       {"v_mad_u64_u32", k_mad_u64_u32}, {"v_mad_u64_u32(dep chain)", k_mad_u64_u32_dep}, {"v_mad_i64_i32", k_mad_i64_i32}};
+        printf("\nwall-clock whole-chip calibration (%d CUs): G wave-instr/s [cyc per wave-instr per SIMD at 2.4 GHz]\n", prop.multiProcessorCount);
+        printf("%-28s %22s %22s %22s %22s\n", "instr", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD", "8 waves/SIMD");
+        for (auto& p : cal) {
+            printf("%-28s", p.name);
+            for (int k = 1; k <= 8; k *= 2) {
+                const int grid = prop.multiProcessorCount * k;
+                hipLaunchKernelGGL(p.fn, dim3(grid), dim3(256), 0, 0, d_out, 12345u);  // warm-up
+                CHECK(hipEventRecord(c0));
+                hipLaunchKernelGGL(p.fn, dim3(grid), dim3(256), 0, 0, d_out, 12345u);
+                CHECK(hipEventRecord(c1)); CHECK(hipEventSynchronize(c1));
+                float ms; CHECK(hipEventElapsedTime(&ms, c0, c1));
+                const double winst = (double)grid * 4 * ITERS * 64.0;
+                const double cyc = 4.0 * prop.multiProcessorCount * 2.4e9 * (ms * 1e-3) / winst;
+                printf("   %9.1f G [%5.2f]", winst / (ms * 1e-3) * 1e-9, cyc);
+            }
+            printf("\n");
+        }
+        printf("sanity: v_fma_f64 at saturation x 64 lanes x 2 flop = vector FP64 TF/s (spec 78.6); v_fma_f32 -> FP32 (spec 157.3 incl. packed)\n\n");
     }
     // ---- field multiplication variants
     std::vector<F12> h(1024);
