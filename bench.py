@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
 """bench.py - BLS12-377 G1 MSM (pairs/s) + Fr NTT (elements/s) on MI355X.
 
-One "step" = one G1 variable-base MSM of 2^lg_msm scalar-point pairs (BASELINE.json configs[1]: 2^24 by default)
-with bases registered in HBM and scalars resident in HBM when the timed region starts.  `value` = pairs/s over all
-ranks (each rank runs its own independent MSM instance: instance-level sharding, no data-path collective -> weak
-scaling).  The JSON line also carries the NTT throughput at 2^24 (the second half of BASELINE.json's metric), a
-`roofline` object for the dominant kernel and for the scalar-read phase, and a `cpu_baseline` (the C++ restatement of
-the reference's rayon path, oracle/, timed on this box's host cores on a bounded sample).
+Default workload (`--workload msm`): one "step" = one G1 variable-base MSM of 2^lg_msm scalar-point pairs (BASELINE.json
+configs[1]: 2^24) with bases registered in HBM and scalars resident in HBM when the timed region starts.  `value` = pairs/s
+over all ranks (each rank runs its own independent MSM instances: instance-level sharding, no data-path collective -> weak
+scaling).  Every timed result is checked outside the timed region (closed form sum_i s_i (i+1) G, evaluated by a one-point MSM
+on the device; on rank 0 at N = 1 also against the CPU oracle, together with the full 2^24 NTT output).  The JSON line also
+carries: the NTT throughput at 2^24, the 2^20 half of BASELINE.json's metric, the throughput without precomputed tables, the
+registration cost, the end-to-end times of the reference's own FFI symbols over host buffers, `roofline` objects following
+SURVEY.md 8(d) (algorithmic bytes n * 128 + 144 for the whole MSM, 32 n for the scalar-read phase, 64 n for an NTT), an
+`alu_roofline` against the wall-clock-calibrated arithmetic ceilings of tools/ecbench.hip, and a `cpu_baseline` (the C++
+restatement of the reference's rayon path, oracle/, timed on this box's host cores on a bounded sample).
+
+`--workload proofs64`: BASELINE.json configs[4] - 64 Varuna-proof-shaped call lists (13 G1 commitments / openings of
+2^16-2^17, ~45 NTTs, the polynomial passes, one 2^16 G2 MSM each; snarkvm_amd/proofs.py) replayed by concurrent caller
+threads, 64 / N proofs per rank; `value` = proofs/s over all ranks (strong scaling), with pairs/s beside it.
 """
 import argparse
 import ctypes
@@ -20,12 +28,42 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+DTYPE = "u32 limbs (29-bit radix) modular integer arithmetic, Fq 377-bit / Fr 253-bit"
+G1_GEN_X = [1171681672315280277, 6528257384425852712, 7514971432460253787, 2032708395764262463, 12876543207309632302, 107509843840671767]
+G1_GEN_Y = [13572190014569192121, 15344828677741220784, 17067903700058808083, 10342263224753415805, 1083990386877464092, 21335464879237822]
+R_MOD = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+
+
+def weighted_sum_mod_r(scalars, start=1):
+    """sum_i (start + i) * scalars[i] mod r for an (n,4) u64 array, vectorised (16-bit pieces, chunked)."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    total = 0
+    CH = 1 << 18
+    for lo in range(0, s.shape[0], CH):
+        hi = min(s.shape[0], lo + CH)
+        wgt = np.arange(start + lo, start + hi, dtype=np.uint64)
+        for limb in range(4):
+            col = s[lo:hi, limb]
+            for piece in range(4):
+                part = (col >> np.uint64(16 * piece)) & np.uint64(0xFFFF)
+                total += int(np.sum(part * wgt, dtype=np.uint64)) << (64 * limb + 16 * piece)  # weights < 2^26, pieces < 2^16, chunk 2^18
+    return total % R_MOD
+
+
+def load_profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["msm", "proofs64"], default="msm")
     ap.add_argument("--lg-msm", type=int, default=24)
     ap.add_argument("--lg-ntt", type=int, default=24)
     ap.add_argument("--ntt-steps", type=int, default=10)
@@ -36,8 +74,11 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the K steps one synchronous MSM at a time instead of one pipelined batch of K independent MSMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the 2^20 / tables1 / FFI legs (they are outside the timed region anyway)")
     ap.add_argument("--cpu-lg-msm", type=int, default=23)
     ap.add_argument("--cpu-lg-ntt", type=int, default=24)
+    ap.add_argument("--proofs", type=int, default=64)
+    ap.add_argument("--proof-workers", type=int, default=4, help="concurrent caller threads per rank (proofs64)")
     args = ap.parse_args()
 
     import torch
@@ -60,12 +101,12 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    from snarkvm_amd import _lib, synthetic
-    from snarkvm_amd.layout import G1_AFFINE
+    from snarkvm_amd import _lib, plugin, synthetic
+    from snarkvm_amd.layout import G1_AFFINE, G1_PROJECTIVE
     from snarkvm_amd.msm import RegisteredBases
 
     L = _lib.lib()
-    _lib.check(L.snarkvm_hip_set_device(ctypes.c_int(dev_index)))
+    _lib.check(L.snarkvm_hip_set_device(ctypes.c_int(dev_index)))  # this process drives exactly one GPU
 
     def barrier():
         torch.cuda.synchronize()
@@ -73,6 +114,43 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    if args.workload == "proofs64":
+        return proofs64(args, rank, world, dev_index, barrier, max_over_ranks)
+
+    gen = np.zeros(1, dtype=G1_AFFINE)
+    gen["x"] = G1_GEN_X
+    gen["y"] = G1_GEN_Y
+
+    def device_multiple_of_g(k):
+        """k * G as an affine record, by a one-point MSM on the device (the plain FFI path with its own planner)."""
+        sc = np.array([[(k >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64)
+        return to_affine(plugin.msm(gen, sc))
+
+    def to_affine(proj):
+        proj = np.ascontiguousarray(proj, dtype=G1_PROJECTIVE).reshape(-1)
+        out = np.zeros(proj.shape[0], dtype=G1_AFFINE)
+        _lib.check(L.snarkvm_hip_g1_to_affine(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(proj.ctypes.data), ctypes.c_size_t(proj.shape[0])))
+        return out
+
+    checks = {}
+
+    def check_results(res, scalars_used, label):
+        """Every result of a (pipelined) run equals the closed form (sum_i s_i (i + 1)) G; fails loudly otherwise."""
+        want = device_multiple_of_g(weighted_sum_mod_r(scalars_used, start=1))
+        got = to_affine(res)
+        for k in range(got.shape[0]):
+            if got[k : k + 1].tobytes() != want.tobytes():
+                raise SystemExit(f"bench.py: RESULT MISMATCH in {label}, instance {k}: the timed MSM does not equal the closed form")
+        checks[label] = f"{got.shape[0]} results == closed form (device one-point MSM)"
+        return want
 
     # ------------------------------------------------------------------ inputs (synthetic, resident in HBM)
     n = 1 << args.lg_msm
@@ -84,9 +162,10 @@ def main():
         args.table_bits = 16 if args.tables else (22 if args.lg_msm >= 24 else 20 if args.lg_msm >= 22 else 16)
     if not args.tables:
         args.tables = 16 if args.table_bits == 16 else -(-254 // args.table_bits)
+    t0 = time.perf_counter()
     rb = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=args.tables,
                          window_bits=0 if (args.table_bits == 16 and args.tables == 16) or args.tables == 1 else args.table_bits)
-    del bases_dev
+    registration_ms = (time.perf_counter() - t0) * 1e3
     scalars = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE + rank)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).cuda()
     torch.cuda.synchronize()
@@ -103,20 +182,16 @@ def main():
     barrier()
     t0 = time.perf_counter()
     if args.no_pipeline:
-        for _ in range(args.steps):
-            res = rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits)
+        res = np.concatenate([rb.msm(device_ptr=d_scalars.data_ptr(), npoints=n, window_bits=args.window_bits) for _ in range(args.steps)])
     else:
         # K independent MSM instances (a batch of commitments) pipelined over the backend's HIP streams: the
         # latency-bound tail of one instance overlaps the accumulation of the next.  Every step does the full work.
         res = rb.msm_batch(device_ptrs=[d_scalars.data_ptr()] * args.steps, npoints=[n] * args.steps, window_bits=args.window_bits)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = world * n * args.steps / dt
+    want_affine = check_results(res, scalars, "timed_msm")  # outside the timed region
 
     # ------------------------------------------------------------------ per-phase kernel times (HIP events on the launch stream)
     L.snarkvm_hip_set_profiling(1)
@@ -135,28 +210,111 @@ def main():
     d_x = torch.from_numpy(x.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
-    def ntt(direction):
-        _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(d_x.data_ptr()), ctypes.c_uint32(args.lg_ntt), 0, direction, 0))
+    def ntt_dev(t, lg, direction):
+        _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(t.data_ptr()), ctypes.c_uint32(lg), 0, direction, 0))
 
-    ntt(0)
-    ntt(1)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.ntt_steps):
-        ntt(i & 1)
-    barrier()
-    ntt_dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([ntt_dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ntt_dt = float(t.item())
+    def time_ntt(t, lg, steps):
+        ntt_dev(t, lg, 0)
+        ntt_dev(t, lg, 1)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ntt_dev(t, lg, i & 1)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    if args.ntt_steps & 1:
+        args.ntt_steps += 1  # forward / inverse pairs: the vector is back to the input afterwards
+    ntt_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps)
     ntt_elems_per_s = world * nn * args.ntt_steps / ntt_dt
     L.snarkvm_hip_set_profiling(1)
-    ntt(0)
+    ntt_dev(d_x, args.lg_ntt, 0)
     ntt_kernel_ms = L.snarkvm_hip_get_phase_ms(0)
     L.snarkvm_hip_set_profiling(0)
+    ntt_forward = d_x.cpu().numpy().view(np.uint64).reshape(-1, 4)  # forward transform of x (for the oracle check below)
+    ntt_dev(d_x, args.lg_ntt, 1)
+    if not np.array_equal(d_x.cpu().numpy().view(np.uint64).reshape(-1, 4), x):
+        raise SystemExit("bench.py: NTT round trip does not return the input")
+    checks["ntt_round_trip"] = f"iNTT(NTT(x)) == x at 2^{args.lg_ntt}"
 
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    # ------------------------------------------------------------------ extra legs (rank 0, N = 1): the rest of BASELINE.json's metric
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        table_bytes = args.tables * n * 128
+        extra["registration_ms"] = registration_ms
+        extra["table_bytes"] = table_bytes
+        # -- the same MSM without precomputed tables (registered bases only: 16 windows of 16 bits, Horner chain on the host)
+        rb1 = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=1)
+        rb1.msm(device_ptr=d_scalars.data_ptr(), npoints=n)
+        barrier()
+        t0 = time.perf_counter()
+        k1 = 2
+        r1 = rb1.msm_batch(device_ptrs=[d_scalars.data_ptr()] * k1, npoints=[n] * k1)
+        barrier()
+        d1 = time.perf_counter() - t0
+        rb1.close()
+        if to_affine(r1)[0:1].tobytes() != want_affine.tobytes():
+            raise SystemExit("bench.py: RESULT MISMATCH in the tables = 1 leg")
+        extra["tables1_value"] = n * k1 / d1
+        extra["tables1_ms_per_step"] = d1 / k1 * 1e3
+        # -- 2^20: MSM over 16 x 16-bit tables (pipelined batch of 8) and NTT
+        if args.lg_msm >= 20:
+            n20 = 1 << 20
+            rb20 = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n20, tables=16)
+            lanes = L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n20))
+            rb20.msm_batch(device_ptrs=[d_scalars.data_ptr()] * lanes, npoints=[n20] * lanes)
+            barrier()
+            t0 = time.perf_counter()
+            k20 = 16
+            r20 = rb20.msm_batch(device_ptrs=[d_scalars.data_ptr()] * k20, npoints=[n20] * k20)
+            barrier()
+            d20 = time.perf_counter() - t0
+            check_results(r20, scalars[:n20], "msm_2p20")
+            t0 = time.perf_counter()
+            for _ in range(5):
+                rb20.msm(device_ptr=d_scalars.data_ptr(), npoints=n20)
+            s20 = (time.perf_counter() - t0) / 5
+            rb20.close()
+            extra["msm_2p20"] = {"value": n20 * k20 / d20, "unit": "pairs/s", "ms_per_step_pipelined": d20 / k20 * 1e3, "ms_sync": s20 * 1e3, "base_tables": "16 x 16 bit"}
+        if args.lg_ntt >= 20:
+            nt = 20
+            d20 = time_ntt(d_x, 20, nt)
+            extra["ntt_2p20"] = {"value": (1 << 20) * nt / d20, "unit": "elements/s", "ms_per_transform": d20 / nt * 1e3}
+        # -- the reference's own FFI symbols over host buffers (PCIe-inclusive; never `value`)
+        ffi = {}
+        host_bases = bases_dev.cpu().numpy().view(G1_AFFINE)
+        for lg in (16, 20, args.lg_msm):
+            m = 1 << lg
+            hb, hs = host_bases[:m], scalars[:m]
+            t0 = time.perf_counter()
+            r_first = plugin.msm(hb, hs)  # first sighting of this host range: upload + conversion, chunked and overlapped
+            first = time.perf_counter() - t0
+            plugin.msm(hb, hs)            # second sighting: the range is registered in HBM (base cache)
+            t0 = time.perf_counter()
+            r_cached = plugin.msm(hb, hs)
+            cached = time.perf_counter() - t0
+            w = device_multiple_of_g(weighted_sum_mod_r(hs, start=1))
+            if to_affine(r_first).tobytes() != w.tobytes() or to_affine(r_cached).tobytes() != w.tobytes():
+                raise SystemExit(f"bench.py: RESULT MISMATCH in snarkvm_msm at 2^{lg}")
+            ffi[f"snarkvm_msm_2p{lg}"] = {"first_call_ms": first * 1e3, "steady_state_ms": cached * 1e3, "pairs_per_s_first": m / first, "pairs_per_s_steady": m / cached}
+        from snarkvm_amd.layout import NTTDirection, NTTInputOutputOrder, NTTType
+        for lg in (16, 20, args.lg_ntt):
+            y = x[: 1 << lg].copy()
+            plugin.NTT(1 << lg, y, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Standard)
+            t0 = time.perf_counter()
+            plugin.NTT(1 << lg, y, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Standard)
+            d = time.perf_counter() - t0
+            if not np.array_equal(y, x[: 1 << lg]):
+                raise SystemExit(f"bench.py: snarkvm_ntt round trip failed at 2^{lg}")
+            ffi[f"snarkvm_ntt_2p{lg}"] = {"ms": d * 1e3, "elements_per_s": (1 << lg) / d}
+        ffi["note"] = ("host buffers in and out through the reference's FFI symbols; MSM first_call = unknown base range (2.4 GB over PCIe at 2^24, "
+                       "overlapped with the computation in 2^21-pair chunks), steady_state = the range was passed before and lives in HBM with 16 tables")
+        extra["end_to_end_ffi"] = ffi
+        checks["ffi"] = "snarkvm_msm first / cached calls == closed form at every size; snarkvm_ntt round trips"
+        del host_bases
+    del bases_dev
+
+    # ------------------------------------------------------------------ CPU baseline + oracle checks (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu as oracle
@@ -164,22 +322,34 @@ def main():
         cores = os.cpu_count() or 1
         threads = min(cores, 64)
         oracle.set_threads(threads)
-        cn = 1 << args.cpu_lg_msm
-        gen = np.zeros(1, dtype=oracle.G1_AFFINE)
-        gen["x"] = [1171681672315280277, 6528257384425852712, 7514971432460253787, 2032708395764262463, 12876543207309632302, 107509843840671767]
-        gen["y"] = [13572190014569192121, 15344828677741220784, 17067903700058808083, 10342263224753415805, 1083990386877464092, 21335464879237822]
-        cn = min(cn, n)
-        cb = oracle.g1_gen_bases(gen, 1, cn)
+        cn = min(1 << args.cpu_lg_msm, n)
+        ogen = np.zeros(1, dtype=oracle.G1_AFFINE)
+        ogen["x"] = G1_GEN_X
+        ogen["y"] = G1_GEN_Y
+        cb = oracle.g1_gen_bases(ogen, 1, cn)
         cs = scalars[:cn]
         oracle.g1_msm(cb[:1024], cs[:1024])  # warm-up
         t0 = time.perf_counter()
         cpu_res = oracle.g1_msm(cb, cs, oracle.MSM_BATCHED)
         cpu_msm_dt = time.perf_counter() - t0
+        # the oracle pins the closed form the timed results were checked against, and the CPU sample itself
+        k_full = weighted_sum_mod_r(scalars, start=1)
+        o_full = oracle.g1_to_affine(oracle.g1_mul(ogen, np.array([(k_full >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)))
+        if o_full.tobytes() != want_affine.tobytes():
+            raise SystemExit("bench.py: the timed MSM result differs from the CPU oracle")
+        k_cn = weighted_sum_mod_r(cs, start=1)
+        o_cn = oracle.g1_to_affine(oracle.g1_mul(ogen, np.array([(k_cn >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)))
+        if oracle.g1_to_affine(cpu_res).tobytes() != o_cn.tobytes():
+            raise SystemExit("bench.py: the CPU oracle disagrees with itself (batched::msm vs closed form)")
+        checks["timed_msm_vs_oracle"] = f"2^{args.lg_msm} result == oracle (batched::msm restatement's scalar multiplication of the closed form)"
         cnn = min(1 << args.cpu_lg_ntt, nn)
-        cx = x[:cnn].copy()
         t0 = time.perf_counter()
-        oracle.ntt(cx)
+        o_ntt = oracle.ntt(x[:cnn].copy())
         cpu_ntt_dt = time.perf_counter() - t0
+        if cnn == nn:
+            if not np.array_equal(o_ntt, ntt_forward):
+                raise SystemExit("bench.py: the device NTT output differs from the CPU oracle")
+            checks["ntt_vs_oracle"] = f"forward NTT 2^{args.lg_ntt} bit-exact vs oracle.ntt (all {nn} elements)"
         cpu = {
             "value": cn / cpu_msm_dt,
             "unit": "pairs/s",
@@ -192,44 +362,45 @@ def main():
             "ntt_unit": "elements/s",
         }
 
-    # HBM bytes per dispatch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs; see
-    # profiles/r01_pmc_traffic.json for provenance and the gfx950 x2 FETCH correction).  Only quoted for the
-    # configuration they were collected on; PMC collection cannot run inside this process.
-    pmc = {}
-    try:
-        if args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)["kernels"]
-    except Exception:
-        pmc = {}
+    # HBM bytes / instruction counts per dispatch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    # runs; gfx950 x2 FETCH correction), and the wall-clock arithmetic ceilings of tools/ecbench.hip / tools/microbench.hip.
+    # Only quoted for the configuration they were collected on; PMC collection cannot run inside this process.
+    default_cfg = args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits
+    pmc = (load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
+    ceil = load_profile_json("r02_alu_ceilings.json")
 
-    valu = {}
-    try:
-        if pmc:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")) as f:
-                valu = json.load(f)["kernels"]
-    except Exception:
-        valu = {}
-
-    def valu_issue(kernel, ms, launches=1):
-        """VALU issue utilisation: PMC wave-instruction count (committed, same configuration) x the 4-cycle wave64 issue
-        floor of a 16-lane SIMD / (1024 SIMDs x 2.4 GHz x measured kernel time)."""
-        k = valu.get(kernel)
-        if not k or not ms:
-            return None
-        cycles = ms * 1e-3 * 2.4e9 * 1024
-        cpi = cycles / (k["SQ_INSTS_VALU"] * launches)
-        return {"wave_insts_per_launch": k["SQ_INSTS_VALU"], "cycles_per_inst": cpi, "issue_floor_cycles": 4.0, "frac": 4.0 / cpi}
-
-    def traffic(kernel, fetch_key, times=1):
-        k = pmc.get(kernel)
-        return None if not k else (k[fetch_key] + k["write_bytes"]) * times
+    def traffic(kernel_prefix, fetch_key, times=1):
+        for name, k in pmc.items():
+            if name.startswith(kernel_prefix):
+                return (k[fetch_key] + k["write_bytes"]) * times
+        return None
 
     if rank == 0:
         acc_ms = phase_ms.get("msm_accumulate", 0.0)
         dig_ms = phase_ms.get("msm_digits", 0.0)
         cbits = args.window_bits or (args.table_bits if args.tables > 1 else 16)
         W = args.tables * (args.table_bits // cbits) if args.tables > 1 else (254 + cbits - 1) // cbits  # digit rows per scalar
+        alg_bytes = n * 128.0 + 144.0  # whole MSM = n (32 + 96) + 144
+        madds = float(n) * W           # mixed additions of the accumulate kernel (one per digit; digit 0 is rare)
+        alu = None
+        if ceil and acc_ms:
+            alu = {
+                "kernel": "msm_accumulate_seg_kernel",
+                "madds_per_launch": madds,
+                "madds_per_s": madds / (acc_ms * 1e-3),
+                "madd_ceiling_per_s": ceil.get("g1_madd_per_s"),
+                "frac": madds / (acc_ms * 1e-3) / ceil["g1_madd_per_s"] if ceil.get("g1_madd_per_s") else None,
+                "mads_per_launch": madds * 2938.0,  # v_mad_u64_u32 per mixed addition: 6 M + 2 S + one two-product reduction over 13 limbs
+                "peak_mads_per_s": ceil.get("v_mad_u64_u32_per_s"),
+                "mad_frac": madds * 2938.0 / (acc_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"] if ceil.get("v_mad_u64_u32_per_s") else None,
+                "source": "profiles/r02_alu_ceilings.json (tools/ecbench.hip, tools/microbench.hip: wall-clock, whole chip)",
+            }
+        alu_ntt = None
+        if ceil and ntt_kernel_ms and ceil.get("v_mad_u64_u32_per_s"):
+            # Fr products per element: lg / 2 butterfly products + one closing product per non-last pass + the final reduction (~half)
+            prods = nn * (args.lg_ntt / 2.0 + 2.0 + 0.5)
+            alu_ntt = {"fr_products_per_launch": prods, "mads_per_launch": prods * 153.0, "peak_mads_per_s": ceil["v_mad_u64_u32_per_s"],
+                       "mad_frac": prods * 153.0 / (ntt_kernel_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"]}
         out = {
             "metric": "BLS12-377 G1 MSM scalar-point pairs/sec (+ Fr NTT elements/sec in ntt_*)",
             "value": pairs_per_s,
@@ -240,32 +411,36 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32 limbs (29-bit radix) modular integer arithmetic, Fq 377-bit / Fr 253-bit",
+            "vs_baseline": None,  # the reference publishes no number for this metric
+            "vs_cpu_baseline": (pairs_per_s / cpu["value"]) if cpu else None,
+            "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": f"G1 Pippenger MSM 2^{args.lg_msm} (BASELINE.json configs[1]), bases (i+1)G registered in HBM, "
                                    f"uniform scalars in HBM; independent instance per GPU",
                        "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables, "table_bits": args.table_bits,
                        "pipelined_batch": not args.no_pipeline},
+            "checks": checks,
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
             "ntt_ms_per_transform": ntt_dt / args.ntt_steps * 1e3,
             "ntt_kernel_ms": ntt_kernel_ms,
+            "ntt_vs_cpu_baseline": (ntt_elems_per_s / cpu["ntt_value"]) if cpu else None,
             "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
-            # dominant kernel: bucket accumulation.  It is ALU-bound; its algorithmic HBM bytes are the gathered
-            # bases (96 B) + sorted index (4 B) per (pair, window) - reported against the HBM peak for context.
+            # dominant kernel: bucket accumulation.  SURVEY.md 8(d): algorithmic bytes of the whole MSM = n (32 + 96) + 144; the
+            # kernel is integer-ALU bound, so `frac` is small by nature - `alu_roofline` is the bound that applies.
             "roofline": {
                 "bound": "hbm",
                 "kernel": "msm_accumulate_seg_kernel",
-                "achieved": (n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 if acc_ms else None,
+                "achieved": alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else None,
                 "peak": 8000.0,
                 "unit": "GB/s",
-                "frac": ((n * 100.0 * W) / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
-                "traffic": traffic("msm_accumulate_seg_kernel<Fp<FqP>, 1>", "fetch_bytes_raw"),
-                "algorithmic_bytes": n * 100.0 * W,
-                "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see valu_issue; roofline_scalar_read is the HBM-bound phase",
-                "valu_issue": valu_issue("msm_accumulate_seg_kernel<Fp<FqP>, 1>", acc_ms),
+                "frac": (alg_bytes / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
+                "traffic": traffic("msm_accumulate_seg_kernel", "fetch_bytes_raw"),
+                "algorithmic_bytes": alg_bytes,
+                "traffic_model": {"bytes": n * 100.0 * W, "what": "one gathered 96-B base + one 4-B sorted index per (pair, digit row)"},
+                "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see alu_roofline; roofline_scalar_read is the HBM-bound phase",
             },
+            "alu_roofline": alu,
             # the phase north_star scopes the HBM claim to: scalar read + digit extraction, 32 B per scalar
             "roofline_scalar_read": {
                 "bound": "hbm",
@@ -274,7 +449,7 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
-                "traffic": traffic("msm_digits_kernel<unsigned int>", "fetch_bytes_x2"),
+                "traffic": traffic("msm_digits_kernel", "fetch_bytes_x2"),
                 "algorithmic_bytes": 32.0 * n,
                 "bytes_incl_digit_writes_GBps": ((32.0 + (4.0 if cbits > 16 else 2.0) * W) * n) / (dig_ms * 1e-3) / 1e9 if dig_ms else None,
             },
@@ -286,12 +461,67 @@ def main():
                 "unit": "GB/s",
                 "frac": ((64.0 * nn) / (ntt_kernel_ms * 1e-3) / 1e9 / 8000.0) if ntt_kernel_ms else None,
                 "traffic": traffic("ntt_pass_kernel_v2", "fetch_bytes_x2", times=3),
-                "valu_issue": valu_issue("ntt_pass_kernel_v2", ntt_kernel_ms, launches=3),
                 "algorithmic_bytes": 64.0 * nn,
+                "alu_roofline": alu_ntt,
             },
             "cpu_baseline": cpu,
         }
+        out.update(extra)
         print(json.dumps(out))
+    rb.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
+    """BASELINE.json configs[4]: a batch of Varuna-proof-shaped call lists, sharded over the ranks (64 / N proofs each) and, inside
+    a rank, replayed by concurrent caller threads."""
+    import torch
+    import torch.distributed as dist
+
+    from snarkvm_amd import proofs
+
+    shape = proofs.ProofShape()
+    keys = proofs.ProverKeys(shape)
+    batch = proofs.ProofBatch(keys, workers=args.proof_workers, devices=[dev_index])
+    mine = list(range(rank, args.proofs, world))
+    # warm-up: one proof per worker (allocations, twiddle tables), and the serial reference results of two proofs
+    batch.run(list(range(len(batch.workspaces))))
+    serial = proofs.ProofBatch(keys, workers=1, devices=[dev_index])
+    probe = sorted({mine[0], mine[-1]}) if mine else []
+    _, want = serial.run(probe, collect=True)
+    barrier()
+    t0 = time.perf_counter()
+    _, got = batch.run(mine, collect=True)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    for p, w in zip(probe, want):
+        if got[mine.index(p)] != w:
+            raise SystemExit(f"bench.py: proof {p} replayed concurrently differs from its serial replay")
+    t = {k: sum(ws.times[k] for ws in batch.workspaces) for k in batch.workspaces[0].times}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Varuna-proof-shaped hot-path replays per second (BASELINE.json configs[4]: batch of 64, G1 + G2)",
+            "value": args.proofs / dt,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.proofs,
+            "warmup": len(batch.workspaces),
+            "ms_per_step": dt / args.proofs * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": DTYPE,
+            "data": "synthetic",
+            "config": {"workload": "64 x (13 G1 commitments / openings of 2^16-2^17 pairs in 6 batched rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM); "
+                                   "device-resident random data, transfer_private domain sizes",
+                       "proofs": args.proofs, "caller_threads_per_rank": len(batch.workspaces), "proofs_per_rank": len(mine)},
+            "g1_pairs_per_s": args.proofs * shape.pairs() / dt,
+            "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt,
+            "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t.items()},
+            "checks": {"concurrent_vs_serial": f"proofs {probe}: all 14 commitments + the G2 result identical to a serial replay"},
+        }))
+    keys.close()
     if world > 1:
         dist.destroy_process_group()
 

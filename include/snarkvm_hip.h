@@ -8,8 +8,9 @@
  * Part 2 is an extension ABI (not in the reference): device-resident operands, SRS registration,
  * timing hooks.  Part 3 are test hooks.
  *
- * All functions are thread-safe (calls are serialised per device, like the reference's resource
- * channel, snarkvm.cu:146-150) and never unwind.  No torch / C++ types cross this boundary.
+ * All functions are thread-safe and never unwind.  Concurrent callers (rayon workers: one commitment each) are handed
+ * different (device, stream) lanes - the reference's resource channel, snarkvm.cu:84,146-150 - and block only when every
+ * lane of every selected device is busy.  No torch / C++ types cross this boundary.
  */
 #ifndef SNARKVM_HIP_H
 #define SNARKVM_HIP_H
@@ -59,10 +60,15 @@ RustError snarkvm_polymul(void *out, size_t pcount, const void *polynomials, con
  * stride `ffi_affine_sz` = 104 bytes), `scalars` are npoints canonical 256-bit integers < r. */
 RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoints, const void *scalars,
                       size_t ffi_affine_sz);
-/* Optional, off by default: with the environment variable SNARKVM_HIP_BASE_CACHE=<tables> (1, 2, 4, 8 or 16) snarkvm_msm keeps
- * the converted bases (+ precomputed tables) of up to four host ranges in HBM and reuses them when a later call passes a
- * slice of the same range - the reference's callers always pass slices of one long-lived `powers_of_beta_g` vector
- * (kzg10/mod.rs:117-119).  A hit is verified against raw copies of every 4096th point; results are unchanged. */
+/* Multi-GPU: like the reference (snarkvm.cu:254-295) a call of >= 2^19 pairs is cut into point-range chunks that are dealt
+ * to every selected device (and to two lanes per device, so that the upload of one chunk overlaps the computation of the
+ * previous one); the per-chunk partial results are combined on the host.
+ * Base cache: a host base range passed a SECOND time is kept in HBM (converted, with 16 precomputed tables, on every device)
+ * and later calls whose bases are a slice of it skip upload and conversion - the reference's callers always pass slices of
+ * one long-lived `powers_of_beta_g` vector (kzg10/mod.rs:117-119).  A hit is verified against raw copies of every 64th point
+ * of the slice; the memory behind a cached range must not be mutated in between at other positions.  Results are unchanged.
+ * SNARKVM_HIP_BASE_CACHE=0 disables it (=1/2/4/8/16 selects the table count), SNARKVM_HIP_BASE_CACHE_MB caps the HBM bytes per
+ * device (default 65536). */
 
 /* ---------------------------------------------------------------------------------------------
  * Part 2 - extension ABI (device-resident data, SRS registration, instrumentation)
@@ -74,17 +80,24 @@ int snarkvm_hip_device_count(void);
  * up to `npoints` pairs: 8 below 2^20, 3 above (SNARKVM_HIP_LANES overrides).  A caller that wants allocation-free timed
  * regions warms up that many instances first. */
 int snarkvm_hip_batch_lanes(size_t npoints);
-/* Select the HIP device used by this process' context (default: device 0 / LOCAL_RANK mapping is the
- * caller's business).  Must be called before the first compute call. */
+/* Devices used by this process (the reference loops over `ngpus()`, snarkvm.cu:123-151).  Default: every visible device, or
+ * the comma-separated list in SNARKVM_HIP_DEVICES.  snarkvm_hip_set_devices selects them explicitly; it must be called before
+ * the first compute call (afterwards only the identical list is accepted).  An id may be listed more than once: each entry
+ * is an independent logical device (own streams, workspaces, base replicas) - how the multi-device paths are tested on a
+ * one-GPU box.  snarkvm_hip_set_device(d) == set_devices({d}): the one-process-per-GPU deployment (LOCAL_RANK mapping is the
+ * caller's business).  snarkvm_hip_num_devices: logical devices in use (0 if none can be initialised). */
+RustError snarkvm_hip_set_devices(const int32_t *ids, size_t n);
 RustError snarkvm_hip_set_device(int device);
+int snarkvm_hip_num_devices(void);
 
-/* Same as snarkvm_ntt but `d_inout` is device memory on the context's device. */
+/* Same as snarkvm_ntt but `d_inout` is device memory (the call runs on the device that owns it). */
 RustError snarkvm_hip_ntt_device(void *d_inout, uint32_t lg_domain_size, int ntt_order, int ntt_direction,
                                  int ntt_type);
 
 /* Register a base vector once (SRS powers are static per proving key; the reference re-uploads
  * 104 B/point on every call, snarkvm.cu:262-275).  `points` is a Rust `[G1Affine]` with the given
- * stride, in host (on_device = 0) or device (on_device = 1) memory.  Returns an opaque handle. */
+ * stride, in host (on_device = 0) or device (on_device = 1) memory.  Every selected device receives its own replica
+ * (host source: parallel uploads; device source: peer copies of the finished tables).  Returns an opaque handle. */
 typedef struct snarkvm_hip_bases snarkvm_hip_bases_t;
 RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t **handle, const void *points, size_t npoints,
                                      size_t ffi_affine_sz, int on_device);
@@ -138,11 +151,20 @@ RustError snarkvm_hip_msm_registered_ex(void *out, const snarkvm_hip_bases_t *ha
 /* A batch of independent MSMs over one registered base vector (the commitments of a batch of proofs,
  * polycommit/sonic_pc/mod.rs:186-245 fans these out over a CPU pool).  Instance k covers bases
  * [offsets[k], offsets[k] + npoints[k]) with the scalar vector scalars[k]; results are written to
- * outs + 144 * k.  Instances are pipelined over several HIP streams so that the latency-bound tail of one MSM
- * overlaps the accumulation of the next. */
+ * outs + 144 * k.  Instances are dealt to the selected devices (host scalars: round-robin; device scalars: the device that
+ * owns them) and, on each device, pipelined over several HIP streams so that the latency-bound tail of one MSM overlaps
+ * the accumulation of the next. */
 RustError snarkvm_hip_msm_registered_batch(void *outs, const snarkvm_hip_bases_t *handle, size_t count,
                                            const size_t *offsets, const size_t *npoints, const void *const *scalars,
                                            int scalars_on_device, int scalars_montgomery, int window_bits);
+
+/* The same with two base ranges per instance: bases [off0[k], off0[k] + n0[k]) followed by [off1[k], off1[k] + n1[k]) against
+ * n0[k] + n1[k] consecutive scalars - a whole round of KZG10 commitments (plaintext + hiding MSM each, polycommit/kzg10/
+ * mod.rs:119,149; degree-bounded ones start at a shifted-powers offset, sonic_pc/mod.rs:203-245) in one call. */
+RustError snarkvm_hip_msm_registered_batch_ex(void *outs, const snarkvm_hip_bases_t *handle, size_t count, const size_t *off0,
+                                              const size_t *n0, const size_t *off1, const size_t *n1,
+                                              const void *const *scalars, int scalars_on_device, int scalars_montgomery,
+                                              int window_bits);
 
 /* out (144 B) = sum of n G1Projective points (host buffers).  Combines the per-device partial results of an MSM whose
  * point range was split over several GPUs (the host `dadd` loop of snarkvm.cu:290-295). */
@@ -169,6 +191,11 @@ RustError snarkvm_hip_register_bases_g2(snarkvm_hip_bases_g2_t **handle, const v
 void snarkvm_hip_free_bases_g2(snarkvm_hip_bases_g2_t *handle);
 RustError snarkvm_hip_msm_g2_registered(void *out, const snarkvm_hip_bases_g2_t *handle, size_t offset, size_t npoints,
                                         const void *scalars, int scalars_on_device, int window_bits);
+/* A batch of independent G2 MSMs over one registered vector, fanned out over devices and lanes like
+ * snarkvm_hip_msm_registered_batch; results are written to outs + 288 * k. */
+RustError snarkvm_hip_msm_g2_registered_batch(void *outs, const snarkvm_hip_bases_g2_t *handle, size_t count,
+                                              const size_t *offsets, const size_t *npoints, const void *const *scalars,
+                                              int scalars_on_device, int window_bits);
 
 /* Setup-time group operations.  Host buffers.
  * fixed_base_msm: out[i] (G1Projective, 144 B) = scalars[i] * g for one base `g` (Rust G1Affine, 104 B) and n Fr
@@ -216,14 +243,14 @@ RustError snarkvm_hip_fr_mul_by_vanishing(void *out, const void *poly, size_t le
  * device memory. */
 RustError snarkvm_hip_g1_generate_bases_device(void *d_out, uint64_t start, size_t npoints);
 
-/* Per-phase timing of the most recent MSM / NTT call, measured with HIP events on the stream the
- * kernels were launched on.  Enable first; then read `count` (name, milliseconds) pairs. */
+/* Per-phase timing of the most recent profiled MSM / NTT call (synchronous single-lane calls), measured with HIP events on
+ * the stream the kernels were launched on.  Enable first; then read `count` (name, milliseconds) pairs. */
 void snarkvm_hip_set_profiling(int enabled);
 int snarkvm_hip_get_phase_count(void);
 const char *snarkvm_hip_get_phase_name(int i);
 double snarkvm_hip_get_phase_ms(int i);
 
-/* Block until all queued work of the context has finished. */
+/* Block until all queued work of every device in use has finished. */
 RustError snarkvm_hip_synchronize(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -242,6 +269,10 @@ int snarkvm_hip_selftest_g1_msm_naive(const void *points_with_infinity, size_t n
 /* The MSM planner (window width, windows, digit rows, buckets, segment length) evaluated on the host:
  * out[10] = {c, W, J, digit rows, buckets per window, total buckets, S, S2, L, wide}.  Returns 0 if consistent. */
 int snarkvm_hip_selftest_msm_plan(size_t n, int window_bits, int tables, int table_bits, uint32_t *out);
+/* The host-side finish of an MSM on its own (no device): out (144 B) = sum_i 2^pos[i] * planes[i] over n G1Projective
+ * memory images - the Horner chain that combines the bit-plane sums the device leaves (and the per-device partial results of
+ * a split MSM, the reference's host `dadd`, snarkvm.cu:290-295).  Returns 0. */
+int snarkvm_hip_selftest_g1_finish(const void *planes_projective, const int32_t *pos, size_t n, void *out);
 /* Same field operations executed by a GPU kernel (one thread per element). */
 RustError snarkvm_hip_devtest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
 

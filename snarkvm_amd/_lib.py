@@ -12,19 +12,19 @@ LIB_PATH = os.environ.get("SNARKVM_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 # every symbol include/snarkvm_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm",
-    "snarkvm_hip_device_count", "snarkvm_hip_batch_lanes", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
+    "snarkvm_hip_device_count", "snarkvm_hip_batch_lanes", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_num_devices", "snarkvm_hip_ntt_device",
     "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_free_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2",
-    "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_g1_to_affine",
+    "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine",
     "snarkvm_hip_fr_mul_device", "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device",
     "snarkvm_hip_fr_vec_op", "snarkvm_hip_fr_divide_by_linear", "snarkvm_hip_fr_batch_inversion_and_mul",
     "snarkvm_hip_fr_distribute_powers", "snarkvm_hip_fr_lagrange_coefficients", "snarkvm_hip_fr_divide_by_vanishing",
     "snarkvm_hip_fr_mul_by_vanishing",
     "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum", "snarkvm_hip_g2_deserialize", "snarkvm_hip_g2_serialize",
-    "snarkvm_hip_register_bases_g2", "snarkvm_hip_free_bases_g2", "snarkvm_hip_msm_g2_registered",
+    "snarkvm_hip_register_bases_g2", "snarkvm_hip_free_bases_g2", "snarkvm_hip_msm_g2_registered", "snarkvm_hip_msm_g2_registered_batch",
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize",
-    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_devtest_field",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_devtest_field",
 ]
 
 
@@ -59,18 +59,20 @@ def lib():
         except ImportError:
             pass
         L = ctypes.CDLL(LIB_PATH)
-        err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_ntt_device",
-                   "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
+        err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_ntt_device",
+                   "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
                    "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device", "snarkvm_hip_synchronize",
                    "snarkvm_hip_fr_vec_op", "snarkvm_hip_fr_divide_by_linear", "snarkvm_hip_fr_batch_inversion_and_mul", "snarkvm_hip_fr_distribute_powers", "snarkvm_hip_fr_lagrange_coefficients", "snarkvm_hip_fr_divide_by_vanishing", "snarkvm_hip_fr_mul_by_vanishing",
                    "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum", "snarkvm_hip_g2_deserialize", "snarkvm_hip_g2_serialize",
-                   "snarkvm_hip_register_bases_g2", "snarkvm_hip_msm_g2_registered",
+                   "snarkvm_hip_register_bases_g2", "snarkvm_hip_msm_g2_registered", "snarkvm_hip_msm_g2_registered_batch",
                    "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
                    "snarkvm_hip_devtest_field"]
         for name in err_fns:
             getattr(L, name).restype = RustError
         L.snarkvm_hip_device_count.restype = ctypes.c_int
         L.snarkvm_hip_batch_lanes.restype = ctypes.c_int
+        L.snarkvm_hip_num_devices.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_g1_finish.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_count.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_name.restype = ctypes.c_char_p
         L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsnarkvm_hip.so")
-SOURCES = ["api.hip", "api_fr.hip", "api_g2.hip"]  # compiled in parallel (the Fq2 instantiations are half of the compile time), then linked
+SOURCES = ["api.hip", "api_fr.hip", "api_g2.hip", "api_serde.hip"]  # compiled in parallel (the Fq2 instantiations are half of the compile time), then linked
 
 
 def _inputs():

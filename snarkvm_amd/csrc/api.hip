@@ -1,12 +1,13 @@
-// api.hip - C ABI (include/snarkvm_hip.h) of the gfx950 MSM / NTT backend: the G1 / Fr entry points.
+// api.hip - C ABI (include/snarkvm_hip.h) of the gfx950 MSM / NTT backend: runtime configuration and the G1 MSM entry points.
 //
 // Host runtime (runtime.hip.h) = what algorithms/cuda/cuda/snarkvm.cu:73-312 (snarkvm_t) and snarkvm_api.cu:23-84 are in the
-// reference: a lazily constructed per-process context (device arenas, streams, twiddle tables), staging of the caller's host
-// buffers, error reporting as RustError, serialisation of concurrent callers.  The G2 entry points live in api_g2.hip.
-#define SV_TU_MSM_G1
+// reference: a lazily constructed per-process runtime over every selected GPU (device arenas, streams, twiddle tables), a
+// pool of (device, stream) resource tokens handed to concurrent callers, staging of the caller's host buffers, the
+// point-range split of one MSM over the GPUs with a host-side combine, error reporting as RustError.
+// Fr entry points: api_fr.hip; point encoding + setup-time group operations: api_serde.hip; G2: api_g2.hip.
 #include "runtime.hip.h"
 
-context_t g_ctx;
+runtime_t g_rt;
 
 extern "C" {
 
@@ -15,336 +16,422 @@ int snarkvm_hip_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-int snarkvm_hip_batch_lanes(size_t npoints) { return context_t::batch_lanes(npoints); }
-RustError snarkvm_hip_set_device(int device) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (g_ctx.ready && g_ctx.device != device) return fail(1, "snarkvm_hip_set_device: context already initialised on another device");
-    g_ctx.device = device;
+int snarkvm_hip_batch_lanes(size_t npoints) { return batch_lanes(npoints); }
+// Select the devices this process uses (before the first compute call).  Duplicated ids make independent logical devices on
+// one GPU (tests).  snarkvm_hip_set_device(d) == set_devices(&d, 1): the one-process-per-GPU deployment.
+RustError snarkvm_hip_set_devices(const int32_t* ids, size_t n) {
+    std::lock_guard<std::mutex> lk(g_rt.cfg_mu);
+    if (n == 0 || !ids) return fail(1, "snarkvm_hip_set_devices: empty device list");
+    std::vector<int> v(ids, ids + n);
+    if (g_rt.configured) {
+        bool same = v.size() == g_rt.devs.size();
+        for (size_t i = 0; same && i < v.size(); i++) same = g_rt.devs[i]->physical == v[i];
+        if (!same) return fail(1, "snarkvm_hip_set_devices: the runtime is already initialised on another device set");
+        return ok();
+    }
+    g_rt.want = v;
     return ok();
 }
-void snarkvm_hip_set_profiling(int enabled) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    g_ctx.profiling = enabled != 0;
+RustError snarkvm_hip_set_device(int device) {
+    const int32_t d = device;
+    return snarkvm_hip_set_devices(&d, 1);
 }
-int snarkvm_hip_get_phase_count(void) { return (int)g_ctx.phases.size(); }
-const char* snarkvm_hip_get_phase_name(int i) { return (i >= 0 && i < (int)g_ctx.phases.size()) ? g_ctx.phases[i].name : ""; }
-double snarkvm_hip_get_phase_ms(int i) { return (i >= 0 && i < (int)g_ctx.phases.size()) ? g_ctx.phases[i].ms : 0.0; }
+int snarkvm_hip_num_devices(void) {
+    try {
+        return g_rt.ndev();
+    } catch (...) {
+        return 0;
+    }
+}
+void snarkvm_hip_set_profiling(int enabled) { g_rt.profiling.store(enabled != 0); }
+int snarkvm_hip_get_phase_count(void) {
+    std::lock_guard<std::mutex> lk(g_rt.prof_mu);
+    return (int)g_rt.last_phases.size();
+}
+const char* snarkvm_hip_get_phase_name(int i) {
+    std::lock_guard<std::mutex> lk(g_rt.prof_mu);
+    return (i >= 0 && i < (int)g_rt.last_phases.size()) ? g_rt.last_phases[i].first.c_str() : "";
+}
+double snarkvm_hip_get_phase_ms(int i) {
+    std::lock_guard<std::mutex> lk(g_rt.prof_mu);
+    return (i >= 0 && i < (int)g_rt.last_phases.size()) ? g_rt.last_phases[i].second : 0.0;
+}
 
 RustError snarkvm_hip_synchronize(void) {
-    API_BEGIN
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    API_END
+    API_TRY
+    g_rt.configure();
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (auto& d : g_rt.devs) {
+        if (!d->ready) continue;
+        HIP_TRY(hipSetDevice(d->physical));
+        for (auto& l : d->lane) {
+            HIP_TRY(hipStreamSynchronize(l.stream));
+            HIP_TRY(hipStreamSynchronize(l.alt));
+        }
+    }
+    (void)hipSetDevice(prev);
+    API_CATCH
 }
 
-// ---- MSM ---------------------------------------------------------------------------------------
-// ---- optional base cache behind the unmodified FFI -------------------------------------------------
-// The reference's callers pass slices of ONE long-lived vector (`powers_of_beta_g[lz .. lz + len]`, kzg10/mod.rs:117-119)
-// and its GPU path re-uploads them on every call.  With SNARKVM_HIP_BASE_CACHE=<tables> (1, 2, 4, 8 or 16; unset = off) a
-// call whose base range lies inside a range seen before reuses the device copy (with `tables` precomputed multiples):
-// no upload, no conversion, no Horner chain.  A hit is verified against raw copies of every CACHE_STEP-th point of the
-// slice; a mismatch drops the entry.  Host pointers are only compared, never dereferenced outside the call that passed
-// them.  At most CACHE_MAX ranges are kept (least recently used goes first).
+// ---- registered bases ---------------------------------------------------------------------------------
+// tables 1 .. J-1 of one replica: table j = 2^table_bits * table j-1
+static void precompute_tables(lane_t& c, snarkvm_hip_bases* h, g1_aff_mem_t* d) {
+    for (int j = 1; j < h->tables; j++)
+        hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, c.stream, d + (size_t)(j - 1) * h->n,
+                           d + (size_t)j * h->n, h->n, h->table_bits);
+    HIP_TRY(hipGetLastError());
+}
+// One replica per logical device.  Host source: every device uploads and converts for itself (in parallel).  Device source:
+// the owner converts and precomputes, the other devices receive the finished tables by peer copies over xGMI.
 static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables,
-                                int table_bits);
+                                int table_bits) {
+    if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
+    if (npoints && !points) throw hip_failure{hipErrorInvalidValue, "register_bases: null points", __LINE__};
+    if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
+    check_tables(tables, table_bits, "register_bases");
+    const int nd = g_rt.ndev();
+    std::unique_ptr<snarkvm_hip_bases> h(new snarkvm_hip_bases());
+    h->n = npoints;
+    h->tables = tables;
+    h->table_bits = table_bits ? table_bits : 256 / tables;
+    h->d.assign(nd, nullptr);
+    const size_t bytes = (size_t)tables * npoints * sizeof(g1_aff_mem_t);
+    try {
+        if (npoints) {
+            const int owner = on_device ? device_for(points, 1) : -1;
+            auto build = [&](int dev) {
+                lane_guard lg(dev);
+                lane_t& c = lg.c();
+                HIP_TRY(hipMalloc((void**)&h->d[dev], bytes));
+                const uint8_t* src = (const uint8_t*)points;
+                if (!on_device) {
+                    c.bases_tmp.ensure(npoints * ffi_affine_sz);
+                    HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, c.stream));
+                    src = c.bases_tmp.as<uint8_t>();
+                }
+                convert_bases<fq_t>(c, src, ffi_affine_sz, npoints, h->d[dev]);
+                precompute_tables(c, h.get(), h->d[dev]);
+                HIP_TRY(hipStreamSynchronize(c.stream));
+            };
+            std::vector<int> all;
+            for (int d = 0; d < nd; d++) all.push_back(d);
+            if (!on_device) {
+                for_each_device(all, build);
+            } else {
+                build(owner);
+                for (int d = 0; d < nd; d++) {
+                    if (d == owner) continue;
+                    lane_guard lg(d);
+                    HIP_TRY(hipMalloc((void**)&h->d[d], bytes));
+                    HIP_TRY(hipMemcpyPeerAsync(h->d[d], g_rt.devs[d]->physical, h->d[owner], g_rt.devs[owner]->physical, bytes, lg.c().stream));
+                    HIP_TRY(hipStreamSynchronize(lg.c().stream));
+                }
+            }
+        }
+    } catch (...) {
+        h->free_all();
+        throw;
+    }
+    *handle = h.release();
+}
+RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
+    API_TRY
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, 1, 0);
+    API_CATCH
+}
+RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
+                                            int tables) {
+    API_TRY
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables, 0);
+    API_CATCH
+}
+RustError snarkvm_hip_register_bases_windowed(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
+                                              int tables, int window_bits) {
+    API_TRY
+    if (window_bits <= 0) throw hip_failure{hipErrorInvalidValue, "register_bases_windowed: window_bits must be positive", __LINE__};
+    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables, window_bits);
+    API_CATCH
+}
+void snarkvm_hip_free_bases(snarkvm_hip_bases_t* h) {
+    if (!h) return;
+    h->free_all();
+    delete h;
+}
+}  // extern "C"
+// handle construction shared with api_serde.hip (bases decoded from their canonical bytes); C++ linkage
+snarkvm_hip_bases* sv_new_bases_handle(size_t npoints, int tables, int table_bits) {
+    snarkvm_hip_bases* h = new snarkvm_hip_bases();
+    h->n = npoints;
+    h->tables = tables;
+    h->table_bits = table_bits;
+    h->d.assign(g_rt.ndev(), nullptr);
+    return h;
+}
+void sv_precompute_tables(lane_t& c, snarkvm_hip_bases* h, g1_aff_mem_t* d) { precompute_tables(c, h, d); }
+extern "C" {
+
+// ---- MSM over registered bases ----------------------------------------------------------------------------
+static void check_window_bits(int window_bits, const char* who) {
+    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw std::runtime_error(std::string(who) + ": window_bits must be 0 or 2..23");
+}
+// One MSM over a registered range with HOST scalars, split by point range over the devices when it is big enough (the
+// reference's multi-GPU MSM, snarkvm.cu:254-295): device d sums its n / ndev pairs over its own replica with the full
+// window set; the per-device bit-plane sums are added on the host before the one Horner chain.  (off1, n1): KZG10's second
+// base range (see snarkvm_hip_msm_registered_ex).
+static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, size_t off0, size_t n0, size_t off1, size_t n1, const void* scalars,
+                                        int scalars_montgomery, int window_bits) {
+    const size_t n = n0 + n1;
+    const int nd = g_rt.ndev();
+    int parts = (int)(n / MSM_SPLIT_MIN);
+    if (parts > nd) parts = nd;
+    if (parts < 1) parts = 1;
+    std::unique_ptr<msm_accum_t<fq_t>> acc(new msm_accum_t<fq_t>());
+    std::mutex acc_mu;
+    std::vector<int> devs;
+    if (parts == 1) {
+        devs.push_back(-1);  // any device with a free lane
+    } else {
+        for (int d = 0; d < parts; d++) devs.push_back(d);
+    }
+    for_each_device(devs, [&](int dev) {
+        const size_t part = parts == 1 ? 0 : (size_t)dev;
+        const size_t lo = n * part / parts, hi = n * (part + 1) / parts, cnt = hi - lo;
+        lane_guard lg(dev);
+        lane_t& c = lg.c();
+        c.begin_call();
+        const g1_aff_mem_t* base = h->d[c.dev->logical];
+        // slice [lo, hi) of the concatenation (range 0 | range 1)
+        const size_t a0 = lo < n0 ? lo : n0, a1 = hi < n0 ? hi : n0;  // part inside range 0
+        const size_t m0 = a1 - a0;
+        const g1_aff_mem_t* b0 = base + off0 + a0;
+        const g1_aff_mem_t* b1 = base + off1 + (lo > n0 ? lo - n0 : 0);
+        c.scalars_tmp.ensure(cnt * 32 + 32);
+        c.phase_begin("msm_h2d");
+        if (cnt) HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, c.stream));
+        c.phase_end();
+        c.pin.ensure(msm_plane_bytes<fq_t>());
+        const msm_pending_t pd = msm_run<fq_t>(c, m0 ? b0 : b1, c.scalars_tmp.as<uint4>(), cnt, c.pin.p, window_bits, b1, m0 ? m0 : ~(size_t)0,
+                                               scalars_montgomery, h->tables, h->n, parts == 1, h->table_bits);
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        {
+            std::lock_guard<std::mutex> lk(acc_mu);
+            msm_collect<fq_t>(*acc, pd);
+        }
+        c.end_call();
+    });
+    acc->finish(out);
+}
+RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, size_t offset, size_t npoints, const void* scalars,
+                                     int scalars_on_device, int window_bits) {
+    API_TRY
+    if (!h || offset + npoints > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered: range exceeds the registered bases", __LINE__};
+    check_window_bits(window_bits, "msm_registered");
+    if (!out || (npoints && !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered: null argument", __LINE__};
+    if (!scalars_on_device) {
+        msm_registered_host_scalars(out, h, offset, npoints, 0, 0, scalars, 0, window_bits);
+    } else {
+        lane_guard lg(device_for(scalars, npoints ? 1 : 0));
+        lane_t& c = lg.c();
+        c.begin_call();
+        msm_run_sync<fq_t>(c, h->d[c.dev->logical] + offset, (const uint4*)scalars, npoints, out, window_bits, nullptr, ~(size_t)0, 0, h->tables, h->n,
+                           h->table_bits);
+        c.end_call();
+    }
+    API_CATCH
+}
+RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h, size_t off0, size_t n0, size_t off1, size_t n1,
+                                        const void* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    API_TRY
+    if (!h || off0 + n0 > h->n || off1 + n1 > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: range exceeds the registered bases", __LINE__};
+    check_window_bits(window_bits, "msm_registered_ex");
+    const size_t n = n0 + n1;
+    if (!out || (n && !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: null argument", __LINE__};
+    if (!scalars_on_device) {
+        msm_registered_host_scalars(out, h, off0, n0, off1, n1, scalars, scalars_montgomery, window_bits);
+    } else {
+        lane_guard lg(device_for(scalars, n ? 1 : 0));
+        lane_t& c = lg.c();
+        c.begin_call();
+        const g1_aff_mem_t* base = h->d[c.dev->logical];
+        msm_run_sync<fq_t>(c, base + off0, (const uint4*)scalars, n, out, window_bits, base + off1, n0, scalars_montgomery, h->tables, h->n, h->table_bits);
+        c.end_call();
+    }
+    API_CATCH
+}
+
+// A batch of independent MSMs (the commitments of a batch of proofs) fanned out over devices x lanes.  Host scalars:
+// instance k goes to device k mod ndev; device scalars: to the device that owns them.  On each device the instances cycle
+// over several lanes, so the latency-bound tail of one overlaps the accumulation of the next; the host finishes instance k
+// (Horner over its bit planes) as soon as its planes have arrived, while the GPU works on the later instances.
+RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t* h, size_t count, const size_t* offsets, const size_t* npoints,
+                                           const void* const* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    API_TRY
+    if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null handle", __LINE__};
+    check_window_bits(window_bits, "msm_registered_batch");
+    if (count && (!outs || !offsets || !npoints || !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null argument", __LINE__};
+    msm_batch_run<fq_t>(outs, *h, count, offsets, npoints, scalars, scalars_on_device, scalars_montgomery, window_bits);
+    API_CATCH
+}
+
+// The same with two base ranges per instance (KZG10::commit with hiding / SonicKZG10::commit's degree-bounded polynomials:
+// instance k = bases [off0[k], + n0[k]) then [off1[k], + n1[k]), n0 + n1 consecutive scalars).
+RustError snarkvm_hip_msm_registered_batch_ex(void* outs, const snarkvm_hip_bases_t* h, size_t count, const size_t* off0, const size_t* n0,
+                                              const size_t* off1, const size_t* n1, const void* const* scalars, int scalars_on_device,
+                                              int scalars_montgomery, int window_bits) {
+    API_TRY
+    if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch_ex: null handle", __LINE__};
+    check_window_bits(window_bits, "msm_registered_batch_ex");
+    if (count && (!outs || !off0 || !n0 || !off1 || !n1 || !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch_ex: null argument", __LINE__};
+    msm_batch_run<fq_t>(outs, *h, count, off0, n0, scalars, scalars_on_device, scalars_montgomery, window_bits, off1, n1);
+    API_CATCH
+}
+
+// ---- the reference's FFI MSM (host bases + host scalars) -----------------------------------------------------------------
+// Base cache behind the unmodified FFI.  The reference's callers pass slices of ONE long-lived vector
+// (`powers_of_beta_g[lz .. lz + len]`, kzg10/mod.rs:117-119) and its GPU path re-uploads them on every call.  Here a host
+// range that is seen a SECOND time is registered (converted, with 16 precomputed tables, on every device) and later calls
+// whose base range lies inside it skip the upload, the conversion and most of the Horner chain.  A hit is verified against
+// raw copies of every CACHE_STEP-th point of the range that falls inside the requested slice (a slice > 1024 points always
+// contains at least 16 of them); a mismatch drops the entry.  Host pointers are only compared, never dereferenced outside
+// the call that passed them.  SNARKVM_HIP_BASE_CACHE=0 turns it off, =<tables> selects 1 / 2 / 4 / 8 / 16 tables;
+// SNARKVM_HIP_BASE_CACHE_MB caps the device bytes per device (default 65536); least recently used ranges go first.
 struct base_cache_entry {
     const uint8_t* host = nullptr;
     size_t n = 0, stride = 0;
-    snarkvm_hip_bases* h = nullptr;
-    std::vector<uint8_t> samples;  // 97 bytes (x, y, infinity) of points 0, CACHE_STEP, 2 * CACHE_STEP, ...
+    std::shared_ptr<snarkvm_hip_bases> h;  // null: seen once, not registered yet (shared: a running call keeps a dropped entry's tables alive)
+    std::vector<uint8_t> samples;     // 97 bytes (x, y, infinity) of points 0, CACHE_STEP, 2 * CACHE_STEP, ...
     uint64_t last_use = 0;
+    size_t bytes() const { return h ? (size_t)h->tables * h->n * sizeof(g1_aff_mem_t) : 0; }
 };
-static constexpr size_t CACHE_STEP = 4096, CACHE_MAX = 4;
+static constexpr size_t CACHE_STEP = 64, CACHE_MAX = 8;
+static std::mutex g_cache_mu;
 static std::vector<base_cache_entry> g_base_cache;
 static uint64_t g_cache_tick = 0;
 static int base_cache_tables() {
-    static const int t = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 0;
+    static const int t = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 16;
     return (t == 1 || t == 2 || t == 4 || t == 8 || t == 16) ? t : 0;
 }
-static void base_cache_drop(size_t i) {
-    if (g_base_cache[i].h) {
-        if (g_base_cache[i].h->d) (void)hipFree(g_base_cache[i].h->d);
-        delete g_base_cache[i].h;
-    }
-    g_base_cache.erase(g_base_cache.begin() + (long)i);
+static size_t base_cache_cap() {
+    static const size_t mb = getenv("SNARKVM_HIP_BASE_CACHE_MB") ? (size_t)atoll(getenv("SNARKVM_HIP_BASE_CACHE_MB")) : 65536;
+    return mb << 20;
 }
-// registered handle + offset covering [points, points + npoints * stride), registering the range on a miss
-static const snarkvm_hip_bases* base_cache_lookup(const void* points, size_t npoints, size_t stride, size_t& offset) {
+static void base_cache_drop(size_t i) { g_base_cache.erase(g_base_cache.begin() + (long)i); }
+// every sampled point of [off, off + npoints) still equals its raw copy
+static bool samples_match(const base_cache_entry& e, size_t off, size_t npoints) {
+    if (!npoints) return false;
+    const size_t k0 = (off + CACHE_STEP - 1) / CACHE_STEP, k1 = (off + npoints - 1) / CACHE_STEP;  // sample indices inside the slice
+    if (k0 > k1) return false;                                                                     // no sample inside: cannot vouch for it
+    for (size_t k = k0; k <= k1; k++)
+        if (memcmp(&e.samples[k * 97], e.host + k * CACHE_STEP * e.stride, 97) != 0) return false;
+    return true;
+}
+// registered handle + offset covering [points, points + npoints * stride); nullptr: use the uncached path this time
+static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, size_t npoints, size_t stride, size_t& offset) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
     const uint8_t* p = (const uint8_t*)points;
     for (size_t i = 0; i < g_base_cache.size(); i++) {
-        base_cache_entry& e = g_base_cache[i];
-        if (e.stride != stride || p < e.host || p + npoints * stride > e.host + e.n * stride || (size_t)(p - e.host) % stride) continue;
-        const size_t off = (size_t)(p - e.host) / stride;
-        bool same = true;
-        for (size_t k = (off + CACHE_STEP - 1) / CACHE_STEP; k * CACHE_STEP < off + npoints && same; k++)
-            same = memcmp(&e.samples[k * 97], e.host + k * CACHE_STEP * stride, 97) == 0;
-        if (!same) {  // the memory behind a cached range changed: forget it
+        if (g_base_cache[i].stride != stride || p < g_base_cache[i].host || p + npoints * stride > g_base_cache[i].host + g_base_cache[i].n * stride ||
+            (size_t)(p - g_base_cache[i].host) % stride)
+            continue;
+        const size_t off = (size_t)(p - g_base_cache[i].host) / stride;
+        if (!samples_match(g_base_cache[i], off, npoints)) {  // the memory behind the range changed: forget it
             base_cache_drop(i);
             break;
         }
-        e.last_use = ++g_cache_tick;
+        g_base_cache[i].last_use = ++g_cache_tick;
+        if (!g_base_cache[i].h) {  // second sighting: register the whole remembered range (all of it is verified first)
+            if (!samples_match(g_base_cache[i], 0, g_base_cache[i].n)) {
+                base_cache_drop(i);
+                break;
+            }
+            const size_t need = (size_t)base_cache_tables() * g_base_cache[i].n * sizeof(g1_aff_mem_t);
+            if (need > base_cache_cap()) return nullptr;
+            for (;;) {  // make room: least recently used registered entries go first
+                size_t used = 0, lru = (size_t)-1;
+                for (size_t j = 0; j < g_base_cache.size(); j++) {
+                    used += g_base_cache[j].bytes();
+                    if (j != i && g_base_cache[j].h && (lru == (size_t)-1 || g_base_cache[j].last_use < g_base_cache[lru].last_use)) lru = j;
+                }
+                if (used + need <= base_cache_cap() || lru == (size_t)-1) break;
+                base_cache_drop(lru);
+                if (lru < i) i--;
+            }
+            snarkvm_hip_bases_t* nh = nullptr;
+            // throws on failure: nothing leaks, the entry stays unregistered
+            register_bases_impl(&nh, g_base_cache[i].host, g_base_cache[i].n, g_base_cache[i].stride, 0, base_cache_tables(), 0);
+            g_base_cache[i].h = std::shared_ptr<snarkvm_hip_bases>(nh, [](snarkvm_hip_bases* b) { snarkvm_hip_free_bases(b); });
+        }
         offset = off;
-        return e.h;
+        return g_base_cache[i].h;
     }
+    // first sighting: remember the range (a bigger range supersedes the ranges it contains)
+    for (size_t i = g_base_cache.size(); i-- > 0;)
+        if (g_base_cache[i].stride == stride && g_base_cache[i].host >= p && g_base_cache[i].host + g_base_cache[i].n * stride <= p + npoints * stride)
+            base_cache_drop(i);
     while (g_base_cache.size() >= CACHE_MAX) {
         size_t lru = 0;
         for (size_t i = 1; i < g_base_cache.size(); i++)
             if (g_base_cache[i].last_use < g_base_cache[lru].last_use) lru = i;
         base_cache_drop(lru);
     }
-    // a slice of a bigger vector may come first: ranges that the new one contains are superseded
-    for (size_t i = g_base_cache.size(); i-- > 0;)
-        if (g_base_cache[i].stride == stride && g_base_cache[i].host >= p && g_base_cache[i].host + g_base_cache[i].n * stride <= p + npoints * stride)
-            base_cache_drop(i);
     base_cache_entry e;
     e.host = p;
     e.n = npoints;
     e.stride = stride;
-    register_bases_impl(&e.h, points, npoints, stride, 0, base_cache_tables(), 0);
-    for (size_t k = 0; k * CACHE_STEP < npoints; k++) e.samples.insert(e.samples.end(), p + k * CACHE_STEP * stride, p + k * CACHE_STEP * stride + 97);
+    for (size_t k = 0; k * CACHE_STEP < e.n; k++) e.samples.insert(e.samples.end(), e.host + k * CACHE_STEP * e.stride, e.host + k * CACHE_STEP * e.stride + 97);
     e.last_use = ++g_cache_tick;
-    g_base_cache.push_back(e);
-    offset = 0;
-    return g_base_cache.back().h;
+    g_base_cache.push_back(std::move(e));
+    return nullptr;
 }
 
 RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
-    API_BEGIN
-    if (base_cache_tables() && npoints > 1024 && ffi_affine_sz >= 104 && !(ffi_affine_sz & 7)) {
-        size_t offset = 0;
-        const snarkvm_hip_bases* h = base_cache_lookup(points, npoints, ffi_affine_sz, offset);
-        g_ctx.scalars_tmp.ensure(npoints * 32);
-        g_ctx.phase_begin("msm_h2d");
-        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, g_ctx.stream));
-        g_ctx.phase_end();
-        msm_run<fq_t>(g_ctx, h->d + offset, g_ctx.scalars_tmp.as<uint4>(), npoints, out, 0, nullptr, ~(size_t)0, 0, h->tables, h->n, 0, true, h->table_bits);
+    API_TRY
+    if (!out) throw hip_failure{hipErrorInvalidValue, "msm: null output", __LINE__};
+    g_rt.configure();  // no device: an error, never a silent host result
+    if (npoints == 0) {
+        write_infinity<fq_t>(out);
     } else {
-        msm_host<fq_t>(g_ctx, out, points, npoints, scalars, ffi_affine_sz);
+        if (!points || !scalars) throw hip_failure{hipErrorInvalidValue, "msm: null argument", __LINE__};
+        std::shared_ptr<snarkvm_hip_bases> h;
+        size_t offset = 0;
+        if (base_cache_tables() && npoints > 1024 && ffi_affine_sz >= 104 && !(ffi_affine_sz & 7)) h = base_cache_lookup(points, npoints, ffi_affine_sz, offset);
+        if (h)
+            msm_registered_host_scalars(out, h.get(), offset, npoints, 0, 0, scalars, 0, 0);
+        else
+            msm_host_chunked<fq_t>(out, points, npoints, scalars, ffi_affine_sz);
     }
-    API_END
+    API_CATCH
 }
 
-// tables 1 .. J-1 of a registered base vector: table j = 2^(256 / J) * table j-1
-static void precompute_tables(snarkvm_hip_bases* h) {
-    for (int j = 1; j < h->tables; j++)
-        hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, g_ctx.stream,
-                           h->d + (size_t)(j - 1) * h->n, h->d + (size_t)j * h->n, h->n, h->table_bits);
-    HIP_TRY(hipGetLastError());
-}
-static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables,
-                                int table_bits) {
-    if (!handle) throw hip_failure{hipErrorInvalidValue, "register_bases: null handle", __LINE__};
-    if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
-    check_tables(tables, table_bits, "register_bases");
-    snarkvm_hip_bases* h = new snarkvm_hip_bases();
-    h->n = npoints;
-    h->tables = tables;
-    h->table_bits = table_bits ? table_bits : 256 / tables;
-    if (npoints) {
-        HIP_TRY(hipMalloc((void**)&h->d, (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
-        const uint8_t* src = (const uint8_t*)points;
-        if (!on_device) {
-            g_ctx.bases_tmp.ensure(npoints * ffi_affine_sz);
-            HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
-            src = g_ctx.bases_tmp.as<uint8_t>();
-        }
-        convert_bases<fq_t>(g_ctx, src, ffi_affine_sz, npoints, h->d);
-        precompute_tables(h);
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    }
-    *handle = h;
-}
-
-// ---- canonical (de)serialisation of G1 points (serde.hip.h) ---------------------------------------
-// bytes (host) -> native base slots and / or Rust-layout records (both device); returns the SERDE_* status bits
-static uint32_t g1_deserialize_run(const void* bytes, size_t n, int compressed, int validate, g1_aff_mem_t* d_native, uint8_t* d_rust) {
-    const size_t psz = compressed ? 48 : 96;
-    g_ctx.bases_tmp.ensure(n * psz);
-    g_ctx.serde_status.ensure(4);
-    HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, bytes, n * psz, hipMemcpyHostToDevice, g_ctx.stream));
-    HIP_TRY(hipMemsetAsync(g_ctx.serde_status.p, 0, 4, g_ctx.stream));
-    hipLaunchKernelGGL(g1_deserialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, g_ctx.bases_tmp.as<uint8_t>(), n, compressed,
-                       validate, d_native, d_rust, g_ctx.serde_status.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-    uint32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, g_ctx.serde_status.p, 4, hipMemcpyDeviceToHost, g_ctx.stream));
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    return st;
-}
-RustError snarkvm_hip_register_bases_serialized(snarkvm_hip_bases_t** handle, const void* bytes, size_t npoints, int compressed, int validate,
-                                                int tables) {
-    API_BEGIN
-    if (!handle || (npoints && !bytes)) throw hip_failure{hipErrorInvalidValue, "register_bases_serialized: null argument", __LINE__};
-    check_tables(tables, 0, "register_bases_serialized");
-    snarkvm_hip_bases* h = new snarkvm_hip_bases();
-    h->n = npoints;
-    h->tables = tables;
-    h->table_bits = 256 / tables;
-    if (npoints) {
-        try {
-            HIP_TRY(hipMalloc((void**)&h->d, (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
-            serde_throw_on_status(g1_deserialize_run(bytes, npoints, compressed, validate, h->d, nullptr), "register_bases_serialized");
-            precompute_tables(h);
-            HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-        } catch (...) {
-            if (h->d) (void)hipFree(h->d);
-            delete h;
-            throw;
-        }
-    }
-    *handle = h;
-    API_END
-}
-RustError snarkvm_hip_g1_deserialize(void* out_affine, const void* bytes, size_t n, int compressed, int validate) {
-    API_BEGIN
-    if (n) {
-        if (!out_affine || !bytes) throw hip_failure{hipErrorInvalidValue, "g1_deserialize: null argument", __LINE__};
-        g_ctx.poly[0].ensure(n * 104);
-        const uint32_t st = g1_deserialize_run(bytes, n, compressed, validate, nullptr, g_ctx.poly[0].as<uint8_t>());
-        serde_throw_on_status(st, "g1_deserialize");
-        HIP_TRY(hipMemcpyAsync(out_affine, g_ctx.poly[0].p, n * 104, hipMemcpyDeviceToHost, g_ctx.stream));
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    }
-    API_END
-}
-RustError snarkvm_hip_g1_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz, int compressed) {
-    API_BEGIN
-    if (n) {
-        if (!out_bytes || !affine) throw hip_failure{hipErrorInvalidValue, "g1_serialize: null argument", __LINE__};
-        if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "g1_serialize: bad stride", __LINE__};
-        const size_t psz = compressed ? 48 : 96;
-        g_ctx.bases_tmp.ensure(n * ffi_affine_sz);
-        g_ctx.poly[0].ensure(n * psz);
-        HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, affine, n * ffi_affine_sz, hipMemcpyHostToDevice, g_ctx.stream));
-        hipLaunchKernelGGL(g1_serialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, g_ctx.bases_tmp.as<uint8_t>(), ffi_affine_sz, n,
-                           compressed, g_ctx.poly[0].as<uint8_t>());
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out_bytes, g_ctx.poly[0].p, n * psz, hipMemcpyDeviceToHost, g_ctx.stream));
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    }
-    API_END
-}
-RustError snarkvm_hip_register_bases(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device) {
-    API_BEGIN
-    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, 1, 0);
-    API_END
-}
-RustError snarkvm_hip_register_bases_tables(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
-                                            int tables) {
-    API_BEGIN
-    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables, 0);
-    API_END
-}
-RustError snarkvm_hip_register_bases_windowed(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device,
-                                              int tables, int window_bits) {
-    API_BEGIN
-    if (window_bits <= 0) throw hip_failure{hipErrorInvalidValue, "register_bases_windowed: window_bits must be positive", __LINE__};
-    register_bases_impl(handle, points, npoints, ffi_affine_sz, on_device, tables, window_bits);
-    API_END
-}
-void snarkvm_hip_free_bases(snarkvm_hip_bases_t* h) {
-    if (!h) return;
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (h->d) (void)hipFree(h->d);
-    delete h;
-}
-RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, size_t offset, size_t npoints, const void* scalars,
-                                     int scalars_on_device, int window_bits) {
-    API_BEGIN
-    if (!h || offset + npoints > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered: range exceeds the registered bases", __LINE__};
-    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_registered: window_bits must be 0 or 2..23", __LINE__};
-    const uint4* d_sc = (const uint4*)scalars;
-    if (!scalars_on_device && npoints) {
-        g_ctx.scalars_tmp.ensure(npoints * 32);
-        g_ctx.phase_begin("msm_h2d");
-        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, g_ctx.stream));
-        g_ctx.phase_end();
-        d_sc = g_ctx.scalars_tmp.as<uint4>();
-    }
-    msm_run<fq_t>(g_ctx, h->d + offset, d_sc, npoints, out, window_bits, nullptr, ~(size_t)0, 0, h->tables, h->n, 0, true, h->table_bits);
-    API_END
-}
-
-RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h, size_t off0, size_t n0, size_t off1, size_t n1,
-                                        const void* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
-    API_BEGIN
-    if (!h || off0 + n0 > h->n || off1 + n1 > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: range exceeds the registered bases", __LINE__};
-    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: window_bits must be 0 or 2..23", __LINE__};
-    const size_t n = n0 + n1;
-    const uint4* d_sc = (const uint4*)scalars;
-    if (!scalars_on_device && n) {
-        g_ctx.scalars_tmp.ensure(n * 32);
-        g_ctx.phase_begin("msm_h2d");
-        HIP_TRY(hipMemcpyAsync(g_ctx.scalars_tmp.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
-        g_ctx.phase_end();
-        d_sc = g_ctx.scalars_tmp.as<uint4>();
-    }
-    msm_run<fq_t>(g_ctx, h->d + off0, d_sc, n, out, window_bits, h->d + off1, n0, scalars_montgomery, h->tables, h->n, 0, true, h->table_bits);
-    API_END
-}
-RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t* h, size_t count, const size_t* offsets, const size_t* npoints,
-                                           const void* const* scalars, int scalars_on_device, int scalars_montgomery, int window_bits) {
-    API_BEGIN
-    if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null handle", __LINE__};
-    if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: window_bits must be 0 or 2..23", __LINE__};
-    if (count * 144 > g_ctx.batch_pinned_cap) {
-        if (g_ctx.batch_pinned) HIP_TRY(hipHostFree(g_ctx.batch_pinned));
-        g_ctx.batch_pinned = nullptr;
-        g_ctx.batch_pinned_cap = 0;
-        HIP_TRY(hipHostMalloc(&g_ctx.batch_pinned, count * 144 + 144, hipHostMallocDefault));
-        g_ctx.batch_pinned_cap = count * 144 + 144;
-    }
-    uint8_t* stage = (uint8_t*)g_ctx.batch_pinned;
-    size_t largest = 0;
-    for (size_t k = 0; k < count; k++) largest = npoints[k] > largest ? npoints[k] : largest;
-    const int nlanes = context_t::batch_lanes(largest);
-    for (size_t k = 0; k < count; k++) {
-        if (offsets[k] + npoints[k] > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
-        const int lane = (int)(k % (size_t)nlanes);
-        msm_ws_t& ws = g_ctx.lane[lane];
-        const uint4* d_sc = (const uint4*)scalars[k];
-        if (!scalars_on_device && npoints[k]) {
-            // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
-            ws.scalars.ensure(npoints[k] * 32);
-            HIP_TRY(hipMemcpyAsync(ws.scalars.p, scalars[k], npoints[k] * 32, hipMemcpyHostToDevice, ws.stream));
-            d_sc = ws.scalars.as<uint4>();
-        }
-        msm_run<fq_t>(g_ctx, h->d + offsets[k], d_sc, npoints[k], stage + 144 * k, window_bits, nullptr, ~(size_t)0, scalars_montgomery, h->tables,
-                      h->n, lane, false, h->table_bits);
-    }
-    for (int l = 0; l < context_t::LANES; l++) HIP_TRY(hipStreamSynchronize(g_ctx.lane[l].stream));
-    memcpy(outs, stage, count * 144);
-    API_END
-}
 RustError snarkvm_hip_g1_sum(void* out, const void* in_projective, size_t n) {
     API_BEGIN
     if (!out || (n && !in_projective)) throw hip_failure{hipErrorInvalidValue, "g1_sum: null argument", __LINE__};
     if (n == 0) {
         write_infinity<fq_t>(out);
     } else {
-        g_ctx.poly[0].ensure(n * 144 + 144);
-        uint32_t* d_in = g_ctx.poly[0].as<uint32_t>();
+        c.poly[0].ensure(n * 144 + 144);
+        uint32_t* d_in = c.poly[0].as<uint32_t>();
         uint32_t* d_out = d_in + 36 * n;
-        HIP_TRY(hipMemcpyAsync(d_in, in_projective, n * 144, hipMemcpyHostToDevice, g_ctx.stream));
-        hipLaunchKernelGGL(g1_sum_kernel, dim3(1), dim3(64), 0, g_ctx.stream, (const uint32_t*)d_in, n, d_out);
+        HIP_TRY(hipMemcpyAsync(d_in, in_projective, n * 144, hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(g1_sum_kernel, dim3(1), dim3(64), 0, c.stream, (const uint32_t*)d_in, n, d_out);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out, d_out, 144, hipMemcpyDeviceToHost, g_ctx.stream));
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        HIP_TRY(hipMemcpyAsync(out, d_out, 144, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
 RustError snarkvm_hip_g1_to_affine(void* out_affine, const void* in_projective, size_t n) {
     API_BEGIN
     if (n) {
-        dev_buf din, dout;
-        din.ensure(n * 144);
-        dout.ensure(n * 104);
-        HIP_TRY(hipMemcpyAsync(din.p, in_projective, n * 144, hipMemcpyHostToDevice, g_ctx.stream));
-        hipLaunchKernelGGL(g1_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g_ctx.stream, din.as<uint32_t>(), dout.as<uint32_t>(), n);
+        if (!out_affine || !in_projective) throw hip_failure{hipErrorInvalidValue, "g1_to_affine: null argument", __LINE__};
+        c.poly[0].ensure(n * 144);
+        c.poly[1].ensure(n * 104);
+        HIP_TRY(hipMemcpyAsync(c.poly[0].p, in_projective, n * 144, hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(g1_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, c.poly[0].as<uint32_t>(), c.poly[1].as<uint32_t>(), n);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out_affine, dout.p, n * 104, hipMemcpyDeviceToHost, g_ctx.stream));
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-        (void)hipFree(din.p);
-        (void)hipFree(dout.p);
+        HIP_TRY(hipMemcpyAsync(out_affine, c.poly[1].p, n * 104, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
@@ -356,7 +443,7 @@ static const uint64_t G1_GEN_X[6] = {1171681672315280277ull, 6528257384425852712
 static const uint64_t G1_GEN_Y[6] = {13572190014569192121ull, 15344828677741220784ull, 17067903700058808083ull,
                                      10342263224753415805ull, 1083990386877464092ull,  21335464879237822ull};
 RustError snarkvm_hip_g1_generate_bases_device(void* d_out, uint64_t start, size_t npoints) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(d_out, npoints ? 1 : 0))
     if (npoints) {
         // convert the generator on the host with the same arithmetic
         uint32_t xw[12], yw[12];
@@ -366,13 +453,13 @@ RustError snarkvm_hip_g1_generate_bases_device(void* d_out, uint64_t start, size
         g1_aff_mem_t gm;
         g.x.pack(gm.x.w);
         g.y.pack(gm.y.w);
-        g_ctx.gen_pts.ensure(npoints * sizeof(g1_xyzz_mem_t));
-        g_ctx.gen_prod.ensure(npoints * sizeof(fq_mem_t));
+        c.gen_pts.ensure(npoints * sizeof(g1_xyzz_mem_t));
+        c.gen_prod.ensure(npoints * sizeof(fq_mem_t));
         const size_t threads = (npoints + GEN_RUN - 1) / GEN_RUN;
-        hipLaunchKernelGGL(g1_generate_bases_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g_ctx.stream, gm, start, npoints,
-                           (uint8_t*)d_out, (size_t)104, g_ctx.gen_pts.as<g1_xyzz_mem_t>(), g_ctx.gen_prod.as<fq_mem_t>());
+        hipLaunchKernelGGL(g1_generate_bases_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, gm, start, npoints,
+                           (uint8_t*)d_out, (size_t)104, c.gen_pts.as<g1_xyzz_mem_t>(), c.gen_prod.as<fq_mem_t>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
@@ -396,20 +483,16 @@ RustError snarkvm_hip_devtest_field(int field, int op, const void* a, const void
     API_BEGIN
     if (field < 0 || field > 1) throw hip_failure{hipErrorInvalidValue, "devtest_field: field must be 0 or 1", __LINE__};
     const size_t bytes = n * (field == 0 ? 32 : 48);
-    dev_buf da, db, dout;
-    da.ensure(bytes);
-    db.ensure(bytes);
-    dout.ensure(bytes);
-    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db.p, b ? b : a, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(devtest_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ctx.stream, field, op, da.as<uint32_t>(),
-                       db.as<uint32_t>(), dout.as<uint32_t>(), n);
+    c.poly[0].ensure(bytes + 16);
+    c.poly[1].ensure(bytes + 16);
+    c.poly[2].ensure(bytes + 16);
+    HIP_TRY(hipMemcpyAsync(c.poly[0].p, a, bytes, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.poly[1].p, b ? b : a, bytes, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(devtest_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, field, op, c.poly[0].as<uint32_t>(),
+                       c.poly[1].as<uint32_t>(), c.poly[2].as<uint32_t>(), n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da.p);
-    (void)hipFree(db.p);
-    (void)hipFree(dout.p);
+    HIP_TRY(hipMemcpyAsync(out, c.poly[2].p, bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
     API_END
 }
 // The MSM planner on the host (no device needed): out = {c, W, J, Wd, nb, nbt, S, S2, L, wide}.  Returns 0.
@@ -417,11 +500,11 @@ int snarkvm_hip_selftest_msm_plan(size_t n, int window_bits, int tables, int tab
     const msm_plan_t p = msm_make_plan(n, window_bits, tables, table_bits);
     const uint32_t v[10] = {(uint32_t)p.c, (uint32_t)p.W, (uint32_t)p.J, (uint32_t)p.Wd, p.nb, p.nbt, p.S, p.S2, p.L, p.c > 16 ? 1u : 0u};
     for (int i = 0; i < 10; i++) out[i] = v[i];
-    // bias must place one 2^(c-1) per digit row below 320 bits
+    // bias must place one 2^(c-1) per digit row below MSM_BIAS_BITS
     uint32_t chk[10] = {0};
     for (int w = 0; w < p.Wd; w++) {
         const int bit = p.c - 1 + p.c * w;
-        if (bit >= 320) return 1;
+        if (bit >= MSM_BIAS_BITS) return 1;
         chk[bit / 32] |= 1u << (bit % 32);
     }
     for (int i = 0; i < 10; i++)
@@ -464,6 +547,22 @@ int snarkvm_hip_selftest_g1_msm_naive(const void* points, size_t npoints, size_t
     j.y.to_mem_mont().pack(o + 12);
     j.z.to_mem_mont().pack(o + 24);
     return 0;
+}
+// The host-side finish of an MSM (runtime.hip.h msm_accum_t) on its own, no device needed: out (144 B) = sum_i 2^pos[i] *
+// planes[i] for `n` G1 points given as Jacobian memory images.  Lets the CPU test-suite pin the Horner code on the oracle.
+int snarkvm_hip_selftest_g1_finish(const void* planes_jacobian, const int32_t* pos, size_t n, void* out) {
+    try {
+        std::unique_ptr<msm_accum_t<fq_t>> acc(new msm_accum_t<fq_t>());
+        const uint32_t* src = (const uint32_t*)planes_jacobian;
+        for (size_t i = 0; i < n; i++) {
+            const g1_jac_t j = {fq_t::from_raw_words(src + 36 * i), fq_t::from_raw_words(src + 36 * i + 12), fq_t::from_raw_words(src + 36 * i + 24)};
+            acc->add(pos[i], g1_xyzz_t::from_jacobian(j));
+        }
+        acc->finish(out);
+        return 0;
+    } catch (...) {
+        return 1;
+    }
 }
 
 }  // extern "C"

@@ -14,35 +14,41 @@ static void check_ntt_args(uint32_t lg, int order, int dir, int type) {
 RustError snarkvm_ntt(void* inout, uint32_t lg, enum NTTInputOutputOrder order, enum NTTDirection dir, enum NTTType type) {
     API_BEGIN
     check_ntt_args(lg, (int)order, (int)dir, (int)type);
+    if (!inout) throw hip_failure{hipErrorInvalidValue, "ntt: null buffer", __LINE__};
     const size_t bytes = sizeof(fr_mem_t) << lg;
-    g_ctx.ntt_data.ensure(bytes);
-    g_ctx.ntt_scratch.ensure(bytes);
-    g_ctx.phase_begin("ntt_h2d");
-    HIP_TRY(hipMemcpyAsync(g_ctx.ntt_data.p, inout, bytes, hipMemcpyHostToDevice, g_ctx.stream));
-    g_ctx.phase_end();
-    g_ctx.phase_begin("ntt_kernels");
-    ntt_run(g_ctx.stream, g_ctx.tb, g_ctx.ntt_data.as<fr_mem_t>(), g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, (int)order, (int)dir, (int)type);
-    g_ctx.phase_end();
+    c.ntt_data.ensure(bytes);
+    c.ntt_scratch.ensure(bytes);
+    c.phase_begin("ntt_h2d");
+    HIP_TRY(hipMemcpyAsync(c.ntt_data.p, inout, bytes, hipMemcpyHostToDevice, c.stream));
+    c.phase_end();
+    c.phase_begin("ntt_kernels");
+    ntt_run(c.ntt_ctx(), c.ntt_data.as<fr_mem_t>(), c.ntt_scratch.as<fr_mem_t>(), (int)lg, (int)order, (int)dir, (int)type);
+    c.phase_end();
     HIP_TRY(hipGetLastError());
-    g_ctx.phase_begin("ntt_d2h");
-    HIP_TRY(hipMemcpyAsync(inout, g_ctx.ntt_data.p, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
-    g_ctx.phase_end();
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    c.phase_begin("ntt_d2h");
+    HIP_TRY(hipMemcpyAsync(inout, c.ntt_data.p, bytes, hipMemcpyDeviceToHost, c.stream));
+    c.phase_end();
+    HIP_TRY(hipStreamSynchronize(c.stream));
     API_END
 }
 RustError snarkvm_hip_ntt_device(void* d_inout, uint32_t lg, int order, int dir, int type) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(d_inout, 1))
     check_ntt_args(lg, order, dir, type);
-    g_ctx.ntt_scratch.ensure(sizeof(fr_mem_t) << lg);
-    g_ctx.phase_begin("ntt_kernels");
-    ntt_run(g_ctx.stream, g_ctx.tb, (fr_mem_t*)d_inout, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, order, dir, type);
-    g_ctx.phase_end();
+    c.ntt_scratch.ensure(sizeof(fr_mem_t) << lg);
+    c.phase_begin("ntt_kernels");
+    ntt_run(c.ntt_ctx(), (fr_mem_t*)d_inout, c.ntt_scratch.as<fr_mem_t>(), (int)lg, order, dir, type);
+    c.phase_end();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
     API_END
 }
 
 // ---- polymul -----------------------------------------------------------------------------------
+// PolyMultiplier::multiply on the device (multiplier.rs:70-134 through snarkvm.cu:188-247 / polynomial.cuh:104-266).  Like the
+// reference's `Polynomial::Mul`, the upload of operand k + 1 (on the lane's second stream, into the other of two operand
+// buffers) overlaps the transform and the pointwise product of operand k; events order the two streams:
+//   ev[b]     "operand buffer b has been uploaded"      (alt -> main)
+//   ev[2 + b] "operand buffer b has been consumed"      (main -> alt)
 RustError snarkvm_polymul(void* out, size_t pcount, const void* polynomials, const void* plens, size_t ecount, const void* evaluations,
                           const void* elens, uint32_t lg) {
     // corner cases of snarkvm.cu:196-210 first (no device needed for the copy)
@@ -63,57 +69,73 @@ RustError snarkvm_polymul(void* out, size_t pcount, const void* polynomials, con
         if (pl[k] > n) throw hip_failure{hipErrorInvalidValue, "polymul: polynomial longer than the domain", __LINE__};
     for (size_t k = 0; k < ecount; k++)
         if (el[k] != n) throw hip_failure{hipErrorInvalidValue, "polymul: evaluation vector length != domain size", __LINE__};
-    g_ctx.ntt_data.ensure(bytes);
-    g_ctx.ntt_scratch.ensure(bytes);
-    g_ctx.ntt_acc.ensure(bytes);
-    hipStream_t st = g_ctx.stream;
-    fr_mem_t* data = g_ctx.ntt_data.as<fr_mem_t>();
-    fr_mem_t* acc = g_ctx.ntt_acc.as<fr_mem_t>();
+    c.ntt_data.ensure(bytes);
+    c.ntt_alt.ensure(bytes);
+    c.ntt_scratch.ensure(bytes);
+    c.ntt_acc.ensure(bytes);
+    hipStream_t st = c.stream;
+    fr_mem_t* buf[2] = {c.ntt_data.as<fr_mem_t>(), c.ntt_alt.as<fr_mem_t>()};
+    fr_mem_t* acc = c.ntt_acc.as<fr_mem_t>();
+    fr_mem_t* scratch = c.ntt_scratch.as<fr_mem_t>();
+    const ntt_ctx_t cx = c.ntt_ctx();
     if (pcount + ecount == 1) {  // a single evaluation vector: zero-pad + inverse NTT (snarkvm.cu:203-208)
-        HIP_TRY(hipMemsetAsync(data, 0, bytes, st));
-        HIP_TRY(hipMemcpyAsync(data, evals[0], sizeof(fr_mem_t) * el[0], hipMemcpyHostToDevice, st));
-        ntt_run(st, g_ctx.tb, data, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, NTT_NN, NTT_INVERSE, NTT_STANDARD);
-        HIP_TRY(hipMemcpyAsync(out, data, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(acc, 0, bytes, st));
+        HIP_TRY(hipMemcpyAsync(acc, evals[0], sizeof(fr_mem_t) * el[0], hipMemcpyHostToDevice, st));
+        ntt_run(cx, acc, scratch, (int)lg, NTT_NN, NTT_INVERSE, NTT_STANDARD);
+        HIP_TRY(hipMemcpyAsync(out, acc, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     } else {
         const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        for (size_t k = 0; k < pcount + ecount; k++) {
-            fr_mem_t* dst = (k == 0) ? acc : data;
+        const size_t total = pcount + ecount;
+        // operand 0 goes straight into the accumulator on the main stream; operands k >= 1 alternate between the two buffers
+        auto upload = [&](size_t k, fr_mem_t* dst, hipStream_t s) {
             if (k < pcount) {
-                HIP_TRY(hipMemcpyAsync(dst, polys[k], sizeof(fr_mem_t) * pl[k], hipMemcpyHostToDevice, st));
-                if (pl[k] < n) HIP_TRY(hipMemsetAsync(dst + pl[k], 0, sizeof(fr_mem_t) * (n - pl[k]), st));
-                ntt_run(st, g_ctx.tb, dst, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, NTT_NN, NTT_FORWARD, NTT_STANDARD);
+                HIP_TRY(hipMemcpyAsync(dst, polys[k], sizeof(fr_mem_t) * pl[k], hipMemcpyHostToDevice, s));
+                if (pl[k] < n) HIP_TRY(hipMemsetAsync(dst + pl[k], 0, sizeof(fr_mem_t) * (n - pl[k]), s));
             } else {
-                HIP_TRY(hipMemcpyAsync(dst, evals[k - pcount], bytes, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(dst, evals[k - pcount], bytes, hipMemcpyHostToDevice, s));
             }
-            if (k > 0) hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, st, acc, acc, data, n, 1);
+        };
+        upload(0, acc, st);
+        if (pcount > 0) ntt_run(cx, acc, scratch, (int)lg, NTT_NN, NTT_FORWARD, NTT_STANDARD);
+        for (size_t k = 1; k < total; k++) {
+            const int b = (int)(k & 1);
+            // the kernels of operand k - 1 are already queued on the main stream: this (host-blocking, pageable) copy runs beside them
+            if (k >= 3) HIP_TRY(hipStreamWaitEvent(c.alt, c.ev[2 + b], 0));  // buffer b was last consumed by operand k - 2
+            upload(k, buf[b], c.alt);
+            HIP_TRY(hipEventRecord(c.ev[b], c.alt));
+            HIP_TRY(hipStreamWaitEvent(st, c.ev[b], 0));
+            if (k < pcount) ntt_run(cx, buf[b], scratch, (int)lg, NTT_NN, NTT_FORWARD, NTT_STANDARD);
+            hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, st, acc, acc, buf[b], n, 1);
+            HIP_TRY(hipEventRecord(c.ev[2 + b], st));
         }
-        ntt_run(st, g_ctx.tb, acc, g_ctx.ntt_scratch.as<fr_mem_t>(), (int)lg, NTT_NN, NTT_INVERSE, NTT_STANDARD);
+        ntt_run(cx, acc, scratch, (int)lg, NTT_NN, NTT_INVERSE, NTT_STANDARD);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out, acc, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(c.alt));
     }
     API_END
 }
 
 // ---- Fr vector helpers ---------------------------------------------------------------------------
 RustError snarkvm_hip_fr_mul_device(void* d_out, const void* d_a, const void* d_b, size_t n) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(d_out, n ? 1 : 0))
     if (n) {
         const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, g_ctx.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_a, (const fr_mem_t*)d_b, n, 1);
+        hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, c.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_a, (const fr_mem_t*)d_b, n, 1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
 RustError snarkvm_hip_fr_convert_device(void* d_out, const void* d_in, size_t n, int to_bigint) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(d_out, n ? 1 : 0))
     if (n) {
         const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(blocks), dim3(256), 0, g_ctx.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_in, n, to_bigint);
+        hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(blocks), dim3(256), 0, c.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_in, n, to_bigint);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
@@ -129,48 +151,48 @@ static unsigned fr_grid(size_t n, unsigned block = 256) {
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 // operand `p` (n elements) as a device pointer: itself, or a staged copy in ctx.poly[slot]
-static fr_mem_t* fr_stage_in(int slot, const void* p, size_t n, int on_device) {
+static fr_mem_t* fr_stage_in(lane_t& c, int slot, const void* p, size_t n, int on_device) {
     if (on_device || !p) return (fr_mem_t*)p;
-    g_ctx.poly[slot].ensure(sizeof(fr_mem_t) * (n ? n : 1));
-    if (n) HIP_TRY(hipMemcpyAsync(g_ctx.poly[slot].p, p, sizeof(fr_mem_t) * n, hipMemcpyHostToDevice, g_ctx.stream));
-    return g_ctx.poly[slot].as<fr_mem_t>();
+    c.poly[slot].ensure(sizeof(fr_mem_t) * (n ? n : 1));
+    if (n) HIP_TRY(hipMemcpyAsync(c.poly[slot].p, p, sizeof(fr_mem_t) * n, hipMemcpyHostToDevice, c.stream));
+    return c.poly[slot].as<fr_mem_t>();
 }
-static fr_mem_t* fr_stage_out(int slot, void* p, size_t n, int on_device) {
+static fr_mem_t* fr_stage_out(lane_t& c, int slot, void* p, size_t n, int on_device) {
     if (on_device || !p) return (fr_mem_t*)p;
-    g_ctx.poly[slot].ensure(sizeof(fr_mem_t) * (n ? n : 1));
-    return g_ctx.poly[slot].as<fr_mem_t>();
+    c.poly[slot].ensure(sizeof(fr_mem_t) * (n ? n : 1));
+    return c.poly[slot].as<fr_mem_t>();
 }
-static void fr_finish_out(fr_mem_t* d, void* p, size_t n, int on_device) {
-    if (!on_device && p && n) HIP_TRY(hipMemcpyAsync(p, d, sizeof(fr_mem_t) * n, hipMemcpyDeviceToHost, g_ctx.stream));
+static void fr_finish_out(lane_t& c, fr_mem_t* d, void* p, size_t n, int on_device) {
+    if (!on_device && p && n) HIP_TRY(hipMemcpyAsync(p, d, sizeof(fr_mem_t) * n, hipMemcpyDeviceToHost, c.stream));
 }
 
-RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b, const void* c, const void* scalar, size_t n, int on_device) {
-    API_BEGIN
+RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b, const void* c3, const void* scalar, size_t n, int on_device) {
+    API_BEGIN_DEV(device_for(a, (on_device && n) ? 1 : 0))
     if (op < 0 || op > FR_OP_RSUB_SCALAR) throw hip_failure{hipErrorInvalidValue, "fr_vec_op: unknown op", __LINE__};
     const bool need_b = op == FR_OP_ADD || op == FR_OP_SUB || op == FR_OP_MUL || op == FR_OP_MUL_SUB || op == FR_OP_AXPY;
     const bool need_c = op == FR_OP_MUL_SUB;
     const bool need_s = op == FR_OP_SCALE || op == FR_OP_SUB_SCALAR || op == FR_OP_AXPY || op == FR_OP_RSUB_SCALAR;
-    if (n && (!out || !a || (need_b && !b) || (need_c && !c) || (need_s && !scalar)))
+    if (n && (!out || !a || (need_b && !b) || (need_c && !c3) || (need_s && !scalar)))
         throw hip_failure{hipErrorInvalidValue, "fr_vec_op: missing operand", __LINE__};
     if (n) {
         fr_mem_t s{};
         if (need_s) s = fr_mem_from_host(scalar);
-        const fr_mem_t* da = fr_stage_in(0, a, n, on_device);
-        const fr_mem_t* db = need_b ? fr_stage_in(1, b, n, on_device) : nullptr;
-        const fr_mem_t* dc = need_c ? fr_stage_in(2, c, n, on_device) : nullptr;
-        fr_mem_t* dout = fr_stage_out(3, out, n, on_device);
-        hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, g_ctx.stream, op, dout, da, db, dc, s, n);
+        const fr_mem_t* da = fr_stage_in(c, 0, a, n, on_device);
+        const fr_mem_t* db = need_b ? fr_stage_in(c, 1, b, n, on_device) : nullptr;
+        const fr_mem_t* dc = need_c ? fr_stage_in(c, 2, c3, n, on_device) : nullptr;
+        fr_mem_t* dout = fr_stage_out(c, 3, out, n, on_device);
+        hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, c.stream, op, dout, da, db, dc, s, n);
         HIP_TRY(hipGetLastError());
-        fr_finish_out(dout, out, n, on_device);
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        fr_finish_out(c, dout, out, n, on_device);
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
 
 // out[i - shift] = h_i = sum_{k >= i} in[k] m^(k - i) (and *first = h_0 when shift == 1); `out` may be null (only h_0 wanted).
-// Scratch for the chunk values of every level lives in ctx.poly[4].
-static void fr_suffix_horner(const fr_mem_t* d_in, size_t n, const fr_mem_t& m, fr_mem_t* d_out, int shift, fr_mem_t* d_first) {
-    hipStream_t st = g_ctx.stream;
+// Scratch for the chunk values of every level lives in the lane's poly[4].
+static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr_mem_t& m, fr_mem_t* d_out, int shift, fr_mem_t* d_first) {
+    hipStream_t st = c.stream;
     int levels = 1;
     size_t total = 0;
     for (size_t t = n; t > 1;) {
@@ -178,8 +200,8 @@ static void fr_suffix_horner(const fr_mem_t* d_in, size_t n, const fr_mem_t& m, 
         total += t;
         levels++;
     }
-    g_ctx.poly[4].ensure(sizeof(fr_mem_t) * (total + levels + 2));
-    fr_mem_t* mult = g_ctx.poly[4].as<fr_mem_t>();
+    c.poly[4].ensure(sizeof(fr_mem_t) * (total + levels + 2));
+    fr_mem_t* mult = c.poly[4].as<fr_mem_t>();
     fr_mem_t* cvbase = mult + levels + 1;
     hipLaunchKernelGGL(fr_horner_multipliers_kernel, dim3(1), dim3(1), 0, st, m, mult, levels);
     // up-sweep: level k holds the chunk values of level k - 1 (level 0 = the input)
@@ -218,58 +240,58 @@ static void fr_suffix_horner(const fr_mem_t* d_in, size_t n, const fr_mem_t& m, 
 }
 
 RustError snarkvm_hip_fr_divide_by_linear(void* quotient, void* remainder, const void* poly, size_t n, const void* point, int on_device) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(poly, (on_device && n) ? 1 : 0))
     if (!point || (n && !poly)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_linear: missing operand", __LINE__};
     if (n == 0) {
         if (remainder) memset(remainder, 0, sizeof(fr_mem_t));
     } else {
         const fr_mem_t z = fr_mem_from_host(point);
-        const fr_mem_t* din = fr_stage_in(0, poly, n, on_device);
-        fr_mem_t* dq = (quotient && n > 1) ? fr_stage_out(1, quotient, n - 1, on_device) : nullptr;
-        g_ctx.poly[2].ensure(sizeof(fr_mem_t));
-        fr_mem_t* drem = g_ctx.poly[2].as<fr_mem_t>();
-        fr_suffix_horner(din, n, z, dq, 1, drem);
-        if (dq) fr_finish_out(dq, quotient, n - 1, on_device);
-        if (remainder) HIP_TRY(hipMemcpyAsync(remainder, drem, sizeof(fr_mem_t), hipMemcpyDeviceToHost, g_ctx.stream));
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        const fr_mem_t* din = fr_stage_in(c, 0, poly, n, on_device);
+        fr_mem_t* dq = (quotient && n > 1) ? fr_stage_out(c, 1, quotient, n - 1, on_device) : nullptr;
+        c.poly[2].ensure(sizeof(fr_mem_t));
+        fr_mem_t* drem = c.poly[2].as<fr_mem_t>();
+        fr_suffix_horner(c, din, n, z, dq, 1, drem);
+        if (dq) fr_finish_out(c, dq, quotient, n - 1, on_device);
+        if (remainder) HIP_TRY(hipMemcpyAsync(remainder, drem, sizeof(fr_mem_t), hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
 
-static void fr_batch_inverse_run(fr_mem_t* d_v, size_t n, const fr_mem_t& coeff) {
+static void fr_batch_inverse_run(lane_t& c, fr_mem_t* d_v, size_t n, const fr_mem_t& coeff) {
     // >= 32 elements per thread amortise the per-thread Fermat inversion; cap the thread count for huge vectors
     size_t T = (n + 31) / 32;
     if (T > (size_t)1 << 17) T = (size_t)1 << 17;
-    g_ctx.poly[4].ensure(sizeof(fr_mem_t) * n);
-    hipLaunchKernelGGL(fr_batch_inverse_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, g_ctx.stream, d_v, n, coeff, g_ctx.poly[4].as<fr_mem_t>(), T);
+    c.poly[4].ensure(sizeof(fr_mem_t) * n);
+    hipLaunchKernelGGL(fr_batch_inverse_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, c.stream, d_v, n, coeff, c.poly[4].as<fr_mem_t>(), T);
     HIP_TRY(hipGetLastError());
 }
 RustError snarkvm_hip_fr_batch_inversion_and_mul(void* inout, size_t n, const void* coeff, int on_device) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(inout, (on_device && n) ? 1 : 0))
     if (n) {
         if (!inout || !coeff) throw hip_failure{hipErrorInvalidValue, "fr_batch_inversion_and_mul: missing operand", __LINE__};
-        fr_mem_t* dv = fr_stage_in(0, inout, n, on_device);
-        fr_batch_inverse_run(dv, n, fr_mem_from_host(coeff));
-        fr_finish_out(dv, inout, n, on_device);
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        fr_mem_t* dv = fr_stage_in(c, 0, inout, n, on_device);
+        fr_batch_inverse_run(c, dv, n, fr_mem_from_host(coeff));
+        fr_finish_out(c, dv, inout, n, on_device);
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
 
-static void fr_distribute_powers_run(fr_mem_t* d_v, size_t n, const fr_mem_t& g, const fr_mem_t& c) {
+static void fr_distribute_powers_run(lane_t& c, fr_mem_t* d_v, size_t n, const fr_mem_t& g, const fr_mem_t& cmul) {
     size_t T = (n + 31) / 32;
     if (T > (size_t)1 << 17) T = (size_t)1 << 17;
-    hipLaunchKernelGGL(fr_distribute_powers_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, g_ctx.stream, d_v, n, g, c, T);
+    hipLaunchKernelGGL(fr_distribute_powers_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, c.stream, d_v, n, g, cmul, T);
     HIP_TRY(hipGetLastError());
 }
-RustError snarkvm_hip_fr_distribute_powers(void* inout, size_t n, const void* g, const void* c, int on_device) {
-    API_BEGIN
+RustError snarkvm_hip_fr_distribute_powers(void* inout, size_t n, const void* g, const void* cmul, int on_device) {
+    API_BEGIN_DEV(device_for(inout, (on_device && n) ? 1 : 0))
     if (n) {
-        if (!inout || !g || !c) throw hip_failure{hipErrorInvalidValue, "fr_distribute_powers: missing operand", __LINE__};
-        fr_mem_t* dv = fr_stage_in(0, inout, n, on_device);
-        fr_distribute_powers_run(dv, n, fr_mem_from_host(g), fr_mem_from_host(c));
-        fr_finish_out(dv, inout, n, on_device);
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        if (!inout || !g || !cmul) throw hip_failure{hipErrorInvalidValue, "fr_distribute_powers: missing operand", __LINE__};
+        fr_mem_t* dv = fr_stage_in(c, 0, inout, n, on_device);
+        fr_distribute_powers_run(c, dv, n, fr_mem_from_host(g), fr_mem_from_host(cmul));
+        fr_finish_out(c, dv, inout, n, on_device);
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
@@ -278,7 +300,7 @@ RustError snarkvm_hip_fr_distribute_powers(void* inout, size_t n, const void* g,
 static const uint32_t FR_TWO_ADIC_ROOT_MEM_HOST[8] = {0xda3ad648u, 0xaf80da4du, 0xfc381dacu, 0x5e223adbu,
                                                       0xb2f92525u, 0x03ba0666u, 0x3befb0ceu, 0x0f906c5bu};
 RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const void* tau, int on_device) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(out, (on_device && out) ? 1 : 0))
     if (lg > 30) throw hip_failure{hipErrorInvalidValue, "fr_lagrange_coefficients: lg_domain_size > 30", __LINE__};
     if (!out || !tau) throw hip_failure{hipErrorInvalidValue, "fr_lagrange_coefficients: missing operand", __LINE__};
     const size_t n = (size_t)1 << lg;
@@ -291,10 +313,10 @@ RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const voi
     fr_mem_t one_mem, omega_mem;
     fr_t::one().to_mem_mont().store(&one_mem);
     omega.to_mem_mont().store(&omega_mem);
-    fr_mem_t* du = fr_stage_out(0, out, n, on_device);
-    hipStream_t st = g_ctx.stream;
+    fr_mem_t* du = fr_stage_out(c, 0, out, n, on_device);
+    hipStream_t st = c.stream;
     hipLaunchKernelGGL(fr_fill_kernel, dim3(fr_grid(n)), dim3(256), 0, st, du, n, one_mem);
-    fr_distribute_powers_run(du, n, omega_mem, one_mem);  // u_i = omega^i
+    fr_distribute_powers_run(c, du, n, omega_mem, one_mem);  // u_i = omega^i
     if (t_size == fr_t::one()) {
         hipLaunchKernelGGL(fr_onehot_kernel, dim3(fr_grid(n)), dim3(256), 0, st, du, n, tau_mem, one_mem);
     } else {
@@ -302,45 +324,45 @@ RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const voi
         ((t_size - fr_t::one()) * fr_t::from_u32((uint32_t)n).inverse()).to_mem_mont().store(&l_mem);
         hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, st, (int)FR_OP_RSUB_SCALAR, du, (const fr_mem_t*)du, (const fr_mem_t*)nullptr,
                            (const fr_mem_t*)nullptr, tau_mem, n);  // tau - omega^i
-        fr_batch_inverse_run(du, n, one_mem);
-        fr_distribute_powers_run(du, n, omega_mem, l_mem);  // * l * omega^i
+        fr_batch_inverse_run(c, du, n, one_mem);
+        fr_distribute_powers_run(c, du, n, omega_mem, l_mem);  // * l * omega^i
     }
     HIP_TRY(hipGetLastError());
-    fr_finish_out(du, out, n, on_device);
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    fr_finish_out(c, du, out, n, on_device);
+    HIP_TRY(hipStreamSynchronize(c.stream));
     API_END
 }
 
 RustError snarkvm_hip_fr_divide_by_vanishing(void* quotient, void* remainder, const void* poly, size_t len, size_t domain_size, int on_device) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(poly, (on_device && len) ? 1 : 0))
     if (domain_size == 0) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_vanishing: empty domain", __LINE__};
     if (len) {
         if (!poly || !remainder || (len > domain_size && !quotient)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_vanishing: missing operand", __LINE__};
         const size_t qlen = len > domain_size ? len - domain_size : 0;
         const size_t rlen = len < domain_size ? len : domain_size;
-        const fr_mem_t* din = fr_stage_in(0, poly, len, on_device);
-        fr_mem_t* dq = qlen ? fr_stage_out(1, quotient, qlen, on_device) : nullptr;
-        fr_mem_t* dr = fr_stage_out(2, remainder, rlen, on_device);
+        const fr_mem_t* din = fr_stage_in(c, 0, poly, len, on_device);
+        fr_mem_t* dq = qlen ? fr_stage_out(c, 1, quotient, qlen, on_device) : nullptr;
+        fr_mem_t* dr = fr_stage_out(c, 2, remainder, rlen, on_device);
         const size_t threads = qlen > rlen ? qlen : rlen;
-        hipLaunchKernelGGL(fr_fold_vanishing_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g_ctx.stream, din, len, domain_size, dq, dr);
+        hipLaunchKernelGGL(fr_fold_vanishing_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, din, len, domain_size, dq, dr);
         HIP_TRY(hipGetLastError());
-        if (qlen) fr_finish_out(dq, quotient, qlen, on_device);
-        fr_finish_out(dr, remainder, rlen, on_device);
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        if (qlen) fr_finish_out(c, dq, quotient, qlen, on_device);
+        fr_finish_out(c, dr, remainder, rlen, on_device);
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
 RustError snarkvm_hip_fr_mul_by_vanishing(void* out, const void* poly, size_t len, size_t domain_size, int on_device) {
-    API_BEGIN
+    API_BEGIN_DEV(device_for(out, (on_device && out) ? 1 : 0))
     const size_t olen = len + domain_size;
     if (olen) {
         if (!out || (len && !poly)) throw hip_failure{hipErrorInvalidValue, "fr_mul_by_vanishing: missing operand", __LINE__};
-        const fr_mem_t* din = fr_stage_in(0, poly, len, on_device);
-        fr_mem_t* dout = fr_stage_out(1, out, olen, on_device);
-        hipLaunchKernelGGL(fr_mul_vanishing_kernel, dim3((unsigned)((olen + 255) / 256)), dim3(256), 0, g_ctx.stream, din, len, domain_size, dout);
+        const fr_mem_t* din = fr_stage_in(c, 0, poly, len, on_device);
+        fr_mem_t* dout = fr_stage_out(c, 1, out, olen, on_device);
+        hipLaunchKernelGGL(fr_mul_vanishing_kernel, dim3((unsigned)((olen + 255) / 256)), dim3(256), 0, c.stream, din, len, domain_size, dout);
         HIP_TRY(hipGetLastError());
-        fr_finish_out(dout, out, olen, on_device);
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        fr_finish_out(c, dout, out, olen, on_device);
+        HIP_TRY(hipStreamSynchronize(c.stream));
     }
     API_END
 }
@@ -350,25 +372,25 @@ RustError snarkvm_hip_g1_fixed_base_msm(void* out_projective, const void* g_affi
     API_BEGIN
     if (n) {
         if (!out_projective || !g_affine || !scalars) throw hip_failure{hipErrorInvalidValue, "g1_fixed_base_msm: null argument", __LINE__};
-        hipStream_t st = g_ctx.stream;
+        hipStream_t st = c.stream;
         // the base in the engine's native form, through the regular conversion kernel
-        g_ctx.bases_tmp.ensure(256 + sizeof(g1_aff_mem_t));
-        HIP_TRY(hipMemcpyAsync(g_ctx.bases_tmp.p, g_affine, 104, hipMemcpyHostToDevice, st));
-        g1_aff_mem_t* d_g = (g1_aff_mem_t*)(g_ctx.bases_tmp.as<uint8_t>() + 256);
-        convert_bases<fq_t>(g_ctx, g_ctx.bases_tmp.as<uint8_t>(), 104, 1, d_g);
+        c.bases_tmp.ensure(256 + sizeof(g1_aff_mem_t));
+        HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, g_affine, 104, hipMemcpyHostToDevice, st));
+        g1_aff_mem_t* d_g = (g1_aff_mem_t*)(c.bases_tmp.as<uint8_t>() + 256);
+        convert_bases<fq_t>(c, c.bases_tmp.as<uint8_t>(), 104, 1, d_g);
         g1_aff_mem_t g_native;
         HIP_TRY(hipMemcpyAsync(&g_native, d_g, sizeof g_native, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const size_t entries = (size_t)FIXED_OUTER << FIXED_WINDOW;
-        g_ctx.poly[0].ensure(entries * sizeof(g1_aff_mem_t));
-        g_ctx.poly[1].ensure(n * 32);
-        g_ctx.poly[2].ensure(n * 144);
-        hipLaunchKernelGGL(g1_fixed_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, g_native, g_ctx.poly[0].as<g1_aff_mem_t>());
-        HIP_TRY(hipMemcpyAsync(g_ctx.poly[1].p, scalars, n * 32, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(g1_fixed_msm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g_ctx.poly[0].as<g1_aff_mem_t>(),
-                           g_ctx.poly[1].as<fr_mem_t>(), n, g_ctx.poly[2].as<uint32_t>());
+        c.poly[0].ensure(entries * sizeof(g1_aff_mem_t));
+        c.poly[1].ensure(n * 32);
+        c.poly[2].ensure(n * 144);
+        hipLaunchKernelGGL(g1_fixed_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, g_native, c.poly[0].as<g1_aff_mem_t>());
+        HIP_TRY(hipMemcpyAsync(c.poly[1].p, scalars, n * 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(g1_fixed_msm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c.poly[0].as<g1_aff_mem_t>(),
+                           c.poly[1].as<fr_mem_t>(), n, c.poly[2].as<uint32_t>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out_projective, g_ctx.poly[2].p, n * 144, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_projective, c.poly[2].p, n * 144, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     API_END
@@ -378,13 +400,13 @@ RustError snarkvm_hip_g1_group_ntt(void* inout_projective, uint32_t lg, int inve
     if (lg > 24) throw hip_failure{hipErrorInvalidValue, "g1_group_ntt: lg_domain_size > 24", __LINE__};
     if (!inout_projective) throw hip_failure{hipErrorInvalidValue, "g1_group_ntt: null argument", __LINE__};
     const size_t n = (size_t)1 << lg;
-    hipStream_t st = g_ctx.stream;
-    g_ctx.poly[0].ensure(n * 144);
-    g_ctx.poly[1].ensure(n * sizeof(g1_xyzz_mem_t));
-    g_ctx.poly[2].ensure((n / 2 + 1) * sizeof(fr_mem_t));
-    uint32_t* d_jac = g_ctx.poly[0].as<uint32_t>();
-    g1_xyzz_mem_t* d_pts = g_ctx.poly[1].as<g1_xyzz_mem_t>();
-    fr_mem_t* d_tw = g_ctx.poly[2].as<fr_mem_t>();
+    hipStream_t st = c.stream;
+    c.poly[0].ensure(n * 144);
+    c.poly[1].ensure(n * sizeof(g1_xyzz_mem_t));
+    c.poly[2].ensure((n / 2 + 1) * sizeof(fr_mem_t));
+    uint32_t* d_jac = c.poly[0].as<uint32_t>();
+    g1_xyzz_mem_t* d_pts = c.poly[1].as<g1_xyzz_mem_t>();
+    fr_mem_t* d_tw = c.poly[2].as<fr_mem_t>();
     HIP_TRY(hipMemcpyAsync(d_jac, inout_projective, n * 144, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(g1_jac_to_xyzz_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_jac, d_pts, n);
     if (lg > 0) {
@@ -397,7 +419,7 @@ RustError snarkvm_hip_g1_group_ntt(void* inout_projective, uint32_t lg, int inve
         omega.to_mem_mont().store(&root_mem);
         const size_t h = n / 2;
         hipLaunchKernelGGL(fr_fill_kernel, dim3(fr_grid(h)), dim3(256), 0, st, d_tw, h, one_mem);
-        fr_distribute_powers_run(d_tw, h, root_mem, one_mem);
+        fr_distribute_powers_run(c, d_tw, h, root_mem, one_mem);
         hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(fr_grid(h)), dim3(256), 0, st, d_tw, (const fr_mem_t*)d_tw, h, 1);
         for (size_t half = n / 2; half >= 1; half >>= 1)
             hipLaunchKernelGGL(g1_ntt_stage_kernel, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, st, d_pts, n, half, (const fr_mem_t*)d_tw, n / (2 * half));

@@ -112,12 +112,13 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     static const int env_S = getenv("SNARKVM_HIP_S") ? atoi(getenv("SNARKVM_HIP_S")) : 0;
     static const int env_S2 = getenv("SNARKVM_HIP_S2") ? atoi(getenv("SNARKVM_HIP_S2")) : 0;
     static const int env_L = getenv("SNARKVM_HIP_L") ? atoi(getenv("SNARKVM_HIP_L")) : 0;
-    // points per accumulate thread: long segments amortise the partial-sum flushes of big MSMs, short ones keep >= ~4 waves
-    // per SIMD busy on small ones (the accumulate of a small MSM is S dependent additions of latency)
+    // points per accumulate thread: long segments amortise the partial-sum flushes of big MSMs; a small MSM is latency-bound
+    // (S dependent additions of ~9.4 us each, tools/ecbench.hip), so its segments shrink until the grid fills two waves per
+    // SIMD (2^17 threads - what the kernel's ~190 VGPRs allow to be resident; a wave runs at full speed up to there)
     {
         const size_t E = (size_t)p.Wd * n;
         p.S = E >= ((size_t)1 << 27) ? 128 : 64;
-        while (p.S > 16 && E / p.S < ((size_t)1 << 18)) p.S >>= 1;
+        while (p.S > 4 && E / p.S < ((size_t)1 << 17)) p.S >>= 1;
     }
     if (env_S > 0) p.S = env_S;
     p.S2 = env_S2 > 1 ? env_S2 : 8;
@@ -311,58 +312,22 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const xyzz_mem_t<F>* __
 }
 
 // ------------------------------------------------------------------------------------------
-// 7. bucket reduction: thread (w, j) covers buckets [jL, (j+1)L) of window w
-//    contribution = sum_l (l+1) B_(jL+l) + jL * sum_l B_(jL+l)
+// 7.-9. tail: weighted bucket sum  sum_b (b + 1) B_b  per window, then the combination of the windows.
+//
+// Everything here is a short chain of DEPENDENT group operations (one wave runs one XYZZ addition in ~10-13 us,
+// tools/ecbench.hip), so the tail is organised to minimise that depth, not the operation count:
+//   7a fold      (windows with >= 2^11 buckets) bucket index b = hi * 2^m + lo:
+//                   sum_b (b + 1) B_b = 2^m * sum_hi hi * H_hi + sum_lo (lo + 1) * L_lo,  H_hi = sum_lo B_(hi,lo),  L_lo = sum_hi B_(hi,lo)
+//                one workgroup per row / column sum - 256 threads (a few serial additions per lane, then an 8-level tree) when
+//                the MSM is small and latency-bound, one wave (less tree overhead per output) for the 2^21 buckets of a big one;
+//                the leftover partial sums of the accumulate phase (<= tail_partials per bucket) are consumed here directly;
+//   7b bit planes  sum_i (i + 1) P_i = sum_j 2^j S_j with S_j = sum over the entries whose weight has bit j set: one
+//                workgroup per (tail window, bit) sums its subset as a tree - no running sums, no double-and-add chains;
+//   9  the remaining sum_p 2^p (planes at bit position p) is a Horner chain of <= ~270 doublings with wave-uniform data: that
+//      is host work, like the reference's host-side collapse of the per-GPU results (algorithms/cuda/cuda/snarkvm.cu:290-295)
+//      - runtime.hip.h::msm_finish_host runs it with this same arithmetic compiled for the host (~1 us per operation on one
+//      core instead of ~10 us on one GPU lane).
 // ------------------------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const xyzz_mem_t<F>* __restrict__ sums,
-                                                                const uint32_t* __restrict__ start,
-                                                                const uint32_t* __restrict__ cnt,
-                                                                xyzz_mem_t<F>* __restrict__ contrib, uint32_t nb,
-                                                                uint32_t L, uint32_t total_threads) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_threads) return;
-    const uint32_t J = nb / L;
-    const uint32_t w = t / J, j = t % J;
-    const uint32_t k0 = w * nb + j * L;
-    xyzz_t<F> run = xyzz_t<F>::inf(), acc = xyzz_t<F>::inf();
-    for (int l = (int)L - 1; l >= 0; l--) {
-        const uint32_t k = k0 + (uint32_t)l;
-        for (uint32_t q = 0; q < cnt[k]; q++) run.add(load_xyzz<F>(&sums[start[k] + q]));  // a few partials may be left per bucket
-        acc.add(run);
-    }
-    if (j) acc.add(run.mul_small(j * L));
-    store_xyzz<F>(&contrib[t], acc);
-}
-// 8. one block per window: tree sum of its J contributions
-template <class F>
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const xyzz_mem_t<F>* __restrict__ contrib,
-                                                             xyzz_mem_t<F>* __restrict__ wsum, uint32_t J) {
-    // 256 partial sums staged in LDS (G1: 48 KiB; G2 uses 128 threads)
-    extern __shared__ uint4 sh_raw[];
-    xyzz_mem_t<F>* sh = (xyzz_mem_t<F>*)sh_raw;
-    const uint32_t w = blockIdx.x;
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    for (uint32_t j = threadIdx.x; j < J; j += blockDim.x) acc.add(load_xyzz<F>(&contrib[(size_t)w * J + j]));
-    store_xyzz<F>(&sh[threadIdx.x], acc);
-    __syncthreads();
-    for (int off = (int)blockDim.x / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            xyzz_t<F> a = load_xyzz<F>(&sh[threadIdx.x]);
-            a.add(load_xyzz<F>(&sh[threadIdx.x + off]));
-            store_xyzz<F>(&sh[threadIdx.x], a);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) wsum[w] = sh[0];
-}
-// 7b. Two-axis fold of one WIDE window (nb = 2^K buckets, K = hb + m): with bucket index b = hi * 2^m + lo,
-//        sum_b (b + 1) B_b = 2^m * sum_hi hi * H_hi + sum_lo (lo + 1) * L_lo,   H_hi = sum_lo B_(hi,lo),  L_lo = sum_hi B_(hi,lo),
-//     so 2 additions per bucket, all independent, replace the long running sums; what is left are two small "windows" of
-//     2^m entries (L at index lo, weight lo + 1; H_hi at index hi - 1, weight hi) combined by the regular tail with c = m.
-//     Workgroups [0, 2^m) fold columns (fixed lo), workgroups [2^m, 2^m + 2^hb) fold rows (fixed hi).
-// ONE wave per output and a shuffle butterfly (a 256-thread LDS tree spent as long in its 8 levels - half the lanes idle, a
-// barrier each - as in its serial additions): 16-32 serial additions per lane, then 6 all-lane exchange levels.
 __device__ __forceinline__ fq_t shfl_xor_field(const fq_t& a, int mask) {
     fq_t r;
 #pragma unroll
@@ -370,27 +335,10 @@ __device__ __forceinline__ fq_t shfl_xor_field(const fq_t& a, int mask) {
     return r;
 }
 __device__ __forceinline__ fq2_t shfl_xor_field(const fq2_t& a, int mask) { return {shfl_xor_field(a.c0, mask), shfl_xor_field(a.c1, mask)}; }
+// Sum of `acc` over the lanes of a workgroup of 64 or 256 threads: 6 all-lane exchange levels inside each wave, then (256
+// threads) the four wave totals through LDS and two more levels on wave 0.  The result is valid in thread 0.  `sh`: 4 points.
 template <class F>
-__global__ void __launch_bounds__(64) msm_fold_wave_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
-                                                           const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out_sums,
-                                                           uint32_t* __restrict__ out_start, uint32_t* __restrict__ out_cnt, int m, int hb) {
-    const uint32_t nlo = 1u << m, nhi = 1u << hb;
-    const bool column = blockIdx.x < nlo;
-    const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
-    const uint32_t slot = column ? fixed : nlo + fixed - 1;  // H_0 has weight 0 and no slot
-    if (!column && fixed == 0) {
-        if (threadIdx.x == 0) {
-            out_start[2 * nlo - 1] = 2 * nlo - 1;
-            out_cnt[2 * nlo - 1] = 0;
-        }
-        return;
-    }
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    const uint32_t cntv = column ? nhi : nlo;
-    for (uint32_t i = threadIdx.x; i < cntv; i += 64) {
-        const uint32_t k = column ? (i << m) + fixed : (fixed << m) + i;
-        for (uint32_t q = 0; q < cnt[k]; q++) acc.add(load_xyzz<F>(&sums[start[k] + q]));
-    }
+__device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh) {
 #pragma unroll 1
     for (int off = 32; off > 0; off >>= 1) {
         xyzz_t<F> o;
@@ -398,42 +346,89 @@ __global__ void __launch_bounds__(64) msm_fold_wave_kernel(const xyzz_mem_t<F>* 
         o.y = shfl_xor_field(acc.y, off);
         o.zz = shfl_xor_field(acc.zz, off);
         o.zzz = shfl_xor_field(acc.zzz, off);
-        acc.add(o);  // every lane ends with the full sum
+        acc.add(o);  // every lane of the wave ends with the wave's sum
     }
-    if (threadIdx.x == 0) {
-        store_xyzz<F>(&out_sums[slot], acc);
-        out_start[slot] = slot;
-        out_cnt[slot] = 1;
-        if (!column && nhi < nlo + 1 && fixed == nhi - 1)  // slots of window 1 beyond the last H stay empty
-            for (uint32_t s2 = nlo + nhi - 1; s2 < 2 * nlo - 1; s2++) {
-                out_start[s2] = s2;
-                out_cnt[s2] = 0;
-            }
+    if (blockDim.x == 64) return;
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) store_xyzz<F>(&sh[wv], acc);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        acc = load_xyzz<F>(&sh[threadIdx.x & 3]);
+#pragma unroll 1
+        for (int off = 2; off > 0; off >>= 1) {
+            xyzz_t<F> o;
+            o.x = shfl_xor_field(acc.x, off);
+            o.y = shfl_xor_field(acc.y, off);
+            o.zz = shfl_xor_field(acc.zz, off);
+            o.zzz = shfl_xor_field(acc.zzz, off);
+            acc.add(o);
+        }
     }
 }
-// 9. Horner across windows (batched.rs:404-413) and conversion to the reference's Jacobian memory image
+// 7a. grid (2^m + 2^hb, W): workgroups [0, 2^m) of a window fold columns (fixed lo -> L_lo, slot lo), workgroups
+// [2^m, 2^m + 2^hb) fold rows (fixed hi -> H_hi, slot 2^m + hi - 1; H_0 has weight 0 and no slot).  Bucket k = w * nb + b
+// holds cnt[k] partial sums at sums[start[k] ...].  out: per window 2^(m+1) dense slots (slot 2^(m+1) - 1 is unused).
 template <class F>
-__global__ void __launch_bounds__(64) msm_final_kernel(const xyzz_mem_t<F>* __restrict__ wsum, jac_mem_t<F>* out, int W, int c) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    // A single active lane with wave-uniform inputs gets "scalarised" by the compiler onto the SALU, whose 32-bit
-    // multiplies make a field product ~2.5x slower than v_mad_u64_u32 (measured: 20 us per G1 doubling).  An opaque VGPR
-    // zero in the address keeps the chain on the vector ALU.
-    int vz = 0;
-    asm volatile("" : "+v"(vz));
-    // total = total * 2^c + S_w: the c doublings run in Jacobian coordinates (2M + 5S each)
-    jac_t<F> j = {F::zero(), F::one(), F::zero()};
-    for (int w = W - 1; w >= 0; w--) {
-        for (int d = 0; d < c; d++) j = j.dbl();
-        xyzz_t<F> total = xyzz_t<F>::from_jacobian(j);
-        total.add(load_xyzz<F>(&wsum[w + vz]));
-        j = total.to_jacobian();
+__global__ void __launch_bounds__(256) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
+                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb) {
+    __shared__ xyzz_mem_t<F> sh[4];
+    const uint32_t nlo = 1u << m, nhi = 1u << hb;
+    const uint32_t w = blockIdx.y;
+    const uint32_t kbase = w << (m + hb);
+    const bool column = blockIdx.x < nlo;
+    const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
+    if (!column && fixed == 0) return;
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    if (column) {
+        // nhi buckets at stride 2^m: lane -> (bucket i, partial sub-range q0 + t * Q)
+        const uint32_t B = blockDim.x, Q = nhi >= B ? 1u : B / nhi;
+        for (uint32_t i = threadIdx.x % (B / Q); i < nhi; i += B / Q) {
+            const uint32_t k = kbase + (i << m) + fixed;
+            const uint32_t c = cnt[k], s0 = start[k];
+            for (uint32_t q = threadIdx.x / (B / Q); q < c; q += Q) acc.add(load_xyzz<F>(&sums[s0 + q]));
+        }
+    } else {
+        // the partial sums of the nlo consecutive buckets of a row are one contiguous range
+        const uint32_t k0 = kbase + (fixed << m);
+        const uint32_t p0 = start[k0], p1 = start[k0 + nlo - 1] + cnt[k0 + nlo - 1];
+        for (uint32_t pos = p0 + threadIdx.x; pos < p1; pos += blockDim.x) acc.add(load_xyzz<F>(&sums[pos]));
     }
-    uint32_t w[3 * F::MEM_WORDS];
-    j.x.to_raw_words(w);
-    j.y.to_raw_words(w + F::MEM_WORDS);
-    j.z.to_raw_words(w + 2 * F::MEM_WORDS);
-    uint32_t* o = (uint32_t*)out;
-    for (int i = 0; i < 3 * F::MEM_WORDS; i++) o[i] = w[i];
+    block_sum<F>(acc, sh);
+    if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
+}
+// 7b. grid (nbits, tail windows).  Tail window tw holds N entries, entry i has weight i + 1:
+//   DENSE (after a fold): tw = 2 * w + sub; sub 0 = the L sums (N = 2^m), sub 1 = the H sums (N = 2^hb - 1); entry i is
+//          sums[(w << (m + 1)) + (sub << m) + i];
+//   else (small windows): tw = w, N = nb, entry i = the cnt[k] partial sums of bucket k = w * nb + i.
+// planes[tw * nbits + j] = sum of the entries of tw whose weight has bit j set.
+template <class F, bool DENSE>
+__global__ void __launch_bounds__(256) msm_bitplane_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
+                                                           const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ planes, uint32_t nb,
+                                                           int m, int hb) {
+    __shared__ xyzz_mem_t<F> sh[4];
+    const uint32_t j = blockIdx.x, tw = blockIdx.y, nbits = gridDim.x;
+    uint32_t N;
+    size_t base;
+    if (DENSE) {
+        const uint32_t w = tw >> 1, sub = tw & 1;
+        N = sub ? (1u << hb) - 1 : (1u << m);
+        base = ((size_t)w << (m + 1)) + ((size_t)sub << m);
+    } else {
+        N = nb;
+        base = (size_t)tw * nb;
+    }
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    for (uint32_t i = threadIdx.x; i < N; i += 256) {
+        if (!(((i + 1) >> j) & 1)) continue;
+        if (DENSE) {
+            acc.add(load_xyzz<F>(&sums[base + i]));
+        } else {
+            const uint32_t c = cnt[base + i], s0 = start[base + i];
+            for (uint32_t q = 0; q < c; q++) acc.add(load_xyzz<F>(&sums[s0 + q]));
+        }
+    }
+    block_sum<F>(acc, sh);
+    if (threadIdx.x == 0) store_xyzz<F>(&planes[(size_t)tw * nbits + j], acc);
 }
 
 // ------------------------------------------------------------------------------------------

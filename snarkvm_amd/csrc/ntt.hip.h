@@ -20,6 +20,9 @@
 // Data stays in the reference's memory form (Montgomery, R = 2^256) throughout; see ff.hip.h for why the
 // 29-bit-limb arithmetic needs no conversion on this (linear) path.
 #pragma once
+#include <mutex>
+#include <vector>
+
 #include "ff.hip.h"
 
 namespace sv {
@@ -385,18 +388,43 @@ static inline ntt_plan_t ntt_make_plan(int lg) {
 
 // ---- full closing-twiddle tables ----------------------------------------------------------------------------------
 // The closing multiplication of a non-last pass needs W^((inner * k) << tw_shift); composing it from the two 4096-entry
-// tables costs a second Fr product per element, and the NTT sits on the VALU issue floor: skipping that
-// product is worth 9 % of a 2^24 transform.  So the composed twiddles of every pass shape (a, s, direction) are
-// materialised once in HBM, in exactly the order the pass stores its outputs (coalesced 32-byte reads next to the
-// 32-byte stores): 2^(a+s) entries - 512 MiB for the first pass of a 2^24 transform, 2 MiB for its second pass; ~2 GiB if
-// every size from 2^17 to 2^24 is used in both directions.  SNARKVM_HIP_NTT_FULL_TW=0 falls back to the composition.
-struct ntt_full_tw_t {
-    fr_mem_t* ptr[2][NTT_MAX_RADIX_LG + 1][NTT_LG_MAX + 1] = {};
+// tables costs a second Fr product per element, and the NTT is ALU-bound: skipping that product is worth 9 %
+// of a 2^24 transform.  So the composed twiddles of a pass shape (a, s, direction) are materialised in HBM, in exactly the
+// order the pass stores its outputs (coalesced 32-byte reads next to the 32-byte stores): 2^(a+s) entries - 512 MiB for the
+// first pass of a 2^24 transform, 2 MiB for its second pass.  The tables live in a per-device cache bounded by
+// SNARKVM_HIP_NTT_TW_MB (default 1536 MiB): least recently used tables that no running call holds are evicted; when nothing
+// can be evicted (or SNARKVM_HIP_NTT_FULL_TW=0) the pass composes its twiddles on the fly.
+struct ntt_tw_entry {
+    fr_mem_t* p = nullptr;
+    size_t bytes = 0;
+    uint64_t last_use = 0;
+    int users = 0;
+};
+struct ntt_tw_cache_t {
+    ntt_tw_entry ptr[2][NTT_MAX_RADIX_LG + 1][NTT_LG_MAX + 1];
     // the table of the pass BEFORE the last one, with 2^261 (forward) or 2^261 / n (inverse) folded in, per transform size:
     // the last pass then ends with Fp::mont_reduce_lazy() instead of a product by one / by n^-1
-    fr_mem_t* prelast[2][NTT_LG_MAX + 1] = {};
+    ntt_tw_entry prelast[2][NTT_LG_MAX + 1];
+    std::mutex mu;
+    size_t bytes = 0;
+    uint64_t tick = 0;
+    template <class Fn>
+    void for_each(Fn fn) {
+        for (auto& d : ptr)
+            for (auto& a : d)
+                for (auto& e : a) fn(e);
+        for (auto& d : prelast)
+            for (auto& e : d) fn(e);
+    }
 };
-static ntt_full_tw_t g_ntt_full_tw;  // guarded by the API mutex (api.hip)
+// what a transform needs from its caller: the stream, the device's small tables, its twiddle cache, and the list of cache
+// entries the call holds until its stream has been synchronised (released by ntt_tw_release)
+struct ntt_ctx_t {
+    hipStream_t st;
+    const ntt_tables_t* tb;
+    ntt_tw_cache_t* cache;
+    std::vector<void*>* leases;
+};
 // fold: 0 plain, 1 times 2^261, 2 times 2^261 * size_inv (size_inv points at the Montgomery form of n^-1)
 static __global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a, int s, int tw_shift, const fr_mem_t* __restrict__ lo,
                                         const fr_mem_t* __restrict__ hi, int fold, const fr_mem_t* __restrict__ size_inv) {
@@ -410,29 +438,53 @@ static __global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a
     }
     t.store(&out[idx]);
 }
-// prelast_lg != 0: this is the pass before the last one of a 2^prelast_lg transform -> the folded variant (see ntt_full_tw_t)
-static inline const fr_mem_t* ntt_get_full_tw(hipStream_t st, const ntt_tables_t& tb, int a, int s, int tw_shift, int dir, int prelast_lg = 0,
-                                              bool* folded = nullptr) {
+static inline void ntt_tw_release_entries(ntt_tw_cache_t& cache, std::vector<void*>& leases) {
+    std::lock_guard<std::mutex> lk(cache.mu);
+    for (void* e : leases) ((ntt_tw_entry*)e)->users--;
+    leases.clear();
+}
+// prelast_lg != 0: this is the pass before the last one of a 2^prelast_lg transform -> the folded variant
+static inline const fr_mem_t* ntt_get_full_tw(const ntt_ctx_t& cx, int a, int s, int tw_shift, int dir, int prelast_lg = 0, bool* folded = nullptr) {
     if (folded) *folded = false;
     static const int enabled = getenv("SNARKVM_HIP_NTT_FULL_TW") ? atoi(getenv("SNARKVM_HIP_NTT_FULL_TW")) : 1;
-    if (!enabled || a + s > NTT_LG_MAX || a > NTT_MAX_RADIX_LG) return nullptr;
+    if (!enabled || !cx.cache || a + s > NTT_LG_MAX || a > NTT_MAX_RADIX_LG) return nullptr;
     static const int fold_enabled = getenv("SNARKVM_HIP_NTT_FOLD") ? atoi(getenv("SNARKVM_HIP_NTT_FOLD")) : 1;
+    static const size_t cap = (getenv("SNARKVM_HIP_NTT_TW_MB") ? (size_t)atoll(getenv("SNARKVM_HIP_NTT_TW_MB")) : 1536) << 20;
     if (prelast_lg && !fold_enabled) prelast_lg = 0;
-    fr_mem_t*& slot = prelast_lg ? g_ntt_full_tw.prelast[dir][prelast_lg] : g_ntt_full_tw.ptr[dir][a][a + s];
-    if (!slot) {
+    ntt_tw_cache_t& cache = *cx.cache;
+    std::lock_guard<std::mutex> lk(cache.mu);
+    ntt_tw_entry& slot = prelast_lg ? cache.prelast[dir][prelast_lg] : cache.ptr[dir][a][a + s];
+    if (!slot.p) {
         const size_t n = (size_t)1 << (a + s);
-        if (hipMalloc((void**)&slot, n * sizeof(fr_mem_t)) != hipSuccess) {
+        const size_t need = n * sizeof(fr_mem_t);
+        if (need > cap) return nullptr;
+        while (cache.bytes + need > cap) {  // evict the least recently used table nobody holds
+            ntt_tw_entry* lru = nullptr;
+            cache.for_each([&](ntt_tw_entry& e) {
+                if (e.p && e.users == 0 && (!lru || e.last_use < lru->last_use)) lru = &e;
+            });
+            if (!lru) return nullptr;  // everything is in use: compose on the fly
+            (void)hipFree(lru->p);
+            cache.bytes -= lru->bytes;
+            *lru = ntt_tw_entry();
+        }
+        if (hipMalloc((void**)&slot.p, need) != hipSuccess) {
             (void)hipGetLastError();
-            slot = nullptr;
+            slot.p = nullptr;
             return nullptr;  // out of memory: compose on the fly
         }
+        slot.bytes = need;
+        cache.bytes += need;
         const int fold = !prelast_lg ? 0 : (dir == NTT_INVERSE ? 2 : 1);
-        hipLaunchKernelGGL(ntt_fill_full_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slot, a, s, tw_shift, tb.pow_lo[dir], tb.pow_hi[dir],
-                           fold, (const fr_mem_t*)(tb.size_inv + (prelast_lg ? prelast_lg : 0)));
-        (void)hipStreamSynchronize(st);  // other streams may use the table from now on
+        hipLaunchKernelGGL(ntt_fill_full_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.st, slot.p, a, s, tw_shift, cx.tb->pow_lo[dir],
+                           cx.tb->pow_hi[dir], fold, (const fr_mem_t*)(cx.tb->size_inv + (prelast_lg ? prelast_lg : 0)));
+        (void)hipStreamSynchronize(cx.st);  // other streams may use the table from now on
     }
+    slot.last_use = ++cache.tick;
+    slot.users++;
+    if (cx.leases) cx.leases->push_back(&slot);
     if (folded) *folded = prelast_lg != 0;
-    return slot;
+    return slot.p;
 }
 
 static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb) {
@@ -449,8 +501,9 @@ static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const nt
 
 // NN-order transform of 2^lg elements held in `data`; `scratch` is a second buffer of the same size.
 // The result is left in `data`.
-static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* data, fr_mem_t* scratch, int lg,
-                              int dir, int type) {
+static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scratch, int lg, int dir, int type) {
+    hipStream_t st = cx.st;
+    const ntt_tables_t& tb = *cx.tb;
     if (lg == 0) {
         // size-1 transform: identity (coset shift g^0 = 1, n^-1 = 1)
         return;
@@ -477,7 +530,7 @@ static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* 
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
             const bool prelast = (k == pl.npass - 2);
             bool f = false;
-            p.tw_full = ntt_get_full_tw(st, tb, p.a, p.s, p.tw_shift, dir, prelast ? lg : 0, &f);
+            p.tw_full = ntt_get_full_tw(cx, p.a, p.s, p.tw_shift, dir, prelast ? lg : 0, &f);
             folded = f;
         } else {
             p.reduce_only = folded ? 1 : 0;
@@ -506,15 +559,15 @@ static inline void ntt_run_nn(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* 
 }
 
 // Full FFI semantics (any order): bit-reversed inputs/outputs are handled with an explicit permutation pass.
-static inline void ntt_run(hipStream_t st, const ntt_tables_t& tb, fr_mem_t* data, fr_mem_t* scratch, int lg, int order,
-                           int dir, int type) {
+static inline void ntt_run(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scratch, int lg, int order, int dir, int type) {
+    hipStream_t st = cx.st;
     const size_t n = (size_t)1 << lg;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (order == NTT_RN || order == NTT_RR) {
         hipLaunchKernelGGL(ntt_bitrev_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, lg);
         (void)hipMemcpyAsync(data, scratch, sizeof(fr_mem_t) * n, hipMemcpyDeviceToDevice, st);
     }
-    ntt_run_nn(st, tb, data, scratch, lg, dir, type);
+    ntt_run_nn(cx, data, scratch, lg, dir, type);
     if (order == NTT_NR || order == NTT_RR) {
         hipLaunchKernelGGL(ntt_bitrev_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, lg);
         (void)hipMemcpyAsync(data, scratch, sizeof(fr_mem_t) * n, hipMemcpyDeviceToDevice, st);

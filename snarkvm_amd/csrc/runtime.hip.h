@@ -12,9 +12,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/snarkvm_hip.h"
@@ -55,12 +61,12 @@ static RustError from_failure(const hip_failure& f) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// context
+// runtime: devices, lanes (the reference's (dev, stream) resource tokens), staging buffers
 // ------------------------------------------------------------------------------------------------
 struct dev_buf {
     void* p = nullptr;
     size_t cap = 0;
-    void ensure(size_t bytes) {
+    void ensure(size_t bytes) {  // on the CURRENT device (a lane guard has selected it)
         if (bytes <= cap) return;
         if (p) HIP_TRY(hipFree(p));
         p = nullptr;
@@ -74,13 +80,22 @@ struct dev_buf {
         return (T*)p;
     }
 };
-
-struct msm_ws_t {
-    hipStream_t stream = nullptr;
-    dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, contrib, wsum, result;
-    dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
-    dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
-    dev_buf fold_sums, fold_idx;                                              // two-axis bucket fold (wide windows)
+struct pinned_buf {  // page-locked host staging (the reference's per-GPU pinned arena, snarkvm.cu:51,123-151)
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_TRY(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    template <class T>
+    T* as() const {
+        return (T*)p;
+    }
 };
 
 struct phase_rec {
@@ -88,47 +103,73 @@ struct phase_rec {
     hipEvent_t e0, e1;
     double ms;
 };
+struct device_t;
 
-struct context_t {
-    std::mutex mu;
-    bool ready = false;
-    int device = 0;
+// One lane = one HIP stream of one device with every scratch buffer a call needs: what a `(dev, stream)` token of the
+// reference's resource channel stands for (snarkvm.cu:84,146-150).  A caller owns a lane for the duration of one API call;
+// concurrent callers (rayon workers: one commitment each, sonic_pc/mod.rs:203-245) get different lanes / devices.
+struct lane_t {
+    device_t* dev = nullptr;
+    int index = 0;
     hipStream_t stream = nullptr;
-    ntt_tables_t tb{};
-    dev_buf tables_mem;
-    // NTT staging
-    dev_buf ntt_data, ntt_scratch, ntt_acc;
-    dev_buf serde_status;  // one u32 of SERDE_* bits (serde.hip.h)
-    dev_buf poly[5];  // staging / scratch of the prover-round vector kernels (poly.hip.h)
-    // MSM workspaces: lane 0 runs on the main stream; lanes 1.. are used by the batch API so that the latency-bound
-    // tail of one MSM (bucket reduction, Horner) overlaps the throughput-bound accumulation of the next
-    static constexpr int LANES = 8;  // streams + workspaces available to the batch API
-    msm_ws_t lane[LANES];
-    // lanes a batch actually cycles through: more lanes hide more of the latency-bound tail of small MSMs, fewer keep the
-    // workspace footprint of big ones down (a 2^24 lane holds ~4 GB)
-    static int batch_lanes(size_t npoints) {
-        static const int env = getenv("SNARKVM_HIP_LANES") ? atoi(getenv("SNARKVM_HIP_LANES")) : 0;
-        int l = env > 0 ? env : (npoints >= ((size_t)1 << 20) ? 3 : LANES);  // measured: 8 lanes +7 % below 2^20, no gain above
-        return l < 1 ? 1 : (l > LANES ? LANES : l);
-    }
+    // MSM workspace
+    dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, planes;
+    dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
+    dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
+    dev_buf fold_sums;                                                        // two-axis bucket fold
     dev_buf bases_tmp, scalars_tmp, gen_pts, gen_prod;
-    void* batch_pinned = nullptr;
-    size_t batch_pinned_cap = 0;
+    // NTT / polynomial staging
+    dev_buf ntt_data, ntt_scratch, ntt_acc, ntt_alt;
+    dev_buf serde_status;  // one u32 of SERDE_* bits (serde.hip.h)
+    dev_buf poly[5];       // staging / scratch of the prover-round vector kernels (poly.hip.h)
+    pinned_buf pin, pin2;  // host staging: MSM bit-plane sums / chunked uploads
+    hipStream_t alt = nullptr;  // second stream of the lane: copies of operand k + 1 while operand k is transformed (polynomial.cuh:136-242)
+    hipEvent_t ev[4] = {};
+    std::vector<void*> tw_leases;  // twiddle tables this call pinned in the device's cache
     // profiling
-    bool profiling = false;
     std::vector<phase_rec> phases;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
 
-    void init() {
+    hipEvent_t new_event() {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+    inline ntt_ctx_t ntt_ctx(hipStream_t st = nullptr);
+    inline void begin_call();
+    inline void phase_begin(const char* name);
+    inline void phase_end();
+    inline void end_call();
+};
+
+struct device_t {
+    int logical = 0, physical = 0;
+    bool ready = false;
+    std::mutex init_mu;
+    ntt_tables_t tb{};
+    dev_buf tables_mem;
+    ntt_tw_cache_t tw;
+    static constexpr int LANES = 8;
+    lane_t lane[LANES];
+    // token pool
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t busy = 0;
+
+    void init() {  // the calling thread has this device current
+        std::lock_guard<std::mutex> lk(init_mu);
         if (ready) return;
-        int ndev = 0;
-        hipError_t e = hipGetDeviceCount(&ndev);
-        if (e != hipSuccess || ndev == 0) throw hip_failure{e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount (no MI355X visible)", __LINE__};
-        HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        lane[0].stream = stream;
-        for (int l = 1; l < LANES; l++) HIP_TRY(hipStreamCreateWithFlags(&lane[l].stream, hipStreamNonBlocking));
+        for (int l = 0; l < LANES; l++) {
+            lane[l].dev = this;
+            lane[l].index = l;
+            HIP_TRY(hipStreamCreateWithFlags(&lane[l].stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&lane[l].alt, hipStreamNonBlocking));
+            for (auto& e : lane[l].ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         // tables: 4 x (lo + hi) x 4096 + 2 x 128 + 25 + 4, 32 B each
         const size_t entries = 8 * NTT_TW_SIZE + 256 + 32 + 8;
         tables_mem.ensure(entries * sizeof(fr_mem_t));
@@ -148,53 +189,247 @@ struct context_t {
         }
         tb.size_inv = take(32);
         tb.consts = take(8);
-        hipLaunchKernelGGL(ntt_setup_consts, dim3(1), dim3(64), 0, stream, tb);
-        hipLaunchKernelGGL(ntt_fill_tables, dim3(NTT_TW_SIZE / 256), dim3(256), 0, stream, tb);
+        hipStream_t st = lane[0].stream;
+        hipLaunchKernelGGL(ntt_setup_consts, dim3(1), dim3(64), 0, st, tb);
+        hipLaunchKernelGGL(ntt_fill_tables, dim3(NTT_TW_SIZE / 256), dim3(256), 0, st, tb);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipStreamSynchronize(st));
         ready = true;
     }
-    // ---- profiling helpers
-    hipEvent_t new_event() {
-        if (events_used == event_pool.size()) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e));
-            event_pool.push_back(e);
+    // lowest free lanes, up to `want` (at least one: blocks until a lane is free); returns the number taken
+    int take(lane_t** out, int want) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return busy != (1u << LANES) - 1; });
+        int got = 0;
+        for (int l = 0; l < LANES && got < want; l++)
+            if (!(busy & (1u << l))) {
+                busy |= 1u << l;
+                out[got++] = &lane[l];
+            }
+        return got;
+    }
+    bool try_take(lane_t** out) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int l = 0; l < LANES; l++)
+            if (!(busy & (1u << l))) {
+                busy |= 1u << l;
+                *out = &lane[l];
+                return true;
+            }
+        return false;
+    }
+    void give(lane_t* l) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            busy &= ~(1u << l->index);
         }
-        return event_pool[events_used++];
-    }
-    void begin_call() {
-        phases.clear();
-        events_used = 0;
-    }
-    void phase_begin(const char* name) {
-        if (!profiling) return;
-        phase_rec r{name, new_event(), new_event(), 0.0};
-        HIP_TRY(hipEventRecord(r.e0, stream));
-        phases.push_back(r);
-    }
-    void phase_end() {
-        if (!profiling) return;
-        HIP_TRY(hipEventRecord(phases.back().e1, stream));
-    }
-    void end_call() {
-        if (!profiling) return;
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (auto& r : phases) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
-            r.ms = ms;
-        }
+        cv.notify_one();
     }
 };
-extern context_t g_ctx;  // defined in api.hip
 
-struct snarkvm_hip_bases {
-    g1_aff_mem_t* d = nullptr;  // tables * n entries: table j at d + j * n holds 2^(256 / tables * j) * P_i
+// The process-wide runtime: the set of devices in use (the reference's `ngpus()` loop, snarkvm.cu:123-151), chosen by
+// snarkvm_hip_set_devices / SNARKVM_HIP_DEVICES (default: every visible device).  A physical device may be listed more than
+// once: each entry is an independent logical device (own streams, workspaces, base replicas) - how the multi-device paths
+// are exercised on a one-GPU box.
+struct runtime_t {
+    std::mutex cfg_mu;
+    std::vector<int> want;  // physical ids requested (empty: default)
+    std::vector<std::unique_ptr<device_t>> devs;
+    bool configured = false;
+    std::atomic<uint32_t> rr{0};
+    // profiling: phases of the most recent profiled call (any lane)
+    std::atomic<bool> profiling{false};
+    std::mutex prof_mu;
+    std::vector<std::pair<std::string, double>> last_phases;
+
+    void configure() {
+        std::lock_guard<std::mutex> lk(cfg_mu);
+        if (configured) return;
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) throw hip_failure{e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount (no MI355X visible)", __LINE__};
+        std::vector<int> ids = want;
+        if (ids.empty()) {
+            if (const char* env = getenv("SNARKVM_HIP_DEVICES")) {
+                for (const char* p = env; *p;) {
+                    char* end = nullptr;
+                    long v = strtol(p, &end, 10);
+                    if (end == p) break;
+                    ids.push_back((int)v);
+                    p = (*end == ',') ? end + 1 : end;
+                }
+            }
+        }
+        if (ids.empty())
+            for (int d = 0; d < ndev; d++) ids.push_back(d);
+        for (int id : ids)
+            if (id < 0 || id >= ndev) throw hip_failure{hipErrorInvalidDevice, "device index out of range (snarkvm_hip_set_devices / SNARKVM_HIP_DEVICES)", __LINE__};
+        for (size_t i = 0; i < ids.size(); i++) {
+            devs.emplace_back(new device_t());
+            devs.back()->logical = (int)i;
+            devs.back()->physical = ids[i];
+        }
+        configured = true;
+    }
+    int ndev() {
+        configure();
+        return (int)devs.size();
+    }
+    // logical device that owns a device pointer (-1: not a device pointer of a configured device)
+    int device_of(const void* ptr) {
+        configure();
+        hipPointerAttribute_t at;
+        if (!ptr || hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        std::vector<int> match;
+        for (auto& d : devs)
+            if (d->physical == at.device) match.push_back(d->logical);
+        if (match.empty()) return -1;
+        return match[rr.fetch_add(1) % match.size()];
+    }
+};
+extern runtime_t g_rt;  // defined in api.hip
+
+// Per-(translation unit, device) kernel attributes: kernels with more than 64 KB of dynamic LDS need the attribute on THEIR
+// function object; the non-template kernels are static, i.e. every unit launches its own copy.
+static void tu_kernel_attributes(int logical) {
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)done.size() <= logical) done.resize(logical + 1, 0);
+    if (done[logical]) return;
+#ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+#endif
+    done[logical] = 1;
+}
+
+// RAII ownership of lanes.  Selecting a lane makes its device current on the calling thread (the HIP current device is per
+// host thread - rayon workers!) and restores the previous one on release.
+struct lane_guard {
+    std::vector<lane_t*> lanes;
+    int prev_device = -1;
+    lane_guard() {}
+    lane_guard(const lane_guard&) = delete;
+    // one lane on logical device `dev`, or on the least busy device when dev < 0
+    explicit lane_guard(int dev) { acquire(dev, 1); }
+    void acquire(int dev, int want) {
+        g_rt.configure();
+        if (prev_device < 0 && hipGetDevice(&prev_device) != hipSuccess) prev_device = 0;
+        const int nd = (int)g_rt.devs.size();
+        device_t* d = nullptr;
+        lane_t* got[device_t::LANES];
+        int n = 0;
+        if (dev >= 0) {
+            if (dev >= nd) throw hip_failure{hipErrorInvalidDevice, "logical device index out of range", __LINE__};
+            d = g_rt.devs[dev].get();
+        } else {
+            const uint32_t s = g_rt.rr.fetch_add(1);
+            for (int i = 0; i < nd && !d; i++) {  // first device (round-robin start) with a free lane
+                device_t* cand = g_rt.devs[(s + i) % nd].get();
+                if (want == 1) {
+                    if (cand->try_take(&got[0])) {
+                        d = cand;
+                        n = 1;
+                    }
+                } else {
+                    d = cand;
+                }
+            }
+            if (!d) d = g_rt.devs[s % nd].get();
+        }
+        if (!n) n = d->take(got, want);
+        for (int i = 0; i < n; i++) lanes.push_back(got[i]);
+        HIP_TRY(hipSetDevice(d->physical));
+        d->init();
+        tu_kernel_attributes(d->logical);
+    }
+    lane_t& c() { return *lanes[0]; }
+    ~lane_guard() {
+        for (lane_t* l : lanes) l->dev->give(l);
+        if (prev_device >= 0) (void)hipSetDevice(prev_device);
+    }
+};
+
+inline ntt_ctx_t lane_t::ntt_ctx(hipStream_t st) { return ntt_ctx_t{st ? st : stream, &dev->tb, &dev->tw, &tw_leases}; }
+inline void lane_t::begin_call() {
+    phases.clear();
+    events_used = 0;
+}
+inline void lane_t::phase_begin(const char* name) {
+    if (!g_rt.profiling.load(std::memory_order_relaxed)) return;
+    phase_rec r{name, new_event(), new_event(), 0.0};
+    HIP_TRY(hipEventRecord(r.e0, stream));
+    phases.push_back(r);
+}
+inline void lane_t::phase_end() {
+    if (!g_rt.profiling.load(std::memory_order_relaxed) || phases.empty()) return;
+    HIP_TRY(hipEventRecord(phases.back().e1, stream));
+}
+static void ntt_tw_release(device_t* dev, std::vector<void*>& leases) { ntt_tw_release_entries(dev->tw, leases); }
+inline void lane_t::end_call() {
+    if (!tw_leases.empty()) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        ntt_tw_release(dev, tw_leases);
+    }
+    if (phases.empty()) return;
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<std::pair<std::string, double>> out;
+    for (auto& r : phases) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+        r.ms = ms;
+        out.emplace_back(r.name, (double)ms);
+    }
+    std::lock_guard<std::mutex> lk(g_rt.prof_mu);
+    g_rt.last_phases.swap(out);
+}
+
+// fn(logical device) on every listed device: inline for one device, one host thread per device otherwise (the reference's
+// per-GPU `pool.spawn`, snarkvm.cu:262).  The first exception is rethrown on the caller's thread.
+template <class Fn>
+static void for_each_device(const std::vector<int>& devices, Fn fn) {
+    if (devices.size() <= 1) {
+        for (int d : devices) fn(d);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> errs(devices.size());
+    for (size_t i = 0; i < devices.size(); i++)
+        th.emplace_back([&, i] {
+            try {
+                fn(devices[i]);
+            } catch (...) {
+                errs[i] = std::current_exception();
+            }
+        });
+    for (auto& t : th) t.join();
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
+}
+
+// registered base vectors: one replica per logical device (every device holds its own copy of the static SRS)
+template <class F>
+struct bases_handle_t {
+    std::vector<aff_mem_t<F>*> d;  // [logical device]: tables * n entries: table j at d + j * n holds 2^(table_bits * j) * P_i
     size_t n = 0;
     int tables = 1;
     int table_bits = 256;  // table j = 2^(table_bits * j) * P
+    void free_all() {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        for (size_t i = 0; i < d.size(); i++)
+            if (d[i]) {
+                (void)hipSetDevice(g_rt.devs[i]->physical);
+                (void)hipFree(d[i]);
+                d[i] = nullptr;
+            }
+        (void)hipSetDevice(prev);
+    }
 };
+struct snarkvm_hip_bases : bases_handle_t<fq_t> {};
 
 // ------------------------------------------------------------------------------------------------
 // MSM driver
@@ -209,27 +444,93 @@ static void write_infinity(void* out) {
     memcpy((uint8_t*)out + fb, FQ_R, 48);
 }
 
-// d_bases: converted device bases; d_scalars: device scalars (32 B each); result written to host `out` (144 B)
+// ---- host-side finish of an MSM --------------------------------------------------------------------------------------
+// The device leaves `nplanes` bit-plane sums (msm.hip.h 7b): the MSM result is sum_i 2^(pos[i]) * plane[i].  The remaining
+// Horner chain (<= ~270 doublings of wave-uniform data) runs here, on the host, with the SAME field / curve code compiled
+// for the host - the counterpart of the reference's host-side `dadd` collapse of its per-GPU results
+// (algorithms/cuda/cuda/snarkvm.cu:290-295).  Several devices / chunks of one MSM simply add their planes into the same
+// accumulator before the chain (msm_accum_t::add_planes), which is the whole multi-GPU combine.
+static constexpr int MSM_MAX_POS = 320;
 template <class F>
-static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
-                    const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
-                    size_t table_stride = 0, int lane_idx = 0, bool sync = true, int table_bits = 0) {
-    msm_ws_t& c = ctx.lane[lane_idx];
-    // per-phase HIP events only on the synchronous single-MSM path (lane 0)
-    auto phase_begin = [&](const char* name) { if (lane_idx == 0 && sync) ctx.phase_begin(name); };
-    auto phase_end = [&]() { if (lane_idx == 0 && sync) ctx.phase_end(); };
-    if (n0 > n) n0 = n;
-    if (n == 0) {
-        write_infinity<F>(out);
-        return;
+struct msm_accum_t {
+    xyzz_t<F> at[MSM_MAX_POS];
+    bool used[MSM_MAX_POS];
+    int top = -1;
+    msm_accum_t() {
+        for (int i = 0; i < MSM_MAX_POS; i++) used[i] = false;
     }
+    void add(int pos, const xyzz_t<F>& p) {
+        if (p.is_inf()) return;
+        if (pos < 0 || pos >= MSM_MAX_POS) throw std::runtime_error("msm: bit position out of range");
+        if (!used[pos]) {
+            at[pos] = p;
+            used[pos] = true;
+        } else {
+            at[pos].add(p);
+        }
+        if (pos > top) top = pos;
+    }
+    // total = sum_p 2^p at[p], Jacobian memory image (the reference's Projective; infinity = (0, 1, 0))
+    void finish(void* out) const {
+        jac_t<F> j = {F::zero(), F::one(), F::zero()};
+        for (int p = top; p >= 0; p--) {
+            j = j.dbl();  // 2M + 5S (projective.rs:302-339)
+            if (used[p]) {
+                xyzz_t<F> t = xyzz_t<F>::from_jacobian(j);
+                t.add(at[p]);
+                j = t.to_jacobian();
+            }
+        }
+        uint32_t w[3 * F::MEM_WORDS];
+        j.x.to_raw_words(w);
+        j.y.to_raw_words(w + F::MEM_WORDS);
+        j.z.to_raw_words(w + 2 * F::MEM_WORDS);
+        memcpy(out, w, sizeof w);
+    }
+};
+// what one device-side MSM run leaves for the host: planes (pinned host memory, valid after the lane's stream has been
+// synchronised) and the bit position of each plane
+struct msm_pending_t {
+    const void* planes = nullptr;  // xyzz_mem_t<F>[nplanes]
+    int nplanes = 0;
+    int tail_windows = 0, nbits = 0;
+    // position of plane (tw, j): DENSE (folded): tw = 2 w + sub -> c w + sub m + j; else tw = w -> c w + j
+    int c = 0, m = 0;
+    bool folded = false;
+    int pos(int idx) const {
+        const int tw = idx / nbits, j = idx % nbits;
+        return folded ? c * (tw >> 1) + (tw & 1) * m + j : c * tw + j;
+    }
+};
+template <class F>
+static void msm_collect(msm_accum_t<F>& acc, const msm_pending_t& pd) {
+    const xyzz_mem_t<F>* pl = (const xyzz_mem_t<F>*)pd.planes;
+    for (int i = 0; i < pd.nplanes; i++) acc.add(pd.pos(i), load_xyzz<F>(&pl[i]));
+}
+
+// Device side of one MSM on lane `c`: d_bases = converted device bases; d_scalars = device scalars (32 B each).  Everything
+// is enqueued on the lane's stream, ending with the copy of the bit-plane sums into `host_planes` (pinned, >=
+// msm_plane_bytes<F>(...)); the caller synchronises the stream and runs msm_collect / msm_accum_t::finish.
+template <class F>
+static size_t msm_plane_bytes() {
+    return (size_t)MSM_MAX_POS * sizeof(xyzz_mem_t<F>);  // upper bound on tail windows * bits
+}
+template <class F>
+static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* host_planes, int window_bits,
+                             const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
+                             size_t table_stride = 0, bool profile = true, int table_bits = 0) {
+    auto phase_begin = [&](const char* name) { if (profile) c.phase_begin(name); };
+    auto phase_end = [&]() { if (profile) c.phase_end(); };
+    msm_pending_t pd;
+    pd.planes = host_planes;
+    if (n0 > n) n0 = n;
+    if (n == 0) return pd;  // no planes: the sum is the point at infinity
     if (n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: npoints must be < 2^31", __LINE__};
     const msm_plan_t pl = msm_make_plan(n, window_bits, tables, table_bits);
-    const bool wide = pl.c > 16;  // u32 digits, three-level sort, two-axis bucket fold
+    const bool wide = pl.c > 16;  // u32 digits, three-level sort
     if ((size_t)pl.Wd * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: windows * npoints must be < 2^32", __LINE__};
     if ((size_t)pl.J * n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: tables * npoints must be < 2^31", __LINE__};
     hipStream_t st = c.stream;
-    constexpr unsigned WS_THREADS = sizeof(xyzz_mem_t<F>) > 192 ? 128 : 256;  // window-sum LDS tile <= 48 KiB
     const size_t E_max = (size_t)pl.Wd * n;
     const uint32_t nbt = pl.nbt;
 
@@ -246,21 +547,21 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
     const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
     c.part_a.ensure(T0_max * sizeof(xyzz_mem_t<F>));
     c.part_b.ensure(T1_max * sizeof(xyzz_mem_t<F>));
-    // tail geometry: a wide window is first folded into two windows of 2^fold_m entries (msm_fold_kernel)
+    // tail geometry: windows of >= 2^11 buckets are first folded into two tail windows of 2^fold_m / 2^fold_hb - 1 entries
     const int K = pl.c - 1;
     const int fold_m = (K + 1) / 2, fold_hb = K - fold_m;
-    static const int fold_min_k = getenv("SNARKVM_HIP_FOLD_MIN_K") ? atoi(getenv("SNARKVM_HIP_FOLD_MIN_K")) : 11;
-    const bool fold = pl.W == 1 && (wide || K >= fold_min_k);  // also shortens the latency-bound tail of 16-bit windows
-    const uint32_t tail_nb = fold ? (1u << fold_m) : pl.nb;
-    const int tail_W = fold ? 2 : pl.W;
-    const int tail_c = fold ? fold_m : pl.c;
-    uint32_t tail_L = fold ? (pl.L < 4 ? pl.L : 4) : pl.L;
-    if (tail_L > tail_nb) tail_L = tail_nb;
-    while (tail_nb % tail_L) tail_L--;
-    const uint32_t J = tail_nb / tail_L;
-    c.contrib.ensure((size_t)tail_W * J * sizeof(xyzz_mem_t<F>));
-    c.wsum.ensure((size_t)tail_W * sizeof(xyzz_mem_t<F>));
-    c.result.ensure(sizeof(jac_mem_t<F>));
+    const bool fold = K >= 11;
+    const int tail_windows = fold ? 2 * pl.W : pl.W;
+    const int nbits = fold ? fold_m + 1 : pl.c;  // weights run up to 2^fold_m (L sums) / 2^(c-1) (plain buckets)
+    pd.tail_windows = tail_windows;
+    pd.nbits = nbits;
+    pd.nplanes = tail_windows * nbits;
+    pd.c = pl.c;
+    pd.m = fold_m;
+    pd.folded = fold;
+    if (pd.nplanes > MSM_MAX_POS || pl.c * (pl.W - 1) + (fold ? fold_m : 0) + nbits > MSM_MAX_POS)
+        throw hip_failure{hipErrorInvalidValue, "msm: window geometry exceeds the tail's bit-position range", __LINE__};
+    c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
 
     // 1. digits
     phase_begin("msm_digits");
@@ -393,7 +694,9 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         {
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
             // (the tail kernels add up to TAIL_PARTIALS leftover partials per bucket themselves: one reduce round less)
-            static const size_t tail_partials = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 4;
+            // short segments (small MSMs) leave a few more: a reduce round costs more latency than the fold's extra additions
+            static const size_t env_tailp = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 0;
+            const size_t tail_partials = env_tailp ? env_tailp : (pl.S <= 16 ? 16 : 4);
             for (size_t m = max_bucket ? ((size_t)max_bucket - 1) / pl.S + 2 : 0; m > tail_partials; m = (m + pl.S2 - 1) / pl.S2) rounds++;
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
@@ -426,86 +729,198 @@ static void msm_run(context_t& ctx, const aff_mem_t<F>* d_bases, const uint4* d_
         T_in_max = T_out_max;
     }
     phase_end();
-    // 7.-9. bucket reduction, window sums, Horner
+    // 7.-9. fold -> bit-plane sums -> (host) Horner
     phase_begin("msm_bucket_reduce");
-    const xyzz_mem_t<F>* tail_sums = pin;
-    const uint32_t *tail_start = start_in, *tail_cnt = cnt_in;
     if (fold) {
-        const uint32_t slots = 2u << fold_m;
-        c.fold_sums.ensure((size_t)slots * sizeof(xyzz_mem_t<F>));
-        c.fold_idx.ensure((size_t)slots * 8);
-        uint32_t* fstart = c.fold_idx.as<uint32_t>();
-        uint32_t* fcnt = fstart + slots;
-        hipLaunchKernelGGL((msm_fold_wave_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb)), dim3(64), 0, st, pin, start_in, cnt_in,
-                           c.fold_sums.as<xyzz_mem_t<F>>(), fstart, fcnt, fold_m, fold_hb);
-        tail_sums = c.fold_sums.as<xyzz_mem_t<F>>();
-        tail_start = fstart;
-        tail_cnt = fcnt;
+        c.fold_sums.ensure(((size_t)pl.W << (fold_m + 1)) * sizeof(xyzz_mem_t<F>));
+        // small MSMs are latency-bound (256 threads per output: short serial part); big ones throughput-bound (one wave per output)
+        const unsigned fold_threads = nbt >= (1u << 18) ? 64u : 256u;
+        hipLaunchKernelGGL((msm_fold_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in, cnt_in,
+                           c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(256), 0, st,
+                           (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, fold_m, fold_hb);
+    } else {
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, false>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(256), 0, st, pin, start_in, cnt_in,
+                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0);
     }
-    const uint32_t total_threads = (uint32_t)tail_W * J;
-    hipLaunchKernelGGL((msm_bucket_reduce_kernel<F>), dim3((total_threads + 255) / 256), dim3(256), 0, st, tail_sums, tail_start, tail_cnt,
-                       c.contrib.as<xyzz_mem_t<F>>(), tail_nb, tail_L, total_threads);
-    hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(tail_W), dim3(WS_THREADS), WS_THREADS * sizeof(xyzz_mem_t<F>), st, c.contrib.as<xyzz_mem_t<F>>(), c.wsum.as<xyzz_mem_t<F>>(), J);
-    phase_end();
-    phase_begin("msm_final_horner");
-    hipLaunchKernelGGL((msm_final_kernel<F>), dim3(1), dim3(64), 0, st, c.wsum.as<xyzz_mem_t<F>>(), c.result.as<jac_mem_t<F>>(), tail_W, tail_c);
     phase_end();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, c.result.p, sizeof(jac_mem_t<F>), hipMemcpyDeviceToHost, st));  // `out` is pinned when !sync
-    if (sync) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(host_planes, c.planes.p, (size_t)pd.nplanes * sizeof(xyzz_mem_t<F>), hipMemcpyDeviceToHost, st));
+    return pd;
+}
+// synchronous single MSM: run, wait, finish on the host into `out` (Jacobian memory image)
+template <class F>
+static void msm_run_sync(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
+                         const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
+                         size_t table_stride = 0, int table_bits = 0) {
+    c.pin.ensure(msm_plane_bytes<F>());
+    const msm_pending_t pd = msm_run<F>(c, d_bases, d_scalars, n, c.pin.p, window_bits, d_bases1, n0, scalars_montgomery, tables, table_stride, true, table_bits);
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    c.phase_begin("msm_host_finish");
+    c.phase_end();
+    msm_accum_t<F>* acc = new msm_accum_t<F>();
+    std::unique_ptr<msm_accum_t<F>> hold(acc);
+    msm_collect<F>(*acc, pd);
+    acc->finish(out);
 }
 
 template <class F>
-static void convert_bases(context_t& c, const uint8_t* d_in, size_t stride, size_t n, aff_mem_t<F>* d_out) {
+static void convert_bases(lane_t& c, const uint8_t* d_in, size_t stride, size_t n, aff_mem_t<F>* d_out, hipStream_t st = nullptr) {
     if (!n) return;
-    hipLaunchKernelGGL((convert_bases_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_in, stride, n, d_out);
+    hipLaunchKernelGGL((convert_bases_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st ? st : c.stream, d_in, stride, n, d_out);
     HIP_TRY(hipGetLastError());
 }
 
-// Plain FFI MSM (host pointers): stage, convert, run.  G1: F = fq_t (stride >= 104), G2: F = fq2_t (stride >= 200).
+// lanes a batch cycles through per device: more lanes hide more of the latency-bound tail of small MSMs, fewer keep the
+// workspace footprint of big ones down (a 2^24 lane holds ~4 GB)
+static int batch_lanes(size_t npoints) {
+    static const int env = getenv("SNARKVM_HIP_LANES") ? atoi(getenv("SNARKVM_HIP_LANES")) : 0;
+    int l = env > 0 ? env : (npoints >= ((size_t)1 << 20) ? 3 : device_t::LANES);  // measured: 8 lanes +7 % below 2^20, no gain above
+    return l < 1 ? 1 : (l > device_t::LANES ? device_t::LANES : l);
+}
+static constexpr size_t MSM_SPLIT_MIN = (size_t)1 << 18;  // pairs per device below which a point-range split costs more than it saves
+static constexpr size_t MSM_CHUNK = (size_t)1 << 21;      // pairs per upload / compute chunk of an MSM whose bases arrive from the host
+
+// The reference's FFI MSM (host bases, host scalars, no registration): G1: F = fq_t (stride >= 104), G2: F = fq2_t (>= 200).
+// A big call is cut into point-range chunks that are dealt round-robin to the devices (the reference's per-GPU slices,
+// snarkvm.cu:254-270) and, on each device, to two lanes in turn: while one lane's chunk is converted, sorted and accumulated,
+// the host is already copying the next chunk into the other lane's staging buffers - the upload (PCIe, ~2.4 ns per pair)
+// hides behind the compute (~2.4 ns per pair without precomputed tables) instead of preceding it.  Every chunk leaves only
+// its bit-plane sums; they are added on the host before the one Horner chain.
 template <class F>
-static void msm_host(context_t& c, void* out, const void* points, size_t npoints, const void* scalars, size_t stride) {
-    if (npoints == 0) {
-        write_infinity<F>(out);
-        return;
-    }
+static void msm_host_chunked(void* out, const void* points, size_t npoints, const void* scalars, size_t stride) {
     const size_t min_stride = 2 * sizeof(typename F::mem_t) + 8;
     if (stride < min_stride || (stride & 7)) throw hip_failure{hipErrorInvalidValue, "msm: bad ffi_affine_sz for this curve", __LINE__};
-    const size_t aff_bytes = (npoints * sizeof(aff_mem_t<F>) + 255) & ~(size_t)255;
-    c.bases_tmp.ensure(aff_bytes + npoints * stride);
-    c.scalars_tmp.ensure(npoints * 32);
-    uint8_t* raw = c.bases_tmp.as<uint8_t>() + aff_bytes;
-    c.phase_begin("msm_h2d");
-    HIP_TRY(hipMemcpyAsync(raw, points, npoints * stride, hipMemcpyHostToDevice, c.stream));
-    HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, scalars, npoints * 32, hipMemcpyHostToDevice, c.stream));
-    c.phase_end();
-    c.phase_begin("msm_convert_bases");
-    convert_bases<F>(c, raw, stride, npoints, c.bases_tmp.as<aff_mem_t<F>>());
-    c.phase_end();
-    msm_run<F>(c, c.bases_tmp.as<aff_mem_t<F>>(), c.scalars_tmp.as<uint4>(), npoints, out, 0);
+    const int nd = g_rt.ndev();
+    size_t nchunks = npoints < 2 * MSM_SPLIT_MIN ? 1 : (npoints + MSM_CHUNK - 1) / MSM_CHUNK;
+    if (nchunks == 1 && nd > 1 && npoints >= 2 * MSM_SPLIT_MIN) nchunks = 2;
+    const int ndu = (int)(nchunks < (size_t)nd ? nchunks : (size_t)nd);
+    std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
+    std::mutex acc_mu;
+    std::vector<int> devs;
+    if (ndu == 1)
+        devs.push_back(-1);
+    else
+        for (int d = 0; d < ndu; d++) devs.push_back(d);
+    const size_t slot = msm_plane_bytes<F>();
+    for_each_device(devs, [&](int dev) {
+        std::vector<size_t> mine;
+        for (size_t i = (dev < 0 ? 0 : (size_t)dev); i < nchunks; i += (size_t)ndu) mine.push_back(i);
+        lane_guard lg;
+        lg.acquire(dev, mine.size() > 1 ? 2 : 1);
+        const int L = (int)lg.lanes.size();
+        std::vector<msm_pending_t> pend(mine.size());
+        for (int l = 0; l < L; l++) {
+            lg.lanes[l]->begin_call();
+            lg.lanes[l]->pin.ensure(slot * ((mine.size() + L - 1) / L));
+        }
+        for (size_t j = 0; j < mine.size(); j++) {
+            const size_t lo = npoints * mine[j] / nchunks, hi = npoints * (mine[j] + 1) / nchunks, cnt = hi - lo;
+            lane_t& c = *lg.lanes[j % L];
+            const bool prof = nchunks == 1;
+            const size_t aff_bytes = (cnt * sizeof(aff_mem_t<F>) + 255) & ~(size_t)255;
+            c.bases_tmp.ensure(aff_bytes + cnt * stride);
+            c.scalars_tmp.ensure(cnt * 32);
+            uint8_t* raw = c.bases_tmp.template as<uint8_t>() + aff_bytes;
+            if (prof) c.phase_begin("msm_h2d");
+            HIP_TRY(hipMemcpyAsync(raw, (const uint8_t*)points + lo * stride, cnt * stride, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, c.stream));
+            if (prof) c.phase_end();
+            if (prof) c.phase_begin("msm_convert_bases");
+            convert_bases<F>(c, raw, stride, cnt, c.bases_tmp.template as<aff_mem_t<F>>());
+            if (prof) c.phase_end();
+            pend[j] = msm_run<F>(c, c.bases_tmp.template as<aff_mem_t<F>>(), c.scalars_tmp.template as<uint4>(), cnt, c.pin.template as<uint8_t>() + slot * (j / L), 0,
+                                 nullptr, ~(size_t)0, 0, 1, 0, prof, 0);
+        }
+        for (int l = 0; l < L; l++) HIP_TRY(hipStreamSynchronize(lg.lanes[l]->stream));
+        {
+            std::lock_guard<std::mutex> lk(acc_mu);
+            for (auto& pd : pend) msm_collect<F>(*acc, pd);
+        }
+        for (int l = 0; l < L; l++) lg.lanes[l]->end_call();
+    });
+    acc->finish(out);
+}
+
+// A batch of independent MSMs over one registered base vector, fanned out over devices x lanes (see
+// snarkvm_hip_msm_registered_batch).  outs: count Jacobian memory images.
+template <class F>
+static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, const size_t* offsets, const size_t* npoints, const void* const* scalars,
+                          int scalars_on_device, int scalars_montgomery, int window_bits, const size_t* off1 = nullptr, const size_t* n1 = nullptr) {
+    // instance k: bases [offsets[k], + npoints[k]) followed by [off1[k], + n1[k]) (KZG10's hiding range; optional), n0 + n1 scalars
+    auto total = [&](size_t k) { return npoints[k] + (n1 ? n1[k] : 0); };
+    const int nd = g_rt.ndev();
+    std::vector<std::vector<size_t>> per_dev(nd);
+    size_t largest = 0;
+    for (size_t k = 0; k < count; k++) {
+        if (offsets[k] + npoints[k] > h.n || (n1 && off1[k] + n1[k] > h.n))
+            throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
+        if (total(k) && !scalars[k]) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null scalar vector", __LINE__};
+        largest = total(k) > largest ? total(k) : largest;
+        int dev = (int)(k % (size_t)nd);
+        if (scalars_on_device && total(k)) {
+            dev = g_rt.device_of(scalars[k]);
+            if (dev < 0) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: scalars are not on a device in use", __LINE__};
+        }
+        per_dev[dev].push_back(k);
+    }
+    const int nlanes = batch_lanes(largest);
+    std::vector<int> devs;
+    for (int d = 0; d < nd; d++)
+        if (!per_dev[d].empty()) devs.push_back(d);
+    const size_t slot = msm_plane_bytes<F>();
+    const size_t out_bytes = sizeof(jac_mem_t<F>);
+    for_each_device(devs, [&](int dev) {
+        const std::vector<size_t>& mine = per_dev[dev];
+        lane_guard lg;
+        lg.acquire(dev, nlanes < (int)mine.size() ? nlanes : (int)mine.size());
+        const int L = (int)lg.lanes.size();
+        std::vector<msm_pending_t> pend(mine.size());
+        std::vector<hipEvent_t> done(mine.size());
+        for (int l = 0; l < L; l++) {
+            lg.lanes[l]->begin_call();
+            lg.lanes[l]->pin.ensure(slot * ((mine.size() + L - 1) / L));
+        }
+        for (size_t i = 0; i < mine.size(); i++) {
+            const size_t k = mine[i];
+            lane_t& c = *lg.lanes[i % L];
+            const uint4* d_sc = (const uint4*)scalars[k];
+            if (!scalars_on_device && total(k)) {
+                // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
+                c.scalars.ensure(total(k) * 32);
+                HIP_TRY(hipMemcpyAsync(c.scalars.p, scalars[k], total(k) * 32, hipMemcpyHostToDevice, c.stream));
+                d_sc = c.scalars.template as<uint4>();
+            }
+            pend[i] = msm_run<F>(c, h.d[dev] + offsets[k], d_sc, total(k), c.pin.template as<uint8_t>() + slot * (i / L), window_bits,
+                                 n1 ? h.d[dev] + off1[k] : nullptr, n1 ? npoints[k] : ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits);
+            done[i] = c.new_event();
+            HIP_TRY(hipEventRecord(done[i], c.stream));
+        }
+        // the host finishes instance i while the GPU works on the later ones
+        std::unique_ptr<msm_accum_t<F>> acc;
+        for (size_t i = 0; i < mine.size(); i++) {
+            HIP_TRY(hipEventSynchronize(done[i]));
+            acc.reset(new msm_accum_t<F>());
+            msm_collect<F>(*acc, pend[i]);
+            acc->finish((uint8_t*)outs + out_bytes * mine[i]);
+        }
+        for (int l = 0; l < L; l++) lg.lanes[l]->end_call();
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
-// exported functions
+// exported-function scaffolding
 // ------------------------------------------------------------------------------------------------
-// Kernels with more than 64 KB of dynamic LDS need the attribute on THEIR function object; the non-template kernels are
-// static, i.e. every translation unit launches its own copy, so every unit sets the attribute once for its copies.
-static void tu_kernel_attributes() {
-    static bool done = false;
-    if (done) return;
-#ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
-    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-#endif
-    done = true;
-}
-#define API_BEGIN                                  \
-    std::lock_guard<std::mutex> _lk(g_ctx.mu);     \
+// API_BEGIN: take one lane on any device;  API_BEGIN_DEV(d): on logical device d (d < 0: any).  `c` is the lane.
+#define API_BEGIN_DEV(devsel)                      \
     try {                                          \
-        g_ctx.init();                              \
-        tu_kernel_attributes();                    \
-        g_ctx.begin_call();
+        lane_guard _lg(devsel);                    \
+        lane_t& c = _lg.c();                       \
+        c.begin_call();
+#define API_BEGIN API_BEGIN_DEV(-1)
 #define API_END                                    \
-    g_ctx.end_call();                              \
+    c.end_call();                                  \
     return ok();                                   \
     }                                              \
     catch (const hip_failure& f) {                 \
@@ -517,6 +932,27 @@ static void tu_kernel_attributes() {
     catch (...) {                                  \
         return fail(1, "snarkvm_hip: unknown error"); \
     }
+// the same handlers for functions that manage their lanes themselves
+#define API_TRY try {
+#define API_CATCH                                  \
+    return ok();                                   \
+    }                                              \
+    catch (const hip_failure& f) {                 \
+        return from_failure(f);                    \
+    }                                              \
+    catch (const std::exception& e) {              \
+        return fail(1, std::string("snarkvm_hip: ") + e.what()); \
+    }                                              \
+    catch (...) {                                  \
+        return fail(1, "snarkvm_hip: unknown error"); \
+    }
+// logical device for a call whose operands live in device memory (on_device != 0): the owner of `ptr`
+static int device_for(const void* ptr, int on_device) {
+    if (!on_device || !ptr) return -1;
+    const int d = g_rt.device_of(ptr);
+    if (d < 0) throw hip_failure{hipErrorInvalidValue, "device pointer does not belong to a device in use (snarkvm_hip_set_devices)", __LINE__};
+    return d;
+}
 
 // ---- test-hook helpers (C++ linkage)
 template <class F>

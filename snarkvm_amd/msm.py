@@ -141,14 +141,38 @@ class RegisteredBasesG2:
         _lib.check(_lib.lib().snarkvm_hip_register_bases_g2(ctypes.byref(self._h), ctypes.c_void_p(bases.ctypes.data), ctypes.c_size_t(self.n),
                                                            ctypes.c_size_t(G2_AFFINE.itemsize), ctypes.c_int(int(tables)), ctypes.c_int(int(window_bits))))
 
-    def msm(self, scalars, offset=0, window_bits=0):
+    def msm(self, scalars=None, offset=0, window_bits=0, device_ptr=None, npoints=None):
+        """sum_i scalars[i] * bases[offset + i]; scalars either a host (n,4) u64 array or a device pointer + npoints."""
         from .layout import G2_PROJECTIVE
 
-        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.zeros(1, dtype=G2_PROJECTIVE)
+        if device_ptr is not None:
+            _lib.check(_lib.lib().snarkvm_hip_msm_g2_registered(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(offset),
+                                                               ctypes.c_size_t(int(npoints)), ctypes.c_void_p(device_ptr), ctypes.c_int(1),
+                                                               ctypes.c_int(window_bits)))
+            return out
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         _lib.check(_lib.lib().snarkvm_hip_msm_g2_registered(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(offset),
                                                            ctypes.c_size_t(scalars.shape[0]), ctypes.c_void_p(scalars.ctypes.data), ctypes.c_int(0),
                                                            ctypes.c_int(window_bits)))
+        return out
+
+    def msm_batch(self, scalars_list=None, offsets=None, device_ptrs=None, npoints=None, window_bits=0):
+        """Independent G2 MSMs over this base vector fanned out over devices and lanes (snarkvm_hip_msm_g2_registered_batch)."""
+        from .layout import G2_PROJECTIVE
+
+        if device_ptrs is not None:
+            count, ns, ptrs, on_dev, keep = len(device_ptrs), [int(v) for v in npoints], [int(p) for p in device_ptrs], 1, None
+        else:
+            keep = [np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4) for s in scalars_list]
+            count, ns, ptrs, on_dev = len(keep), [k.shape[0] for k in keep], [k.ctypes.data for k in keep], 0
+        offs = [0] * count if offsets is None else [int(o) for o in offsets]
+        out = np.zeros(count, dtype=G2_PROJECTIVE)
+        c_offs = (ctypes.c_size_t * max(1, count))(*offs)
+        c_ns = (ctypes.c_size_t * max(1, count))(*ns)
+        c_ptrs = (ctypes.c_void_p * max(1, count))(*ptrs)
+        _lib.check(_lib.lib().snarkvm_hip_msm_g2_registered_batch(ctypes.c_void_p(out.ctypes.data), self._h, ctypes.c_size_t(count), c_offs, c_ns, c_ptrs,
+                                                                 ctypes.c_int(on_dev), ctypes.c_int(window_bits)))
         return out
 
     def close(self):
@@ -161,6 +185,17 @@ class RegisteredBasesG2:
             self.close()
         except Exception:
             pass
+
+
+def set_devices(ids):
+    """Devices this process uses (snarkvm_hip_set_devices): before the first compute call.  A repeated id makes an independent
+    logical device on the same GPU."""
+    arr = (ctypes.c_int32 * len(ids))(*[int(i) for i in ids])
+    _lib.check(_lib.lib().snarkvm_hip_set_devices(arr, ctypes.c_size_t(len(ids))))
+
+
+def num_devices():
+    return _lib.lib().snarkvm_hip_num_devices()
 
 
 def g1_sum(points):

@@ -1,0 +1,227 @@
+"""The hot-path call pattern of one Varuna proof (BASELINE.json configs[3] / [4]) replayed on the gfx950 backend.
+
+No circuit and no protocol logic: only the MSM / NTT / polynomial calls the prover issues, in the order and sizes of SURVEY.md
+3.1 for `credits.aleo/transfer_private` (|R| = |C| = 2^16, |K| = 2^17), on device-resident random data:
+
+  round 1   iNTT + NTT at |C|, commit w (hiding)                                          first.rs:127-160
+  round 2   3 iNTT at |R|, z_a * z_b on 2|R| (2 NTT + product + iNTT), - z_c, / (X^|R| - 1), commit h_0   second.rs:104-170
+  round 3   3 x (iNTT at |C| + product on 2|C|), commit g_1 (hiding), commit h_1           third.rs:158-317
+  round 4   3 x (3 iNTT at |K|, one of them coset; one product on 2|K|), commit g_a, g_b, g_c   fourth.rs:174-231
+  round 5   4 commits of the combined polynomials (one pipelined batch), 3 openings (p / (X - z), p(z), MSM)
+            fifth.rs:50-66, sonic_pc/mod.rs:316-337
+  + one G2 MSM of 2^16 pairs per proof (north_star's G2 leg; the reference prover itself issues none)
+
+`ProofBatch` replays many such proofs concurrently: worker threads (the reference's rayon workers, one commitment / proof
+each) call the C ABI at the same time and the backend hands every call its own (device, stream) lane; with several devices
+in use the proofs' working sets are spread over them and every call runs where its data lives.
+"""
+import ctypes
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _lib, synthetic
+from .layout import G1_AFFINE, G1_PROJECTIVE, G2_AFFINE, G2_PROJECTIVE
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class ProofShape:
+    """Sizes of one proof's domains; defaults = transfer_private (test_credits.rs:2868-2897)."""
+
+    def __init__(self, lg_r=16, lg_k=17, lg_g2=16):
+        self.lg_r, self.lg_k, self.lg_g2 = lg_r, lg_k, lg_g2
+        self.nmax = 1 << (lg_k + 1)
+
+    def pairs(self):
+        """scalar-point pairs of the G1 commitments / openings of one proof"""
+        nR, nK = 1 << self.lg_r, 1 << self.lg_k
+        return (nR) + nR + (nR + 1) + nR + 3 * (nK - 1) + (nK - 2 + nK + nR + nK) + (nK - 1 + nR - 1 + nK - 1)
+
+
+class ProverKeys:
+    """The static device-resident operands shared by every proof: registered G1 powers (+ the gamma powers behind them) with
+    16 precomputed tables, a registered G2 vector, and a pool of random Fr data the proofs slice their "polynomials" from.
+    Registration replicates the bases to every device the backend uses."""
+
+    def __init__(self, shape, seed=99):
+        import torch
+
+        self.shape = shape
+        L = _lib.lib()
+        n = shape.nmax + 8
+        buf = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        _lib.check(L.snarkvm_hip_g1_generate_bases_device(_p(buf), ctypes.c_uint64(1), ctypes.c_size_t(n)))
+        self.h = ctypes.c_void_p()
+        _lib.check(L.snarkvm_hip_register_bases_tables(ctypes.byref(self.h), _p(buf), ctypes.c_size_t(n), ctypes.c_size_t(G1_AFFINE.itemsize), 1, 16))
+        self.g1_host = buf.cpu().numpy().view(G1_AFFINE)
+        del buf
+        # G2: the generator's multiples would need Fq2 point generation on the host; a G2 vector of repeated (decoded) real
+        # points with random scalars exercises the same kernels
+        self.hg2 = ctypes.c_void_p()
+        self.g2_host = None
+        if shape.lg_g2:
+            self.g2_host = synthetic.g2_points(1 << shape.lg_g2)
+            _lib.check(L.snarkvm_hip_register_bases_g2(ctypes.byref(self.hg2), ctypes.c_void_p(self.g2_host.ctypes.data), ctypes.c_size_t(self.g2_host.shape[0]),
+                                                       ctypes.c_size_t(G2_AFFINE.itemsize), 16, 0))
+        self.pool_host = synthetic.random_fr_integers(shape.nmax + 4096, seed)  # any residue < r is a valid Montgomery image
+        self.point = self.pool_host[7:8].copy()
+
+    def close(self):
+        L = _lib.lib()
+        if self.h:
+            L.snarkvm_hip_free_bases(self.h)
+            self.h = ctypes.c_void_p()
+        if self.hg2:
+            L.snarkvm_hip_free_bases_g2(self.hg2)
+            self.hg2 = ctypes.c_void_p()
+
+
+class ProofWorkspace:
+    """Device buffers of one in-flight proof on one device (four work vectors of the largest domain + the data pool)."""
+
+    def __init__(self, keys, device_index=0):
+        import torch
+
+        self.keys = keys
+        self.device = torch.device("cuda", device_index)
+        with torch.cuda.device(self.device):
+            self.pool = torch.from_numpy(keys.pool_host.view(np.int64)).to(self.device)
+            self.work = [torch.empty(keys.shape.nmax * 4, dtype=torch.int64, device=self.device) for _ in range(4)]
+            torch.cuda.synchronize()
+        self.out = np.zeros(1, dtype=G1_PROJECTIVE)
+        self.outs = np.zeros(4, dtype=G1_PROJECTIVE)
+        self.out_g2 = np.zeros(1, dtype=G2_PROJECTIVE)
+        self.rem = np.zeros((1, 4), dtype=np.uint64)
+        self.times = {"msm": 0.0, "ntt": 0.0, "poly": 0.0, "g2": 0.0}
+
+
+def replay(ws, salt=0, collect=None):
+    """Issue the hot-path calls of one proof on workspace `ws`.  `salt` shifts the slices of the random pool the proof reads, so
+    different proofs commit to different polynomials.  collect: a list that receives a copy of every commitment (144 B each;
+    the G2 result last) for checking."""
+    import torch
+
+    L = _lib.lib()
+    keys = ws.keys
+    sh = keys.shape
+    nR, nK = 1 << sh.lg_r, 1 << sh.lg_k
+    a, b, c, d = ws.work
+    pool = ws.pool
+    t = ws.times
+
+    def timed(kind, fn):
+        t0 = time.perf_counter()
+        fn()
+        t[kind] += time.perf_counter() - t0
+
+    def ntt(v, lg, direction, kind=0):
+        timed("ntt", lambda: _lib.check(L.snarkvm_hip_ntt_device(_p(v), ctypes.c_uint32(lg), 0, direction, kind)))
+
+    def load(v, n, shift):  # a fresh "polynomial" of n coefficients (device copy on torch's stream: not part of the hot path)
+        s = 4 * (shift + salt)
+        with torch.cuda.device(ws.device):
+            v[: 4 * n].copy_(pool[s : s + 4 * n])
+            if v.shape[0] > 4 * n:
+                v[4 * n :].zero_()
+            torch.cuda.current_stream().synchronize()
+
+    def product(x, y, lg):  # PolyMultiplier::multiply of two coefficient vectors on the 2^lg domain, result in x
+        ntt(x, lg, 0)
+        ntt(y, lg, 0)
+        timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_mul_device(_p(x), _p(x), _p(y), ctypes.c_size_t(1 << lg))))
+        ntt(x, lg, 1)
+
+    def commit_round(polys):
+        """SonicKZG10::commit of one round (sonic_pc/mod.rs:177-257): every (vector, length, hiding degree) of the round in ONE
+        batched call - plaintext MSM over powers[0 .. n) + hiding MSM over the gamma powers each, Fr::to_bigint fused."""
+        k = len(polys)
+        ptrs = (ctypes.c_void_p * k)(*[v.data_ptr() if hasattr(v, "data_ptr") else int(v) for v, _, _ in polys])
+        off0 = (ctypes.c_size_t * k)(*([0] * k))
+        n0 = (ctypes.c_size_t * k)(*[n for _, n, _ in polys])
+        off1 = (ctypes.c_size_t * k)(*([sh.nmax] * k))
+        n1 = (ctypes.c_size_t * k)(*[h for _, _, h in polys])
+        outs = np.zeros(k, dtype=G1_PROJECTIVE)
+        timed("msm", lambda: _lib.check(L.snarkvm_hip_msm_registered_batch_ex(ctypes.c_void_p(outs.ctypes.data), keys.h, k, off0, n0, off1, n1, ptrs, 1, 1, 0)))
+        if collect is not None:
+            collect.extend(outs[i : i + 1].tobytes() for i in range(k))
+
+    load(a, nR, 1); ntt(a, sh.lg_r, 1); load(b, nR, 2); ntt(b, sh.lg_r, 0); commit_round([(a, nR - 2, 2)])         # round 1
+    for i, v in enumerate((a, b, c)):                                                                             # round 2
+        load(v, nR, 10 + i); ntt(v, sh.lg_r, 1)
+    with torch.cuda.device(ws.device):
+        d.copy_(c)
+        torch.cuda.current_stream().synchronize()
+    product(a, b, sh.lg_r + 1)
+    timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_vec_op(1, _p(a), _p(a), _p(d), None, None, ctypes.c_size_t(2 * nR), 1)))
+    timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_vanishing(_p(b), _p(c), _p(a), ctypes.c_size_t(2 * nR), ctypes.c_size_t(nR), 1)))
+    commit_round([(b, nR, 0)])
+    for m in range(3):                                                                                            # round 3
+        load(a, nR, 20 + m); ntt(a, sh.lg_r, 1); load(b, nR, 30 + m); product(a, b, sh.lg_r + 1)
+    commit_round([(a, nR - 1, 2), (b, nR, 0)])                                                                    # g_1 (hiding), h_1
+    r4 = (a, b, c)                                                                                                # round 4: g_a, g_b, g_c
+    for m in range(3):
+        v = r4[m]
+        load(v, nK, 40 + m); ntt(v, sh.lg_k, 1); load(d, nK, 50 + m); ntt(d, sh.lg_k, 1); load(d, nK, 60 + m); ntt(d, sh.lg_k, 1, 1)
+        if m == 0:
+            load(d, nK, 70); product(v, d, sh.lg_k + 1)
+    commit_round([(a, nK - 1, 0), (b, nK - 1, 0), (c, nK - 1, 0)])
+    base = pool.data_ptr()                                                                                        # round 5
+    commit_round([(base + 32 * (3 + salt), nK - 2, 0), (base + 32 * (5 + salt), nK, 0), (base + 32 * (9 + salt), nR, 0), (base + 32 * (11 + salt), nK, 0)])
+    opens = []                                                                                                    # openings
+    for (s, n), q in zip(((13, nK), (17, nR), (19, nK)), (b, c, d)):
+        load(a, n, s)
+        timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_linear(_p(q), ctypes.c_void_p(ws.rem.ctypes.data), _p(a), ctypes.c_size_t(n),
+                                                                            ctypes.c_void_p(keys.point.ctypes.data), 1)))
+        opens.append((q, n - 1, 0))
+    commit_round(opens)                                                                                           # batch_open: the three witness commitments
+    if keys.hg2:                                                                                                 # G2 leg
+        n2 = 1 << sh.lg_g2
+        timed("g2", lambda: _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, n2,
+                                                                        ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0)))
+        if collect is not None:
+            collect.append(ws.out_g2.tobytes())
+
+
+class ProofBatch:
+    """`count` proofs replayed by `workers` concurrent caller threads (BASELINE.json configs[4]: 64 proofs; one process per GPU
+    takes its share, or one process drives every device the backend uses)."""
+
+    def __init__(self, keys, workers=4, devices=None):
+        import torch
+
+        self.keys = keys
+        ndev = torch.cuda.device_count()
+        devices = list(range(ndev)) if devices is None else list(devices)
+        self.workspaces = [ProofWorkspace(keys, devices[w % len(devices)]) for w in range(workers)]
+        self._free = list(self.workspaces)
+        self._lock = threading.Lock()
+
+    def run(self, salts, collect=False):
+        """Replay one proof per entry of `salts`; returns (wall seconds, [commitment lists] or None)."""
+        results = [None] * len(salts)
+
+        def one(i):
+            with self._lock:
+                ws = self._free.pop()
+            try:
+                got = [] if collect else None
+                replay(ws, salts[i], got)
+                results[i] = got
+            finally:
+                with self._lock:
+                    self._free.append(ws)
+
+        t0 = time.perf_counter()
+        if len(self.workspaces) == 1:
+            for i in range(len(salts)):
+                one(i)
+        else:
+            with ThreadPoolExecutor(len(self.workspaces)) as ex:
+                list(ex.map(one, range(len(salts))))
+        return time.perf_counter() - t0, (results if collect else None)

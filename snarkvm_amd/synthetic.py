@@ -61,3 +61,60 @@ def witness_like_scalars(n, seed):
     s[small, 1:] = 0
     s[small, 0] &= np.uint64(0xFFFF)
     return s
+
+
+# ------------------------------------------------------------------------------------------ G2 base sets
+Q_MOD = 258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177
+# G2 generator, canonical coordinates (x = x0 + x1 u, y = y0 + y1 u over Fq[u]/(u^2 + 5); curves/src/bls12_377/g2.rs:237-315)
+G2_GEN = ((170590608266080109581922461902299092015242589883741236963254737235977648828052995125541529645051927918098146183295,
+           83407003718128594709087171351153471074446327721872642659202721143408712182996929763094113874399921859453255070254),
+          (1843833842842620867708835993770650838640642469700861403869757682057607397502738488921663703124647238454792872005,
+           33145532013610981697337930729788870077912093258611421158732879580766461459275194744385880708057348608045241477209))
+
+
+def _fq2_mul(a, b):
+    return ((a[0] * b[0] - 5 * a[1] * b[1]) % Q_MOD, (a[0] * b[1] + a[1] * b[0]) % Q_MOD)
+
+
+def _fq2_inv(a):
+    ninv = pow((a[0] * a[0] + 5 * a[1] * a[1]) % Q_MOD, Q_MOD - 2, Q_MOD)
+    return (a[0] * ninv % Q_MOD, (-a[1]) * ninv % Q_MOD)
+
+
+def _g2_add_affine(p, q):
+    """p + q for affine G2 points with p != -q (a = 0 curve; plain chord / tangent formulas over Python integers)."""
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        num = _fq2_mul((3, 0), _fq2_mul(x1, x1))
+        den = ((2 * y1[0]) % Q_MOD, (2 * y1[1]) % Q_MOD)
+    else:
+        num = ((y2[0] - y1[0]) % Q_MOD, (y2[1] - y1[1]) % Q_MOD)
+        den = ((x2[0] - x1[0]) % Q_MOD, (x2[1] - x1[1]) % Q_MOD)
+    lam = _fq2_mul(num, _fq2_inv(den))
+    l2 = _fq2_mul(lam, lam)
+    x3 = ((l2[0] - x1[0] - x2[0]) % Q_MOD, (l2[1] - x1[1] - x2[1]) % Q_MOD)
+    t = _fq2_mul(lam, ((x1[0] - x3[0]) % Q_MOD, (x1[1] - x3[1]) % Q_MOD))
+    return (x3, ((t[0] - y1[0]) % Q_MOD, (t[1] - y1[1]) % Q_MOD))
+
+
+def g2_points(n, distinct=512):
+    """n G2 bases as a Rust `[G2Affine]` array (200 B stride, Montgomery coordinates): `distinct` consecutive multiples of the
+    generator tiled to n - the shape of the reference's MSM benches, which tile a small set of points
+    (algorithms/benches/msm/variable_base.rs:29-32)."""
+    from .layout import G2_AFFINE
+
+    distinct = max(1, min(distinct, n))
+    R384 = 1 << 384
+    pts = [G2_GEN]
+    for _ in range(distinct - 1):
+        pts.append(_g2_add_affine(pts[-1], G2_GEN))
+    out = np.zeros(distinct, dtype=G2_AFFINE)
+    for i, (x, y) in enumerate(pts):
+        limbs = []
+        for v in (x[0], x[1], y[0], y[1]):
+            m = v * R384 % Q_MOD
+            limbs.append([(m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(6)])
+        out[i]["x"] = limbs[0] + limbs[1]
+        out[i]["y"] = limbs[2] + limbs[3]
+    reps = (n + distinct - 1) // distinct
+    return np.tile(out, reps)[:n].copy()

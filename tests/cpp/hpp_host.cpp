@@ -9,6 +9,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "snarkvm_hip.hpp"
@@ -92,6 +93,50 @@ int main(int argc, char** argv) {
         std::cout << "OK" << std::endl;
         return 0;
     }
-    std::cerr << "usage: hpp_host validate | run <dir>" << std::endl;
+    if (argc >= 3 && std::string(argv[1]) == "multi") {
+        // Two logical devices (the same GPU listed twice when only one is visible) driven by four concurrent caller threads -
+        // the reference's deployment: rayon workers calling the three FFI symbols at once (sonic_pc/mod.rs:203-245), every
+        // GPU in use (snarkvm.cu:254-295).  Thread t works on the scalar vector rotated by t and the Fr vector scaled by a
+        // rotation, so every result is different; the Python side checks each one against the oracle.
+        const std::string dir = argv[2];
+        const int ndev_visible = snarkvm_hip_device_count();
+        const int32_t ids[2] = {0, ndev_visible > 1 ? 1 : 0};
+        try {
+            snarkvm_hip::check(snarkvm_hip_set_devices(ids, 2));
+            if (snarkvm_hip_num_devices() != 2) throw snarkvm_hip::Error(1, "expected two logical devices");
+            auto bases = read_all<G1Affine>(dir + "/bases.bin");
+            auto scalars = read_all<Fr>(dir + "/scalars.bin");
+            auto fr = read_all<Fr>(dir + "/fr.bin");
+            const int T = 4;
+            std::vector<std::thread> th;
+            std::vector<std::string> errs(T);
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&, t] {
+                    try {
+                        std::vector<Fr> sc(scalars.size());
+                        for (size_t i = 0; i < sc.size(); i++) sc[i] = scalars[(i + (size_t)t * 7) % sc.size()];
+                        for (int rep = 0; rep < 3; rep++) {  // the repeated base range is registered on both devices (base cache)
+                            G1Projective r = snarkvm_hip::msm<G1Affine, G1Projective, Fr>(bases.data(), bases.size(), sc.data(), sc.size());
+                            write_all(dir + "/msm_" + std::to_string(t) + "_" + std::to_string(rep) + ".bin", &r, 1);
+                        }
+                        std::vector<Fr> x(fr.size());
+                        for (size_t i = 0; i < x.size(); i++) x[i] = fr[(i + (size_t)t * 3) % x.size()];
+                        snarkvm_hip::NTT(x.size(), x.data(), NN, Forward, Standard);
+                        write_all(dir + "/ntt_" + std::to_string(t) + ".bin", x.data(), x.size());
+                    } catch (const std::exception& e) {
+                        errs[t] = e.what();
+                    }
+                });
+            for (auto& x : th) x.join();
+            for (auto& e : errs)
+                if (!e.empty()) throw snarkvm_hip::Error(1, e);
+        } catch (const snarkvm_hip::Error& e) {
+            std::cerr << "snarkvm_hip::Error " << e.code << ": " << e.what() << std::endl;
+            return 2;
+        }
+        std::cout << "OK" << std::endl;
+        return 0;
+    }
+    std::cerr << "usage: hpp_host validate | run <dir> | multi <dir>" << std::endl;
     return 64;
 }

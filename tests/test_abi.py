@@ -76,4 +76,4 @@ def test_product_never_imports_the_oracle():
                     assert not pat_c.search(open(path).read()), path
     bench = open(os.path.join(util.ROOT, "bench.py")).read()
     first = bench.index("from oracle import")
-    assert bench.count("from oracle import") == 1 and first > bench.index("CPU baseline (rank 0, N = 1 only)")
+    assert bench.count("from oracle import") == 1 and first > bench.index("CPU baseline + oracle checks (rank 0, N = 1 only)")

@@ -1,0 +1,128 @@
+"""Multi-device paths of the C ABI on a one-GPU box: the same GPU listed twice (SNARKVM_HIP_DEVICES=0,0) gives two independent
+logical devices - own streams, workspaces and base replicas - so the point-range split of one MSM, the replication of
+registered bases, the batch fan-out and the lane tokens of concurrent callers all run their real code.  Each scenario is a
+subprocess because the device set is fixed at the first compute call of a process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import ctypes, sys
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from oracle import cpu as oracle
+from oracle import pyref
+from snarkvm_amd import _lib, msm, plugin, synthetic
+from snarkvm_amd.layout import NTTDirection, NTTInputOutputOrder, NTTType
+from tests import util
+
+assert msm.num_devices() == 2, msm.num_devices()
+G = util.g1_generator_affine()
+n = (1 << 19) + 321
+bases = oracle.g1_gen_bases(G, 1, n)
+sc = synthetic.random_fr_integers(n, 777)
+def closed(s, start=1):
+    return oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(s, start=start), 4)))
+def eq(got, want):
+    return util.affine_equal(oracle.g1_to_affine(got), want)
+want = closed(sc)
+# 1. plain FFI: cut into two point-range chunks, one per logical device, combined on the host
+assert eq(plugin.msm(bases, sc), want), "ffi split"
+# 2. second and third sighting of the same host range: registered on both devices (base cache), split by point range
+assert eq(plugin.msm(bases, sc), want), "ffi cached 1"
+assert eq(plugin.msm(bases, sc), want), "ffi cached 2"
+assert eq(plugin.msm(bases[5:300005], sc[:300000]), closed(sc[:300000], start=6)), "ffi cached slice"
+# 3. registered bases are replicated; host scalars split over both replicas, device scalars run where they live
+rb = msm.RegisteredBases(bases, tables=16)
+assert eq(rb.msm(sc), want), "registered host scalars"
+d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+torch.cuda.synchronize()
+for _ in range(3):  # the owner lookup rotates over the logical devices that share the physical GPU
+    assert eq(rb.msm(device_ptr=d_sc.data_ptr(), npoints=n), want), "registered device scalars"
+# 4. batch fan-out: instance k on logical device k mod 2, several lanes each; ragged sizes and offsets
+sizes = [1000, 70000, 1, 33333, 0, 262144, 4097]
+offs = [0, 11, 500000, 7, 3, 1000, 99]
+res = rb.msm_batch([sc[:m] for m in sizes], offsets=offs)
+for k, (m, o) in enumerate(zip(sizes, offs)):
+    if m == 0:
+        assert oracle.g1_to_affine(res[k:k+1])["infinity"][0] == 1
+    else:
+        assert eq(res[k:k+1], closed(sc[:m], start=o + 1)), ("batch", k)
+res = rb.msm_batch(device_ptrs=[d_sc.data_ptr()] * 5, npoints=[n, 5000, n, 123, 65536])
+for k, m in enumerate([n, 5000, n, 123, 65536]):
+    assert eq(res[k:k+1], closed(sc[:m])), ("device batch", k)
+# KZG10-shaped call with two base ranges, host scalars (split path with a range boundary inside a part)
+out = np.zeros(1, dtype=oracle.G1_PROJECTIVE)
+n0, n1, off1 = 400000, 124000, 100
+_lib.check(_lib.lib().snarkvm_hip_msm_registered_ex(ctypes.c_void_p(out.ctypes.data), rb._h, ctypes.c_size_t(0), ctypes.c_size_t(n0), ctypes.c_size_t(off1),
+                                                   ctypes.c_size_t(n1), ctypes.c_void_p(sc.ctypes.data), 0, 0, 0))
+k = (util.weighted_sum_mod_r(sc[:n0], start=1) + util.weighted_sum_mod_r(sc[n0:n0 + n1], start=off1 + 1)) %% pyref.R_MOD
+assert eq(out, oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(k, 4)))), "two-range split"
+rb.close()
+# 5. concurrent callers (rayon workers): 8 threads, NTTs and small MSMs at once on whatever lane / device is free
+xs = [oracle.fr_op("from_bigint", synthetic.random_fr_integers(1 << 13, 900 + t)) for t in range(8)]
+def work(t):
+    y = xs[t].copy()
+    plugin.NTT(1 << 13, y, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Standard)
+    ok = np.array_equal(y, oracle.ntt(xs[t]))
+    m = 3000 + 100 * t
+    ok = ok and eq(plugin.msm(bases[t:t + m], sc[:m]), closed(sc[:m], start=t + 1))
+    return ok
+with ThreadPoolExecutor(8) as ex:
+    assert all(ex.map(work, range(8))), "concurrent callers"
+# 6. G2: registered on both devices, batch over devices
+from snarkvm_amd.layout import G2_AFFINE
+raw = open(%r, "rb").read()
+g2 = np.zeros(1, dtype=G2_AFFINE)
+_lib.check(_lib.lib().snarkvm_hip_g2_deserialize(ctypes.c_void_p(g2.ctypes.data), ctypes.c_char_p(raw), ctypes.c_size_t(1), 0))
+g2b = np.concatenate([g2] * 600)
+g2sc = synthetic.random_fr_integers(600, 31337)
+rg = msm.RegisteredBasesG2(g2b, tables=16)
+want2 = oracle.g2_to_affine(oracle.g2_msm(g2b, g2sc)).tobytes()
+res = rg.msm_batch([g2sc, g2sc[:100], g2sc])
+assert oracle.g2_to_affine(res[0:1]).tobytes() == want2 and oracle.g2_to_affine(res[2:3]).tobytes() == want2
+assert oracle.g2_to_affine(res[1:2]).tobytes() == oracle.g2_to_affine(oracle.g2_msm(g2b[:100], g2sc[:100])).tobytes()
+rg.close()
+print("MULTI_OK")
+'''
+
+
+def test_two_logical_devices_end_to_end():
+    env = dict(os.environ, SNARKVM_HIP_DEVICES="0,0")
+    script = SCRIPT % (util.ROOT, os.path.join(util.ROOT, "tests", "golden", "beta_h_g2.bin"))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=1200, cwd=util.ROOT)
+    assert "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_device_set_is_fixed_after_first_use():
+    script = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from snarkvm_amd import _lib, msm
+msm.set_devices([0])
+assert msm.num_devices() == 1
+msm.set_devices([0])            # the identical list is accepted
+try:
+    msm.set_devices([0, 0])     # a different one is refused once the runtime exists
+    raise SystemExit("accepted a second device set")
+except _lib.HipError:
+    pass
+try:
+    import ctypes
+    _lib.check(_lib.lib().snarkvm_hip_set_devices(None, ctypes.c_size_t(0)))
+    raise SystemExit("accepted an empty device list")
+except _lib.HipError:
+    pass
+print("SET_OK")
+''' % util.ROOT
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, cwd=util.ROOT)
+    assert "SET_OK" in r.stdout, r.stdout + r.stderr

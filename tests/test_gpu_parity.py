@@ -561,16 +561,23 @@ sc = synthetic.random_fr_integers(n, 2468)
 def check(b, s):
     got = oracle.g1_to_affine(plugin.msm(b, s))
     assert util.affine_equal(got, oracle.g1_to_affine(oracle.g1_msm(b, s))), "mismatch"
-check(bases[:9000], sc[:9000])          # miss: registers [0, 9000)
+check(bases[:9000], sc[:9000])          # first sighting: remembered, uncached path
+check(bases[:9000], sc[:9000])          # second sighting: registers [0, 9000), served from HBM
 check(bases[:9000], sc[:9000])          # hit
-check(bases[100:5100], sc[:5000])       # hit with an offset
-check(bases, sc)                        # bigger range supersedes the first one
-check(bases[4096:12000], sc[:7904])     # hit inside the big range, starting exactly on a sampled point
+check(bases[100:5100], sc[:5000])       # hit with an offset that is not a sampled position
+check(bases[1:1100], sc[:1099])         # short slice between sampled positions: still >= 16 samples inside
+check(bases, sc)                        # bigger range supersedes the first one (first sighting again)
+check(bases[4096:12000], sc[:7904])     # second sighting of the big range: registered; hit starting on a sampled point
+check(bases, sc)                        # hit on the whole range
 bases[8192] = bases[1]                  # the memory changes in place at a sampled position
-check(bases, sc)                        # detected -> re-registered
-bases[8191] = bases[2]                  # an unsampled position: documented limitation, so re-register through a fresh array
+check(bases, sc)                        # detected -> dropped, uncached path
+check(bases, sc)                        # registered again with the new content
+check(bases, sc)
+bases[8191] = bases[2]                  # an unsampled position: documented limitation, so continue through a fresh array
 fresh = bases.copy()
 check(fresh, sc)
+check(fresh, sc)
+check(fresh[37:12345], sc[:12308])
 print("CACHE_OK")
 ''' % util.ROOT
     env = dict(os.environ, SNARKVM_HIP_BASE_CACHE="4")
@@ -624,6 +631,8 @@ def test_extension_abi_rejects_bad_arguments(golden):
     P = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
     err(L.snarkvm_hip_register_bases_windowed(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 11, 22))   # 11 * 22 < 254
     err(L.snarkvm_hip_register_bases_windowed(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 12, 24))   # window > 23
+    err(L.snarkvm_hip_register_bases_windowed(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 16, 23))   # 368 digit bits > 288
+    err(L.snarkvm_hip_register_bases_windowed(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 14, 23))   # 322 digit bits > 288
     err(L.snarkvm_hip_register_bases_tables(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(104), 0, 3))         # not a power of two
     err(L.snarkvm_hip_register_bases_tables(ctypes.byref(h), P(bases), ctypes.c_size_t(64), ctypes.c_size_t(100), 0, 4))         # stride < 104
     rb = RegisteredBases(bases, tables=4)

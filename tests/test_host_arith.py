@@ -149,6 +149,37 @@ def test_msm_planner_invariants():
             assert small["c"] <= 16 and small["wide"] == 0
         forced = _plan(1000, window_bits=bits, tables=tables, table_bits=bits)
         assert forced["c"] == bits and forced["wide"] == 1
-    assert _plan(1 << 24, tables=12, table_bits=22)["S"] == 128 and _plan(1 << 14, tables=16)["S"] == 16
+    assert _plan(1 << 24, tables=12, table_bits=22)["S"] == 128 and _plan(1 << 16, tables=16)["S"] == 8 and _plan(1 << 14, tables=16)["S"] == 4
     d = _plan(1 << 20, window_bits=13, tables=16)  # request that does not divide the table width: largest divisor below
     assert d["c"] == 8 and d["W"] == 2
+
+
+def test_msm_host_finish_matches_oracle():
+    """The host-side end of every MSM (runtime.hip.h msm_accum_t: bit-plane sums at bit positions -> one Horner chain; also the
+    combine step of a multi-device / chunked MSM, the reference's host `dadd`, snarkvm.cu:290-295) compiled for the host:
+    sum_i 2^pos[i] * P_i == the oracle's MSM with scalars 2^pos[i] mod r, for repeated positions, infinity planes, position 0
+    and positions beyond the scalar field's bit length."""
+    from snarkvm_amd.layout import G1_PROJECTIVE
+
+    rng = np.random.default_rng(77)
+    n = 40
+    bases = oracle.g1_gen_bases(util.g1_generator_affine(), 3, n)
+    pos = rng.integers(0, 300, size=n).astype(np.int32)
+    pos[:6] = [0, 0, 299, 299, 17, 253]
+    planes = np.zeros(n, dtype=G1_PROJECTIVE)
+    planes["x"] = bases["x"]
+    planes["y"] = bases["y"]
+    planes["z"] = np.array(pyref.to_limbs(pyref.fq_to_mont(1), 6), dtype=np.uint64)
+    inf = [5, 11]
+    for i in inf:  # Projective::zero(): z == 0 (any x, y)
+        planes[i]["z"] = 0
+    out = np.zeros(1, dtype=G1_PROJECTIVE)
+    rc = _lib.lib().snarkvm_hip_selftest_g1_finish(_p(planes), _p(pos), ctypes.c_size_t(n), _p(out))
+    assert rc == 0
+    keep = [i for i in range(n) if i not in inf]
+    scalars = util.ints_to_fr([pow(2, int(pos[i]), pyref.R_MOD) for i in keep])
+    want = oracle.g1_msm(bases[keep], scalars)
+    assert util.affine_equal(oracle.g1_to_affine(out), oracle.g1_to_affine(want))
+    # nothing but infinity -> Projective::zero()
+    rc = _lib.lib().snarkvm_hip_selftest_g1_finish(_p(planes[inf]), _p(pos[inf].copy()), ctypes.c_size_t(2), _p(out))
+    assert rc == 0 and oracle.g1_to_affine(out)["infinity"][0] == 1

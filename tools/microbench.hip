@@ -310,7 +310,7 @@ int main() {
     {
         hipEvent_t c0, c1; CHECK(hipEventCreate(&c0)); CHECK(hipEventCreate(&c1));
         Probe cal[] = {{"v_fma_f32", k_fma_f32}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_fma_f64", k_fma_f64}, {"v_add_u32", k_add_u32}, {"v_and_b32", k_and_b32},
-                       {"v_add3_u32", k_add3_u32}, {"v_cndmask_b32", k_cndmask_b32}, {"v_ashrrev_i32", k_ashrrev_i32}, {"v_bfe_u32", k_bfe_u32},
+                       {"v_add3_u32", k_add3_u32}, {"v_ashrrev_i32", k_ashrrev_i32}, {"v_bfe_u32", k_bfe_u32},
                        {"v_alignbit_b32", k_alignbit_b32}, {"v_lshrrev_b64", k_lshrrev_b64}, {"v_lshl_add_u64", k_lshl_add_u64},
                        {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mad_u32_u24", k_mad_u32_u24},
                        {"v_mad_u64_u32", k_mad_u64_u32}, {"v_mad_u64_u32(dep chain)", k_mad_u64_u32_dep}, {"v_mad_i64_i32", k_mad_i64_i32}};
