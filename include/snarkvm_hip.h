@@ -129,10 +129,14 @@ RustError snarkvm_hip_register_bases_serialized(snarkvm_hip_bases_t **handle, co
 RustError snarkvm_hip_g1_deserialize(void *out_affine, const void *bytes, size_t n, int compressed, int validate);
 RustError snarkvm_hip_g1_serialize(void *out_bytes, const void *affine, size_t n, size_t ffi_affine_sz, int compressed);
 
-/* G2 points, uncompressed only (192 B: x.c0, x.c1, y.c0, y.c1 canonical little-endian, flags in the last byte; fp2.rs:425-455),
+/* G2 points, uncompressed (192 B: x.c0, x.c1, y.c0, y.c1 canonical little-endian, flags in the last byte; fp2.rs:425-455),
  * e.g. `beta-h.usrs`: bytes (host) <-> Rust `[G2Affine]` (200 B stride, host). */
 RustError snarkvm_hip_g2_deserialize(void *out_affine, const void *bytes, size_t n, int validate);
 RustError snarkvm_hip_g2_serialize(void *out_bytes, const void *affine, size_t n, size_t ffi_affine_sz);
+/* Compressed G2 points (96 B: x.c0, x.c1 with the flags; y = `Fp2::sqrt` of x^3 + b' selected by the sign flag in the order
+ * of fields/src/fp2.rs:240-250, all on the device; fields/src/fp2.rs:208-230, curves/src/templates/.../affine.rs:140-150). */
+RustError snarkvm_hip_g2_deserialize_compressed(void *out_affine, const void *bytes, size_t n, int validate);
+RustError snarkvm_hip_g2_serialize_compressed(void *out_bytes, const void *affine, size_t n, size_t ffi_affine_sz);
 
 /* MSM over registered bases [offset, offset + npoints).  `scalars` in host (scalars_on_device = 0) or
  * device memory.  `out` is a 144-byte host buffer (Jacobian, as snarkvm_msm).  `window_bits` = 0 picks

@@ -356,3 +356,62 @@ def g2_deserialize(b, validate=False):
     if validate and not (g2_is_on_curve(p) and g2_mul(p, R_MOD) is None):
         raise SerializationError("InvalidData")
     return p
+
+
+# ---- Fq2 square root and the compressed G2 encoding (test oracle for serde.hip.h's compressed G2 path)
+def fq2_sqrt(a):
+    """`Fp2::sqrt` (fields/src/fp2.rs:208-230): complex method (eprint 2012/685, algorithm 8); None where the reference
+    returns None - including a base-field element that is a non-residue in Fq (fp2.rs:210-212 only tries `c0.sqrt()`)."""
+    c0, c1 = a[0] % Q_MOD, a[1] % Q_MOD
+    if c1 == 0:
+        r = fq_sqrt(c0)
+        return None if r is None else (r, 0)
+    norm = (c0 * c0 + 5 * c1 * c1) % Q_MOD  # c0^2 - nonresidue c1^2, nonresidue = -5 (fq2.rs:58-69)
+    alpha = fq_sqrt(norm)
+    if alpha is None:  # legendre(norm) = QNR
+        return None
+    two_inv = pow(2, Q_MOD - 2, Q_MOD)
+    delta = (alpha + c0) * two_inv % Q_MOD
+    if pow(delta, (Q_MOD - 1) // 2, Q_MOD) == Q_MOD - 1:  # delta.legendre().is_qnr()
+        delta = (delta - alpha) % Q_MOD
+    r0 = fq_sqrt(delta)
+    if r0 is None or r0 == 0:
+        return None
+    return (r0, c1 * two_inv % Q_MOD * pow(r0, Q_MOD - 2, Q_MOD) % Q_MOD)
+
+
+def fq2_gt(a, b):
+    """`Ord for Fp2` (fp2.rs:240-250): lexicographic, c1 first."""
+    return (a[1], a[0]) > (b[1], b[0])
+
+
+def g2_serialize_compressed(p):
+    """x.c0 plain, x.c1 with the SWFlags (macros.rs:66-85; `from_y_sign(y > -y)` in the order of fp2.rs:240-250)."""
+    if p is None:
+        x, flags = (0, 0), 1 << 6
+    else:
+        ny = ((-p[1][0]) % Q_MOD, (-p[1][1]) % Q_MOD)
+        x, flags = p[0], (1 << 7) if fq2_gt(p[1], ny) else 0
+    b = bytearray(x[0].to_bytes(48, "little") + x[1].to_bytes(48, "little"))
+    b[95] |= flags
+    return bytes(b)
+
+
+def g2_deserialize_compressed(b, validate=False):
+    """macros.rs:115-127 + affine.rs:140-150 over Fq2."""
+    x0 = int.from_bytes(b[:48], "little")
+    if x0 >= Q_MOD:
+        raise SerializationError("coordinate >= q")
+    x1, pos, inf = _read_fq_with_flags(b[48:96])
+    if inf:
+        return None
+    x = (x0, x1)
+    y = fq2_sqrt(fq2_add(fq2_mul(fq2_mul(x, x), x), G2_B))
+    if y is None:
+        raise SerializationError("InvalidData")
+    ny = ((-y[0]) % Q_MOD, (-y[1]) % Q_MOD)
+    y = y if (fq2_gt(ny, y) != pos) else ny  # `if (y < negy) ^ greatest { y } else { negy }`
+    p = (x, y)
+    if validate and not (g2_is_on_curve(p) and g2_mul(p, R_MOD) is None):
+        raise SerializationError("InvalidData")
+    return p

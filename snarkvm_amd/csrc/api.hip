@@ -345,7 +345,12 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
                 base_cache_drop(i);
                 break;
             }
-            const size_t need = (size_t)base_cache_tables() * g_base_cache[i].n * sizeof(g1_aff_mem_t);
+            // table geometry by size, as measured (profiles/r01_size_sweep.md): 12 x 22-bit windows from 2^23 points, 13 x 20-bit from
+            // 2^21, else the configured count of 256 / tables-bit tables
+            int tables = base_cache_tables(), bits = 0;
+            if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 23)) tables = 12, bits = 22;
+            else if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 21)) tables = 13, bits = 20;
+            const size_t need = (size_t)tables * g_base_cache[i].n * sizeof(g1_aff_mem_t);
             if (need > base_cache_cap()) return nullptr;
             for (;;) {  // make room: least recently used registered entries go first
                 size_t used = 0, lru = (size_t)-1;
@@ -359,7 +364,7 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
             }
             snarkvm_hip_bases_t* nh = nullptr;
             // throws on failure: nothing leaks, the entry stays unregistered
-            register_bases_impl(&nh, g_base_cache[i].host, g_base_cache[i].n, g_base_cache[i].stride, 0, base_cache_tables(), 0);
+            register_bases_impl(&nh, g_base_cache[i].host, g_base_cache[i].n, g_base_cache[i].stride, 0, tables, bits);
             g_base_cache[i].h = std::shared_ptr<snarkvm_hip_bases>(nh, [](snarkvm_hip_bases* b) { snarkvm_hip_free_bases(b); });
         }
         offset = off;

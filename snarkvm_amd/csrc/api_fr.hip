@@ -8,7 +8,7 @@ extern "C" {
 
 // ---- NTT -------------------------------------------------------------------------------------
 static void check_ntt_args(uint32_t lg, int order, int dir, int type) {
-    if (lg > (uint32_t)NTT_LG_MAX) throw hip_failure{hipErrorMemoryAllocation, "ntt: lg_domain_size > 24 is not supported by this backend", __LINE__};
+    if (lg > (uint32_t)NTT_LG_MAX) throw hip_failure{hipErrorMemoryAllocation, "ntt: lg_domain_size > 26 is not supported by this backend", __LINE__};
     if (order < 0 || order > 3 || dir < 0 || dir > 1 || type < 0 || type > 1) throw hip_failure{hipErrorInvalidValue, "ntt: bad enum value", __LINE__};
 }
 RustError snarkvm_ntt(void* inout, uint32_t lg, enum NTTInputOutputOrder order, enum NTTDirection dir, enum NTTType type) {

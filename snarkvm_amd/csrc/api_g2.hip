@@ -108,19 +108,20 @@ RustError snarkvm_hip_msm_g2_registered_batch(void* outs, const snarkvm_hip_base
     API_CATCH
 }
 
-RustError snarkvm_hip_g2_deserialize(void* out_affine, const void* bytes, size_t n, int validate) {
+static RustError g2_deserialize_impl(void* out_affine, const void* bytes, size_t n, int compressed, int validate) {
     API_BEGIN
 #ifdef SV_NO_G2
     throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
 #else
     if (n) {
         if (!out_affine || !bytes) throw hip_failure{hipErrorInvalidValue, "g2_deserialize: null argument", __LINE__};
-        c.bases_tmp.ensure(n * 192);
+        const size_t psz = compressed ? 96 : 192;
+        c.bases_tmp.ensure(n * psz);
         c.poly[0].ensure(n * 200);
         c.serde_status.ensure(4);
-        HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, bytes, n * 192, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, bytes, n * psz, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipMemsetAsync(c.serde_status.p, 0, 4, c.stream));
-        hipLaunchKernelGGL(g2_deserialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, c.bases_tmp.as<uint8_t>(), n, validate,
+        hipLaunchKernelGGL(g2_deserialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, c.bases_tmp.as<uint8_t>(), n, compressed, validate,
                            c.poly[0].as<uint8_t>(), c.serde_status.as<uint32_t>());
         HIP_TRY(hipGetLastError());
         uint32_t st = 0;
@@ -132,7 +133,7 @@ RustError snarkvm_hip_g2_deserialize(void* out_affine, const void* bytes, size_t
 #endif
     API_END
 }
-RustError snarkvm_hip_g2_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz) {
+static RustError g2_serialize_impl(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz, int compressed) {
     API_BEGIN
 #ifdef SV_NO_G2
     throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
@@ -141,16 +142,26 @@ RustError snarkvm_hip_g2_serialize(void* out_bytes, const void* affine, size_t n
         if (!out_bytes || !affine) throw hip_failure{hipErrorInvalidValue, "g2_serialize: null argument", __LINE__};
         if (ffi_affine_sz < 200 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "g2_serialize: bad stride", __LINE__};
         c.bases_tmp.ensure(n * ffi_affine_sz);
-        c.poly[0].ensure(n * 192);
+        const size_t psz = compressed ? 96 : 192;
+        c.poly[0].ensure(n * psz);
         HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, affine, n * ffi_affine_sz, hipMemcpyHostToDevice, c.stream));
         hipLaunchKernelGGL(g2_serialize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, c.bases_tmp.as<uint8_t>(), ffi_affine_sz, n,
-                           c.poly[0].as<uint8_t>());
+                           compressed, c.poly[0].as<uint8_t>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out_bytes, c.poly[0].p, n * 192, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(out_bytes, c.poly[0].p, n * psz, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
     }
 #endif
     API_END
+}
+
+RustError snarkvm_hip_g2_deserialize(void* out_affine, const void* bytes, size_t n, int validate) { return g2_deserialize_impl(out_affine, bytes, n, 0, validate); }
+RustError snarkvm_hip_g2_deserialize_compressed(void* out_affine, const void* bytes, size_t n, int validate) {
+    return g2_deserialize_impl(out_affine, bytes, n, 1, validate);
+}
+RustError snarkvm_hip_g2_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz) { return g2_serialize_impl(out_bytes, affine, n, ffi_affine_sz, 0); }
+RustError snarkvm_hip_g2_serialize_compressed(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz) {
+    return g2_serialize_impl(out_bytes, affine, n, ffi_affine_sz, 1);
 }
 
 }  // extern "C"

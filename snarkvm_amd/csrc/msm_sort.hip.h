@@ -183,6 +183,246 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* 
     }
 }
 
+// ---- level 1 fused with the scalar read (wide windows: the 2^24 regime) ---------------------------------------------------
+// The stand-alone digit kernel reads 32 B per scalar and writes the J x n digit matrix (48 B per scalar at J = 12), which the
+// level-1 histogram and scatter then read once each: 176 B of HBM traffic per scalar before a single entry is in place, and
+// a "scalar-read phase" that spends most of its time writing.  Here the digits never exist in memory: the histogram kernel IS
+// the scalar-read phase (a read-only stream of the scalars, digits recoded in registers, counts in LDS, one contiguous row of
+// counters written per workgroup), and the scatter kernel reads the scalars a second time, keeps the recoded words of its
+// scalars in registers and places FUSED_G digit rows at a time through LDS (the (v, remainder) staging of a tile would not fit
+// for all rows at once).  64 B read + 72 B written per scalar instead of 248 B.
+//   tile t            = FUSED_TILE consecutive scalars x all digit rows; key = row * B1 + bin
+//   cnt[t][key]       tile-major, so a workgroup reads / writes one contiguous row of KEYS counters
+//   offsets           entries are grouped by q = (window, bin); inside a group by table j, then by tile.  The exclusive scan in
+//                     that order runs hierarchically: per-chunk column sums (FUSED_CHUNK tiles) laid out [(q, j)][chunk], one
+//                     flat exclusive scan over them, then a per-chunk pass that turns them into off[t][key].
+static constexpr int FUSED_TILE = 2048;    // scalars per workgroup
+static constexpr int FUSED_THREADS = 512;  // 4 scalars per thread
+static constexpr int FUSED_G = 4;          // digit rows staged per round of the scatter
+static constexpr int FUSED_SPT = FUSED_TILE / FUSED_THREADS;
+static constexpr int FUSED_CHUNK = 64;     // tiles per chunk of the offset scan
+
+// 32-byte scalar (two 16-byte halves) -> recoded words s' = scalar (+ Fr::to_bigint) + bias; digit row r = (s' >> c r) & (2^c - 1)
+__device__ __forceinline__ void recode_scalar(const uint4& lo, const uint4& hi, const msm_digit_params_t& dp, uint32_t* s /* 11 words */) {
+    s[0] = lo.x, s[1] = lo.y, s[2] = lo.z, s[3] = lo.w, s[4] = hi.x, s[5] = hi.y, s[6] = hi.z, s[7] = hi.w, s[8] = 0, s[9] = 0, s[10] = 0;
+    if (dp.montgomery) {
+        fr_t c32 = fr_t::zero();
+        c32.v[0] = 32;  // a * 2^256 read as internal a * 2^-5 (ff.hip.h): one Montgomery product by the integer 2^5 gives a
+        (fr_t::unpack(s) * c32).pack(s);
+    }
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        carry += (uint64_t)s[k] + dp.bias[k];
+        s[k] = (uint32_t)carry;
+        carry >>= 32;
+    }
+}
+// C and r are compile-time (the callers unroll over r): the word index and the shift fold to constants, so the recoded words
+// stay in registers (a run-time index would push them to scratch memory)
+template <int C>
+__device__ __forceinline__ uint32_t recoded_digit(const uint32_t* s, int r) {
+    const int bit = C * r, wi = bit >> 5, sh = bit & 31;
+    // v_alignbit_b32: low 32 bits of (s[wi + 1] : s[wi]) >> sh - kept as an intrinsic so that the compiler does not turn the
+    // 64-bit shift into an unaligned load from a stack copy of s[]
+    const uint32_t x = sh ? __builtin_amdgcn_alignbit(s[wi + 1], s[wi], (uint32_t)sh) : s[wi];
+    return x & ((1u << C) - 1);
+}
+static constexpr int FUSED_MAX_ROWS = 16;  // 288 digit bits / 17-bit windows
+// Coalesced read of 2 * FUSED_THREADS consecutive scalars (half a tile) into `stage` (4 * FUSED_THREADS uint4 = 32 KB): every
+// thread issues its four 16-byte loads before anything waits on them.
+__device__ __forceinline__ void fused_stage_half(const uint4* __restrict__ scalars, size_t first, size_t n, uint4* stage) {
+    const size_t cnt = first >= n ? 0 : (n - first < (size_t)(2 * FUSED_THREADS) ? n - first : (size_t)(2 * FUSED_THREADS));
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t idx = threadIdx.x + k * FUSED_THREADS;
+        v[k] = ((size_t)(idx >> 1) < cnt) ? scalars[first * 2 + idx] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) stage[threadIdx.x + k * FUSED_THREADS] = v[k];
+}
+// dynamic LDS: rows * B1 counters.  The scalar read needs no staging here: every thread issues the eight 16-byte loads of its
+// four scalars up front (lane stride 32 B: the two loads of a scalar use the two halves of the same cache lines, so every
+// line is fetched from HBM once) and nothing but the LDS counters sits between the loads and the end of the kernel.
+template <int C>
+__global__ void __launch_bounds__(FUSED_THREADS) radix_hist1_fused_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ cnt,
+                                                                   msm_radix_params_t p, msm_digit_params_t dp) {
+    extern __shared__ uint32_t fused_hist[];
+    const uint32_t B1 = 1u << p.HB;
+    const uint32_t rows = (uint32_t)dp.W;  // digit rows per scalar (= W * J)
+    const uint32_t keys = rows * B1;
+    uint32_t* hist = fused_hist;
+    const uint32_t t = blockIdx.x;
+    uint4 lo[FUSED_SPT], hi[FUSED_SPT];
+#pragma unroll
+    for (int q = 0; q < FUSED_SPT; q++) {
+        const size_t i = (size_t)t * FUSED_TILE + (size_t)q * FUSED_THREADS + threadIdx.x;
+        if (i < p.n) {
+            lo[q] = scalars[2 * i];
+            hi[q] = scalars[2 * i + 1];
+        } else {
+            lo[q] = hi[q] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < keys; i += FUSED_THREADS) hist[i] = 0;
+    __syncthreads();
+    const int half = 1 << (p.c - 1);
+#pragma unroll
+    for (int q = 0; q < FUSED_SPT; q++) {
+        if ((size_t)t * FUSED_TILE + (size_t)q * FUSED_THREADS + threadIdx.x >= p.n) continue;
+        uint32_t s[11];
+        recode_scalar(lo[q], hi[q], dp, s);
+#pragma unroll
+        for (int r = 0; r < FUSED_MAX_ROWS; r++) {
+            uint32_t b, neg;
+            if (C * r < MSM_BIAS_BITS && (uint32_t)r < rows && digit_bucket(recoded_digit<C>(s, r), half, b, neg)) atomicAdd(&hist[r * B1 + (b >> p.LB)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < keys; i += FUSED_THREADS) cnt[(size_t)t * keys + i] = hist[i];
+}
+// key = (j * W + w) * B1 + bin  ->  position of (q = w * B1 + bin, j) in the scan order
+__device__ __forceinline__ uint32_t fused_group_index(uint32_t key, uint32_t B1, uint32_t W, uint32_t J) {
+    const uint32_t r = key / B1, bin = key - r * B1;
+    const uint32_t w = r % W, j = r / W;
+    return (w * B1 + bin) * J + j;
+}
+// chunk column sums: csum[(q * J + j) * nchunks + chunk] = sum over the chunk's tiles of cnt[t][key]
+static __global__ void __launch_bounds__(FUSED_THREADS) fused_chunk_sums_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ csum, uint32_t ntiles,
+                                                                         uint32_t nchunks, uint32_t keys, uint32_t B1, uint32_t W, uint32_t J) {
+    const uint32_t ch = blockIdx.x;
+    const uint32_t t0 = ch * FUSED_CHUNK, t1 = (t0 + FUSED_CHUNK < ntiles) ? t0 + FUSED_CHUNK : ntiles;
+    for (uint32_t key = threadIdx.x; key < keys; key += FUSED_THREADS) {
+        uint32_t s = 0;
+        for (uint32_t t = t0; t < t1; t++) s += cnt[(size_t)t * keys + key];
+        csum[(size_t)fused_group_index(key, B1, W, J) * nchunks + ch] = s;
+    }
+}
+// off[t][key] = scanned chunk offset + prefix of the chunk's earlier tiles; chunk 0 also publishes the bin starts of level 2
+static __global__ void __launch_bounds__(FUSED_THREADS) fused_tile_offsets_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ choff,
+                                                                           const uint32_t* __restrict__ csum, uint32_t* __restrict__ off,
+                                                                           uint32_t* __restrict__ binstart, uint32_t ntiles, uint32_t nchunks, uint32_t keys,
+                                                                           uint32_t B1, uint32_t W, uint32_t J) {
+    const uint32_t ch = blockIdx.x;
+    const uint32_t t0 = ch * FUSED_CHUNK, t1 = (t0 + FUSED_CHUNK < ntiles) ? t0 + FUSED_CHUNK : ntiles;
+    for (uint32_t key = threadIdx.x; key < keys; key += FUSED_THREADS) {
+        const uint32_t g = fused_group_index(key, B1, W, J);
+        uint32_t run = choff[(size_t)g * nchunks + ch];
+        if (ch == 0 && g % J == 0) binstart[g / J] = run;
+        for (uint32_t t = t0; t < t1; t++) {
+            const size_t idx = (size_t)t * keys + key;
+            const uint32_t c = cnt[idx];
+            off[idx] = run;
+            run += c;
+        }
+    }
+    if (ch == 0 && threadIdx.x == 0) {  // one past the last group: the total number of entries
+        const size_t last = (size_t)W * B1 * J * nchunks - 1;
+        binstart[W * B1] = choff[last] + csum[last];
+    }
+}
+// Exclusive scan over FUSED_THREADS values held one per thread (8 waves)
+__device__ __forceinline__ uint32_t block512_excl_scan(uint32_t v, uint32_t* wave_tot) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += t;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wv; k++) base += wave_tot[k];
+    return base + inc - v;
+}
+// requires FUSED_G * B1 <= FUSED_THREADS (B1 <= 128: the wide path keys level 1 on 7 bits); uint16_t remainders (LB = 14)
+template <int C>
+__global__ void __launch_bounds__(FUSED_THREADS) radix_scatter1_fused_kernel(const uint4* __restrict__ scalars, const uint32_t* __restrict__ cnt,
+                                                                      const uint32_t* __restrict__ off, uint32_t* __restrict__ v1,
+                                                                      uint16_t* __restrict__ l1, msm_radix_params_t p, msm_digit_params_t dp) {
+    __shared__ uint32_t sv_[FUSED_G * FUSED_TILE];  // also the staging area of the scalar read (4 * FUSED_THREADS uint4 = 32 KB)
+    __shared__ uint16_t sl_[FUSED_G * FUSED_TILE];
+    __shared__ uint16_t skey_[FUSED_G * FUSED_TILE];
+    __shared__ uint32_t lcount[FUSED_THREADS], lstart[FUSED_THREADS], cursor[FUSED_THREADS], gbase[FUSED_THREADS], wave_tot[8];
+    const uint32_t B1 = 1u << p.HB;
+    const uint32_t rows = (uint32_t)dp.W;
+    const uint32_t keys = rows * B1;
+    const uint32_t t = blockIdx.x;
+    const int half = 1 << (p.c - 1);
+    const uint32_t lmask = (1u << p.LB) - 1;
+    // ---- read the tile's scalars (coalesced through LDS) and keep their recoded words in registers
+    uint32_t sw[FUSED_SPT][10];
+    uint4* stage = (uint4*)sv_;
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const size_t first = (size_t)t * FUSED_TILE + (size_t)hf * (2 * FUSED_THREADS);
+        __syncthreads();
+        fused_stage_half(scalars, first, p.n, stage);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            const uint32_t li = sub * FUSED_THREADS + threadIdx.x;
+            uint32_t s[11];
+            recode_scalar(stage[2 * li], stage[2 * li + 1], dp, s);  // slots past n hold zeros: recoded, never placed
+#pragma unroll
+            for (int k = 0; k < 10; k++) sw[hf * 2 + sub][k] = s[k];
+        }
+    }
+    // ---- FUSED_G digit rows per round: group in LDS by (row, bin), write whole runs
+#pragma unroll
+    for (int round = 0; round < FUSED_MAX_ROWS / FUSED_G; round++) {
+        const uint32_t r0 = (uint32_t)round * FUSED_G;
+        if (r0 >= rows) break;
+        __syncthreads();  // staging area / previous round's runs consumed
+        {
+            const uint32_t lk = threadIdx.x;  // one (row in round, bin) per thread
+            const uint32_t rl = lk / B1, bin = lk - rl * B1, r = r0 + rl;
+            uint32_t c = 0, gb = 0;
+            if (rl < FUSED_G && r < rows) {
+                const size_t idx = (size_t)t * keys + (size_t)r * B1 + bin;
+                c = cnt[idx];
+                gb = off[idx];
+            }
+            lcount[lk] = c;
+            gbase[lk] = gb;
+            const uint32_t start = block512_excl_scan(c, wave_tot);
+            lstart[lk] = start;
+            cursor[lk] = start;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < FUSED_SPT; q++) {
+            const size_t i64 = (size_t)t * FUSED_TILE + (size_t)(q >> 1) * (2 * FUSED_THREADS) + (size_t)(q & 1) * FUSED_THREADS + threadIdx.x;
+            if (i64 >= p.n) continue;
+            const uint32_t i = (uint32_t)i64;
+#pragma unroll
+            for (int rl = 0; rl < FUSED_G; rl++) {
+                const int r = round * FUSED_G + rl;  // compile-time after unrolling
+                uint32_t b, neg;
+                if (C * r < MSM_BIAS_BITS && (uint32_t)r < rows && digit_bucket(recoded_digit<C>(sw[q], r), half, b, neg)) {
+                    const uint32_t lk = (uint32_t)rl * B1 + (b >> p.LB);
+                    const uint32_t pos = atomicAdd(&cursor[lk], 1u);
+                    const uint32_t j = (uint32_t)r / (uint32_t)p.W;
+                    sv_[pos] = ((uint32_t)((size_t)j * p.n) + i) | neg;
+                    sl_[pos] = (uint16_t)(b & lmask);
+                    skey_[pos] = (uint16_t)lk;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t last = FUSED_G * B1 - 1;
+        const uint32_t total = lstart[last] + lcount[last];
+        for (uint32_t pos = threadIdx.x; pos < total; pos += FUSED_THREADS) {
+            const uint32_t lk = skey_[pos];
+            const size_t dst = (size_t)gbase[lk] + (pos - lstart[lk]);
+            v1[dst] = sv_[pos];
+            l1[dst] = sl_[pos];
+        }
+    }
+}
+
 // ---- level 2 tiling: bin q = w * B1 + bin covers [binstart[q], binstart[q+1]) of v1/l1 and gets ceil(size / TILE) tiles
 static __global__ void radix_bin_layout_kernel(const uint32_t* __restrict__ off1, const uint32_t* __restrict__ counts1, size_t ncounts1,
                                         uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t TPW) {

@@ -1,7 +1,7 @@
 // ntt.hip.h - radix-2 NTT / iNTT over BLS12-377 Fr for gfx950.
 //
 // Replaces (behaviour, not code): sppark's NTT::Base / NTT_internal / bit_rev as called from
-// algorithms/cuda/cuda/snarkvm.cu:154-186 and polynomial.hip.h:104-266, and the CPU transforms of
+// algorithms/cuda/cuda/snarkvm.cu:154-186 and polynomial.cuh:104-266, and the CPU transforms of
 // algorithms/src/fft/domain.rs:374-443 (in_order_fft / ifft / coset_ifft), :691-773 (io/oi helpers).
 //
 // Structure (MI355X-first): a 2^lg transform is split into at most three passes of radix <= 2^8
@@ -15,7 +15,7 @@
 //     would overwrite), hence the ping-pong with a scratch buffer in ntt_run().
 // Every pass reads and writes each element exactly once in >= 256-byte contiguous runs, so HBM traffic is
 // passes * 2 * 32 * n bytes (algorithmic minimum 2 * 32 * n: SURVEY.md 8d).  Twiddles are never
-// streamed from HBM: per-stage twiddles come from a 128-entry table of w_256 powers staged in LDS.
+// streamed from HBM: per-stage twiddles come from a 256-entry table of w_512 powers staged in LDS.
 //
 // Data stays in the reference's memory form (Montgomery, R = 2^256) throughout; see ff.hip.h for why the
 // 29-bit-limb arithmetic needs no conversion on this (linear) path.
@@ -27,10 +27,11 @@
 
 namespace sv {
 
-static constexpr int NTT_LG_MAX = 24;     // two-level tables cover exponents < 2^24
-static constexpr int NTT_TW_BITS = 12;    // w^e = hi[e >> 12] * lo[e & 4095]
+static constexpr int NTT_LG_MAX = 26;     // two-level tables cover exponents < 2^26 (2 GiB vectors; larger domains: the caller's CPU path)
+static constexpr int NTT_TW_BITS = 13;    // w^e = hi[e >> 13] * lo[e & 8191]
 static constexpr int NTT_TW_SIZE = 1 << NTT_TW_BITS;
-static constexpr int NTT_MAX_RADIX_LG = 8;
+static constexpr int NTT_MAX_RADIX_LG = 9;  // passes of radix <= 2^8 up to 2^24; 2^25 / 2^26 use radix-2^9 passes on narrower tiles
+static constexpr int NTT_LOCAL = 1 << (NTT_MAX_RADIX_LG - 1);  // per-stage twiddles: powers of w_512 staged in LDS
 
 // order / direction / type enums: algorithms/cuda/src/lib.rs:22-40
 enum { NTT_NN = 0, NTT_NR = 1, NTT_RN = 2, NTT_RR = 3 };
@@ -41,7 +42,7 @@ enum { NTT_STANDARD = 0, NTT_COSET = 1 };
 struct ntt_tables_t {
     fr_mem_t* pow_lo[2];   // [dir][4096]  W^(+-i)          W = primitive 2^24-th root of unity
     fr_mem_t* pow_hi[2];   // [dir][4096]  W^(+-4096 i)
-    fr_mem_t* local[2];    // [dir][128]   w_256^(+-i)
+    fr_mem_t* local[2];    // [dir][NTT_LOCAL]   w_512^(+-i)
     fr_mem_t* g_lo[2];     // [0]: g^i  [1]: g^-i          g = 22 (fr.rs:126-135)
     fr_mem_t* g_hi[2];     //      g^(+-4096 i)
     fr_mem_t* size_inv;    // [25]  (2^lg)^-1
@@ -58,7 +59,7 @@ static __global__ void ntt_setup_consts(ntt_tables_t t) {
     uint32_t w8[8];
     for (int i = 0; i < 8; i++) w8[i] = FR_TWO_ADIC_ROOT_MEM[i];
     fr_t w = fr_t::unpack(w8).from_mem_mont();          // 2^47-th root, internal form
-    for (int i = 0; i < 47 - NTT_LG_MAX; i++) w = w.sqr();  // -> primitive 2^24-th root
+    for (int i = 0; i < 47 - NTT_LG_MAX; i++) w = w.sqr();  // -> primitive 2^NTT_LG_MAX-th root
     fr_t g = fr_t::from_u32(22);
     w.store(&t.consts[0]);
     w.inverse().store(&t.consts[1]);
@@ -81,7 +82,7 @@ static __global__ void ntt_fill_tables(ntt_tables_t t) {
         fr_mem_t* hi = which < 2 ? t.pow_hi[which] : t.g_hi[which - 2];
         b.pow_u64((uint64_t)i).store(&lo[i]);
         b.pow_u64((uint64_t)i << NTT_TW_BITS).store(&hi[i]);
-        if (which < 2 && i < 128) b.pow_u64((uint64_t)i << 16).store(&t.local[which][i]);
+        if (which < 2 && i < NTT_LOCAL) b.pow_u64((uint64_t)i << (NTT_LG_MAX - NTT_MAX_RADIX_LG)).store(&t.local[which][i]);
     }
 }
 
@@ -122,11 +123,12 @@ __device__ __forceinline__ fr_t tw_lookup(const fr_mem_t* lo, const fr_mem_t* hi
 //     skip the conditional subtraction.  Bound: entering local stage s every value is < 2^s * r (inputs canonical),
 //     so after a <= 8 stages values are < 256 r < 2^261 (9 limbs).  The closing multiplication (inter-pass twiddle,
 //     1/n scaling, or the constant one) brings the value below 2r and one conditional subtraction makes it
-//     canonical again before it is stored.
+//     canonical again before it is stored.  (Radix-2^9 passes, used from 2^25: the top limb holds the 262nd bit and the
+//     closing product is < 2.17 r - two conditional subtractions.)
 // ------------------------------------------------------------------------------------------
 struct ntt_lds_t {
     uint32_t* data;  // E elements of 9 limbs each (stride 9 words is coprime to the bank count; the limb offsets are immediates)
-    uint32_t* tw;    // 9 planes of 128 limbs (w_256 powers, internal form)
+    uint32_t* tw;    // 9 planes of NTT_LOCAL limbs (w_512 powers, internal form)
     int E;
     __device__ __forceinline__ fr_t get(int e) const {
         fr_t x;
@@ -141,7 +143,7 @@ struct ntt_lds_t {
     __device__ __forceinline__ fr_t twiddle(int idx) const {
         fr_t x;
 #pragma unroll
-        for (int l = 0; l < 9; l++) x.v[l] = tw[l * 128 + idx];
+        for (int l = 0; l < 9; l++) x.v[l] = tw[l * NTT_LOCAL + idx];
         return x;
     }
 };
@@ -219,10 +221,10 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, n
         in_col_stride = (size_t)1 << (p.lg_n - p.a1);
     }
     // local twiddles -> LDS planes
-    for (int i = tid; i < 128; i += nthr) {
+    for (int i = tid; i < NTT_LOCAL; i += nthr) {
         const fr_t w = fr_t::load(&tb.local[p.dir][i]);
 #pragma unroll
-        for (int l = 0; l < 9; l++) L.tw[l * 128 + i] = w.v[l];
+        for (int l = 0; l < 9; l++) L.tw[l * NTT_LOCAL + i] = w.v[l];
     }
     __syncthreads();
 
@@ -308,7 +310,11 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, n
                         }
                     }
                 }
-                store_fr_global(&p.out[g], y.reduce_lazy());
+                fr_t z = y.reduce_lazy();
+                // a radix-2^9 pass ends with values < 2^9 r = 1.17 * 2^261: the closing product is < 2.17 r, one more conditional
+                // subtraction makes it canonical
+                if (p.a > 8) z = z.reduce_lazy();
+                store_fr_global(&p.out[g], z);
             }
         }
         __syncthreads();
@@ -317,7 +323,7 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, n
     }
 }
 
-// out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.hip.h:128,189; domain.rs:797-804 derange)
+// out[i] = in[bitrev(i)]   (sppark `bit_rev`, polynomial.cuh:128,189; domain.rs:797-804 derange)
 static __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int lg_n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= ((size_t)1 << lg_n)) return;
@@ -327,7 +333,7 @@ static __global__ void ntt_bitrev_kernel(const fr_mem_t* in, fr_mem_t* out, int 
     d[0] = s[0];
     d[1] = s[1];
 }
-// polynomial_inner_multiply (polynomial.hip.h:36-45): out[i] = a[i] * b[i] (memory Montgomery form, R = 2^256).
+// polynomial_inner_multiply (polynomial.cuh:36-45): out[i] = a[i] * b[i] (memory Montgomery form, R = 2^256).
 // mont261(x, y) = x y 2^-261 = (a b 2^256) 2^-5, so `fix` = 2^(5 + 261) mod r restores the form (see ff.hip.h);
 // with fix_later the factor is left for the caller to fold into a later constant.
 static __global__ void fr_pointwise_mul_kernel(fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, size_t n, int fix_now) {
@@ -368,22 +374,30 @@ struct ntt_plan_t {
 };
 static inline ntt_plan_t ntt_make_plan(int lg) {
     ntt_plan_t pl;
-    if (lg <= NTT_MAX_RADIX_LG) {
+    constexpr int R8 = 8;  // preferred pass radix: a [2^8 x 8] tile is 72 KiB of LDS, two workgroups per CU
+    if (lg <= R8) {
         pl.npass = 1;
         pl.a[0] = lg;
         pl.a[1] = pl.a[2] = 0;
-    } else if (lg <= 2 * NTT_MAX_RADIX_LG) {
+    } else if (lg <= 2 * R8) {
         pl.npass = 2;
         pl.a[0] = lg / 2;
         pl.a[1] = lg - pl.a[0];
         pl.a[2] = 0;
-    } else {
+    } else {  // up to 3 * 9 = 27 bits; 2^25 and 2^26 get one or two radix-2^9 passes
         pl.npass = 3;
         pl.a[0] = lg / 3;
         pl.a[1] = (lg - pl.a[0]) / 2;
         pl.a[2] = lg - pl.a[0] - pl.a[1];
     }
     return pl;
+}
+// tile width (log2) of a pass of radix 2^a whose tile dimension offers `avail` bits: [2^a x 2^lgT] elements of 36 bytes must
+// fit the 96 KiB the pass kernel may use
+static inline int ntt_tile_lg(int a, int avail) {
+    int lgT = avail < 3 ? avail : 3;
+    while (lgT > 0 && a + lgT > 11) lgT--;
+    return lgT;
 }
 
 // ---- full closing-twiddle tables ----------------------------------------------------------------------------------
@@ -494,7 +508,7 @@ static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const nt
         int threads = (int)(E / 4);  // one radix-4 group per thread
         if (threads < 64) threads = 64;
         if (threads > 512) threads = 512;
-        const size_t shmem = (9 * E + 9 * 128) * sizeof(uint32_t);
+        const size_t shmem = (9 * E + 9 * NTT_LOCAL) * sizeof(uint32_t);
         hipLaunchKernelGGL(ntt_pass_kernel_v2, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
     }
 }
@@ -526,7 +540,7 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
         p.reduce_only = 0;
         if (!p.last) {
             p.s = lg - consumed - p.a;
-            p.lgT = p.s < 3 ? p.s : 3;
+            p.lgT = ntt_tile_lg(p.a, p.s);
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
             const bool prelast = (k == pl.npass - 2);
             bool f = false;
@@ -536,7 +550,7 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
             p.reduce_only = folded ? 1 : 0;
             p.a1 = (pl.npass >= 2) ? pl.a[0] : 0;
             p.lg_mid = (pl.npass == 3) ? pl.a[1] : 0;
-            p.lgT = p.a1 < 3 ? p.a1 : 3;
+            p.lgT = ntt_tile_lg(p.a, p.a1);
         }
         if (pl.npass == 1) {
             p.in = data;

@@ -117,6 +117,7 @@ struct lane_t {
     dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
     dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
     dev_buf fold_sums;                                                        // two-axis bucket fold
+    dev_buf fchunk;                                                           // chunk sums / offsets of the fused level-1 scan
     dev_buf bases_tmp, scalars_tmp, gen_pts, gen_prod;
     // NTT / polynomial staging
     dev_buf ntt_data, ntt_scratch, ntt_acc, ntt_alt;
@@ -170,8 +171,8 @@ struct device_t {
             HIP_TRY(hipStreamCreateWithFlags(&lane[l].alt, hipStreamNonBlocking));
             for (auto& e : lane[l].ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        // tables: 4 x (lo + hi) x 4096 + 2 x 128 + 25 + 4, 32 B each
-        const size_t entries = 8 * NTT_TW_SIZE + 256 + 32 + 8;
+        // tables: 4 x (lo + hi) x NTT_TW_SIZE + 2 x NTT_LOCAL + size_inv[27] + 4 constants, 32 B each
+        const size_t entries = 8 * NTT_TW_SIZE + 2 * NTT_LOCAL + 32 + 8;
         tables_mem.ensure(entries * sizeof(fr_mem_t));
         fr_mem_t* base = tables_mem.as<fr_mem_t>();
         size_t off = 0;
@@ -185,7 +186,7 @@ struct device_t {
             tb.pow_hi[d] = take(NTT_TW_SIZE);
             tb.g_lo[d] = take(NTT_TW_SIZE);
             tb.g_hi[d] = take(NTT_TW_SIZE);
-            tb.local[d] = take(128);
+            tb.local[d] = take(NTT_LOCAL);
         }
         tb.size_inv = take(32);
         tb.consts = take(8);
@@ -534,7 +535,6 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     const size_t E_max = (size_t)pl.Wd * n;
     const uint32_t nbt = pl.nbt;
 
-    c.digits.ensure(E_max * (wide ? sizeof(uint32_t) : sizeof(uint16_t)));
     c.scan_tmp.ensure((scan_tmp_elems((size_t)nbt + 1)) * 4);
     c.boff.ensure(((size_t)nbt + 2) * 4);
     c.cnt_a.ensure(((size_t)nbt + 1) * 4);
@@ -563,23 +563,27 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         throw hip_failure{hipErrorInvalidValue, "msm: window geometry exceeds the tail's bit-position range", __LINE__};
     c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
 
-    // 1. digits
-    phase_begin("msm_digits");
-    {
-        msm_digit_params_t dp;
-        memcpy(dp.bias, pl.bias, sizeof dp.bias);
-        dp.c = pl.c;
-        dp.W = pl.Wd;
-        dp.n = n;
-        dp.montgomery = scalars_montgomery;
+    // 1. scalar read.  Wide windows: fused with the level-1 partition below (the digits never exist in memory); otherwise the
+    // stand-alone digit kernel writes the [rows][n] digit matrix.
+    static const int fused_env = getenv("SNARKVM_HIP_FUSED") ? atoi(getenv("SNARKVM_HIP_FUSED")) : 1;
+    const bool fused = wide && fused_env && pl.c <= 22 && pl.Wd <= FUSED_MAX_ROWS;  // level-1 key of <= 7 bits: FUSED_G * 2^HB <= FUSED_THREADS
+    msm_digit_params_t dp;
+    memcpy(dp.bias, pl.bias, sizeof dp.bias);
+    dp.c = pl.c;
+    dp.W = pl.Wd;
+    dp.n = n;
+    dp.montgomery = scalars_montgomery;
+    if (!fused) {
+        phase_begin("msm_digits");
+        c.digits.ensure(E_max * (wide ? sizeof(uint32_t) : sizeof(uint16_t)));
         size_t blocks = (n + 255) / 256;
         if (blocks > 256 * 16) blocks = 256 * 16;
         if (wide)
             hipLaunchKernelGGL((msm_digits_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint32_t>(), dp);
         else
             hipLaunchKernelGGL((msm_digits_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
+        phase_end();
     }
-    phase_end();
     int rounds = 0;
     {
         // ---- 2.-4. LDS-staged radix partition (msm_sort.hip.h) -> bucket-major `sorted` + boff; two levels, three when wide
@@ -592,7 +596,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         rp.LB = wide ? 14 : LBL;        // bits left below the level-1 key
         rp.HB = K - rp.LB;
         rp.nb = pl.nb;
-        rp.tiles_per_row = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+        rp.tiles_per_row = fused ? (uint32_t)((n + FUSED_TILE - 1) / FUSED_TILE) : (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
         rp.TPW = (uint32_t)pl.J * rp.tiles_per_row;
         const uint32_t B1 = 1u << rp.HB;
         const uint32_t nbins = (uint32_t)pl.W * B1;
@@ -617,20 +621,57 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         uint32_t* bsize = c.rbsize.as<uint32_t>();
         uint32_t* d_max = bsize + nbt + 1;
         uint32_t* boffp = c.boff.as<uint32_t>();
-        phase_begin("msm_sort_level1");
-        if (wide) {
+        if (fused) {
+            // the scalar-read phase proper: a read-only pass over the scalars (32 B each) that leaves the level-1 histograms
+            const uint32_t ntiles = rp.tiles_per_row, keys = (uint32_t)pl.Wd * B1;
+            const uint32_t nchunks = (ntiles + FUSED_CHUNK - 1) / FUSED_CHUNK;
+            const size_t ngroups = (size_t)keys * nchunks;
+            c.counts.ensure((size_t)ntiles * keys * 4);
+            c.offsets.ensure((size_t)ntiles * keys * 4);
+            c.fchunk.ensure(2 * ngroups * 4);
+            c.scan_tmp.ensure(scan_tmp_elems(ngroups > (size_t)nbt + 2 ? ngroups : (size_t)nbt + 2) * 4);
+            counts1 = c.counts.as<uint32_t>();
+            off1 = c.offsets.as<uint32_t>();
+            uint32_t* csum = c.fchunk.as<uint32_t>();
+            uint32_t* choff = csum + ngroups;
+            phase_begin("msm_scalar_read");
+            const size_t hist_lds = (size_t)keys * 4;
+#define SV_FUSED_HIST(CB)                                                                                                                         \
+    case CB:                                                                                                                                      \
+        hipLaunchKernelGGL((radix_hist1_fused_kernel<CB>), dim3(ntiles), dim3(FUSED_THREADS), hist_lds, st, d_scalars, counts1, rp, dp);         \
+        break;
+            switch (pl.c) { SV_FUSED_HIST(17) SV_FUSED_HIST(18) SV_FUSED_HIST(19) SV_FUSED_HIST(20) SV_FUSED_HIST(21) SV_FUSED_HIST(22) }
+#undef SV_FUSED_HIST
+            phase_end();
+            phase_begin("msm_sort_level1");
+            hipLaunchKernelGGL(fused_chunk_sums_kernel, dim3(nchunks), dim3(FUSED_THREADS), 0, st, (const uint32_t*)counts1, csum, ntiles, nchunks, keys, B1,
+                               (uint32_t)pl.W, (uint32_t)pl.J);
+            exclusive_scan_u32(st, csum, choff, ngroups, c.scan_tmp.as<uint32_t>());
+            hipLaunchKernelGGL(fused_tile_offsets_kernel, dim3(nchunks), dim3(FUSED_THREADS), 0, st, (const uint32_t*)counts1, (const uint32_t*)choff,
+                               (const uint32_t*)csum, off1, c.rbinstart.as<uint32_t>(), ntiles, nchunks, keys, B1, (uint32_t)pl.W, (uint32_t)pl.J);
+#define SV_FUSED_SCATTER(CB)                                                                                                                      \
+    case CB:                                                                                                                                      \
+        hipLaunchKernelGGL((radix_scatter1_fused_kernel<CB>), dim3(ntiles), dim3(FUSED_THREADS), 0, st, d_scalars, (const uint32_t*)counts1,     \
+                           (const uint32_t*)off1, c.rv1.as<uint32_t>(), c.rl1.as<uint16_t>(), rp, dp);                                            \
+        break;
+            switch (pl.c) { SV_FUSED_SCATTER(17) SV_FUSED_SCATTER(18) SV_FUSED_SCATTER(19) SV_FUSED_SCATTER(20) SV_FUSED_SCATTER(21) SV_FUSED_SCATTER(22) }
+#undef SV_FUSED_SCATTER
+        } else if (wide) {
+            phase_begin("msm_sort_level1");
             hipLaunchKernelGGL((radix_hist1_kernel<uint32_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint32_t>(), counts1, rp);
             exclusive_scan_u32(st, counts1, off1, ncounts1, c.scan_tmp.as<uint32_t>());
             hipLaunchKernelGGL((radix_scatter1_kernel<uint32_t, uint16_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint32_t>(),
                                counts1, off1, c.rv1.as<uint32_t>(), c.rl1.as<uint16_t>(), rp);
         } else {
+            phase_begin("msm_sort_level1");
             hipLaunchKernelGGL((radix_hist1_kernel<uint16_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(), counts1, rp);
             exclusive_scan_u32(st, counts1, off1, ncounts1, c.scan_tmp.as<uint32_t>());
             hipLaunchKernelGGL((radix_scatter1_kernel<uint16_t, uint8_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(),
                                counts1, off1, c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(), rp);
         }
-        hipLaunchKernelGGL(radix_bin_layout_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, off1, counts1, ncounts1, c.rbinstart.as<uint32_t>(),
-                           nbins, rp.TPW);
+        if (!fused)
+            hipLaunchKernelGGL(radix_bin_layout_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, off1, counts1, ncounts1, c.rbinstart.as<uint32_t>(),
+                               nbins, rp.TPW);
         phase_end();
         // one further level: items (v_in, rem_in) grouped in `nseg` segments -> grouped by (segment, next `bits` key bits)
         auto tile_segments = [&](const uint32_t* seg_start, uint32_t nseg) {

@@ -204,17 +204,49 @@ static __global__ void g1_serialize_kernel(const uint8_t* __restrict__ affine, s
     }
 }
 
-// ---- G2 (uncompressed only): x.c0, x.c1, y.c0, y.c1 as 48-byte little-endian canonical integers, SWFlags in the top bits
-// of the last one (fields/src/fp2.rs:425-455: c0 plain, c1 with the flags); 192 bytes, e.g. `beta-h.usrs`.
+// ---- G2: x.c0, x.c1, y.c0, y.c1 as 48-byte little-endian canonical integers, SWFlags in the top bits of the last one
+// (fields/src/fp2.rs:425-455: c0 plain, c1 with the flags); 192 bytes uncompressed (e.g. `beta-h.usrs`), 96 bytes compressed
+// (x only; y = the Fq2 square root of x^3 + b' selected by the sign flag, affine.rs:140-150 with `Ord for Fp2`, fp2.rs:240-250).
 // G2 curve constant b' = (0, b1) (curves/src/bls12_377/g2.rs:92-113), canonical integer words of b1
 __device__ static const uint32_t G2_B_C1_INT[12] = {0x9999999au, 0x1c9ed999u, 0x1ccccccdu, 0x0dd39e5cu, 0x3c6bf800u, 0x129207b6u,
                                                    0xcd5fd889u, 0xdc7b4f91u, 0x7460c589u, 0x43bd0373u, 0xdb0fd6f3u, 0x010222f6u};
-__device__ inline bool g2_is_on_curve(const aff_t<fq2_t>& p) {
+// `Fp2::sqrt` (fields/src/fp2.rs:208-230; complex method, eprint 2012/685 algorithm 8).  false where the reference returns None
+// - including an element of the base field that is a non-residue THERE (fp2.rs:210-212 only tries `c0.sqrt()`).
+__device__ inline bool fq2_sqrt(const fq2_t& a, fq2_t& root) {
+    if (a.c1.is_zero()) {
+        fq_t r;
+        if (!fq_sqrt(a.c0, r)) return false;
+        root = {r, fq_t::zero()};
+        return true;
+    }
+    const fq_t norm = a.c0.sqr() + fq2_t::mul5(a.c1.sqr());  // c0^2 - nonresidue * c1^2, nonresidue = -5
+    fq_t alpha;
+    if (!fq_sqrt(norm, alpha)) return false;  // legendre(norm) == QNR
+    const fq_t two_inv = fq_t::from_u32(2).inverse();
+    fq_t delta = (alpha + a.c0) * two_inv;
+    fq_t c0;
+    if (!fq_sqrt(delta, c0)) {  // delta is a non-residue: the other choice of alpha's sign
+        delta = delta - alpha;
+        if (!fq_sqrt(delta, c0)) return false;
+    }
+    if (c0.is_zero()) return false;  // cannot happen for c1 != 0
+    root = {c0, a.c1 * two_inv * c0.inverse()};
+    return true;
+}
+// a > b in the reference's order on Fp2 (fp2.rs:240-250): lexicographic, c1 first, canonical integers
+__device__ __forceinline__ bool fq2_int_gt(const fq2_t& a, const fq2_t& b) {
+    const fq_t a1 = a.c1.mont_to_int(), b1 = b.c1.mont_to_int();
+    if (a1 != b1) return fq_int_gt(a1, b1);
+    return fq_int_gt(a.c0.mont_to_int(), b.c0.mont_to_int());
+}
+__device__ inline fq2_t g2_curve_b() {
     uint32_t bw[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) bw[k] = G2_B_C1_INT[k];
-    const fq2_t b = {fq_t::zero(), fq_t::unpack(bw).int_to_mont()};
-    return p.y.sqr() == p.x.sqr() * p.x + b;
+    return {fq_t::zero(), fq_t::unpack(bw).int_to_mont()};
+}
+__device__ inline bool g2_is_on_curve(const aff_t<fq2_t>& p) {
+    return p.y.sqr() == p.x.sqr() * p.x + g2_curve_b();
 }
 __device__ inline bool g2_is_in_subgroup(const aff_t<fq2_t>& p) {
     xyzz_t<fq2_t> acc = xyzz_t<fq2_t>::inf();
@@ -227,19 +259,38 @@ __device__ inline bool g2_is_in_subgroup(const aff_t<fq2_t>& p) {
     }
     return acc.is_inf();
 }
-static __global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int validate, uint8_t* __restrict__ out_rust, uint32_t* status) {
+static __global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, size_t n, int compressed, int validate, uint8_t* __restrict__ out_rust,
+                                      uint32_t* status) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint8_t* src = bytes + i * 192;
-    const uint8_t fb = src[191];
+    const size_t psz = compressed ? 96 : 192;
+    const uint8_t* src = bytes + i * psz;
+    const uint8_t fb = src[psz - 1];
     const bool f_pos = (fb >> 7) & 1, f_inf = (fb >> 6) & 1;
     uint32_t st = 0;
     if (f_pos && f_inf) st |= SERDE_BAD_FLAGS;
     fq_t c[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (!fq_from_le_bytes(src + 48 * k, k == 3 ? 0x3fffffffu : 0xffffffffu, c[k])) st |= SERDE_NOT_CANONICAL;
-    aff_t<fq2_t> p = {{c[0].int_to_mont(), c[1].int_to_mont()}, {c[2].int_to_mont(), c[3].int_to_mont()}};
+    const int ncoord = compressed ? 2 : 4;
+    for (int k = 0; k < ncoord; k++)
+        if (!fq_from_le_bytes(src + 48 * k, k == ncoord - 1 ? 0x3fffffffu : 0xffffffffu, c[k])) st |= SERDE_NOT_CANONICAL;
+    aff_t<fq2_t> p;
+    if (compressed) {
+        if (f_inf) {
+            p = {fq2_t::zero(), fq2_t::one()};  // Affine::zero() = (0, 1, infinity)
+        } else {
+            p.x = {c[0].int_to_mont(), c[1].int_to_mont()};
+            fq2_t y;
+            if (!fq2_sqrt(p.x.sqr() * p.x + g2_curve_b(), y)) {
+                st |= SERDE_NOT_ON_CURVE;  // from_x_coordinate == None -> InvalidData
+                y = fq2_t::zero();
+            }
+            const fq2_t ny = y.neg();
+            const bool y_lt_ny = fq2_int_gt(ny, y);
+            p.y = (y_lt_ny != f_pos) ? y : ny;  // affine.rs:147
+        }
+    } else {
+        p = {{c[0].int_to_mont(), c[1].int_to_mont()}, {c[2].int_to_mont(), c[3].int_to_mont()}};
+    }
     if (validate && !f_inf && !st) {
         if (!g2_is_on_curve(p))
             st |= SERDE_NOT_ON_CURVE;
@@ -255,18 +306,34 @@ static __global__ void g2_deserialize_kernel(const uint8_t* __restrict__ bytes, 
     dst[48] = f_inf ? 1u : 0u;
     dst[49] = 0;
 }
-static __global__ void g2_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, uint8_t* __restrict__ out) {
+static __global__ void g2_serialize_kernel(const uint8_t* __restrict__ affine, size_t stride, size_t n, int compressed, uint8_t* __restrict__ out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = (const uint32_t*)(affine + i * stride);
     const bool inf = (src[48] & 0xffu) != 0;
-    uint8_t* dst = out + i * 192;
+    fq_t c[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t w[12];
 #pragma unroll
         for (int j = 0; j < 12; j++) w[j] = src[12 * k + j];
-        fq_to_le_bytes(fq_t::from_raw_words(w).mont_to_int(), (k == 3 && inf) ? (uint8_t)(1u << 6) : (uint8_t)0, dst + 48 * k);
+        c[k] = fq_t::from_raw_words(w);
+    }
+    if (compressed) {
+        uint8_t* dst = out + i * 96;
+        if (inf) {
+            fq_to_le_bytes(fq_t::zero(), 0, dst);
+            fq_to_le_bytes(fq_t::zero(), 1u << 6, dst + 48);
+        } else {
+            const fq2_t y = {c[2], c[3]};
+            const bool pos = fq2_int_gt(y, y.neg());  // SWFlags::from_y_sign(y > -y)
+            fq_to_le_bytes(c[0].mont_to_int(), 0, dst);
+            fq_to_le_bytes(c[1].mont_to_int(), pos ? (uint8_t)(1u << 7) : (uint8_t)0, dst + 48);
+        }
+    } else {
+        uint8_t* dst = out + i * 192;
+#pragma unroll
+        for (int k = 0; k < 4; k++) fq_to_le_bytes(c[k].mont_to_int(), (k == 3 && inf) ? (uint8_t)(1u << 6) : (uint8_t)0, dst + 48 * k);
     }
 }
 

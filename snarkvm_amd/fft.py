@@ -97,9 +97,22 @@ class Evaluations:
 
 
 def evaluate_over_domain(coeffs, domain):
-    """fft/polynomial/mod.rs:261-300 for a dense polynomial no longer than the domain: zero-pad + FFT.
-    (Longer polynomials are folded chunk-wise on the host by the reference; that path stays with the caller.)"""
-    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    """`Polynomial::evaluate_over_domain` for a dense polynomial (fft/polynomial/mod.rs:261-300).
+
+    deg < |domain|: zero-pad + FFT.  deg >= |domain|: the reference transforms every chunk of |domain| coefficients and adds
+    the evaluation vectors (mod.rs:277-285); the transform is linear, so the same field elements come out of ONE transform of
+    the chunk-wise sum of the coefficients - which is the remainder of the polynomial modulo X^|domain| - 1, computed on the
+    device by the class fold of `divide_by_vanishing_poly` (poly.hip.h fr_fold_vanishing_kernel)."""
+    import ctypes
+
+    from . import _lib, poly
+
+    coeffs = poly.trim(coeffs)  # `degree()` looks at the trimmed polynomial (dense.rs:88-96)
     if coeffs.shape[0] > domain.size:
-        raise NotImplementedError("polynomial longer than the domain: fold on the host first (polynomial/mod.rs:270-286)")
+        n = coeffs.shape[0]
+        q = np.zeros((n - domain.size, 4), dtype=np.uint64)
+        folded = np.zeros((domain.size, 4), dtype=np.uint64)
+        _lib.check(_lib.lib().snarkvm_hip_fr_divide_by_vanishing(ctypes.c_void_p(q.ctypes.data), ctypes.c_void_p(folded.ctypes.data), ctypes.c_void_p(coeffs.ctypes.data),
+                                                                ctypes.c_size_t(n), ctypes.c_size_t(domain.size), ctypes.c_int(0)))
+        coeffs = folded
     return Evaluations(domain.fft(coeffs), domain)

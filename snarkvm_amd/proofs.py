@@ -91,7 +91,7 @@ class ProofWorkspace:
         self.keys = keys
         self.device = torch.device("cuda", device_index)
         with torch.cuda.device(self.device):
-            self.pool = torch.from_numpy(keys.pool_host.view(np.int64)).to(self.device)
+            self.pool = torch.from_numpy(keys.pool_host.view(np.int64).reshape(-1)).to(self.device)
             self.work = [torch.empty(keys.shape.nmax * 4, dtype=torch.int64, device=self.device) for _ in range(4)]
             torch.cuda.synchronize()
         self.out = np.zeros(1, dtype=G1_PROJECTIVE)
@@ -186,6 +186,32 @@ def replay(ws, salt=0, collect=None):
                                                                         ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0)))
         if collect is not None:
             collect.append(ws.out_g2.tobytes())
+
+
+def normalize_results(results):
+    """Commitment lists as comparable values: the device returns Jacobian representatives whose coordinates depend on the
+    order in which bucket entries happened to be added, so results are compared after affine normalisation (as the reference's
+    own tests do, variable_base/mod.rs:96-105).  G1 records (144 B) go through snarkvm_hip_g1_to_affine; the G2 record (288 B)
+    is normalised with Python integers."""
+    from . import kzg10
+
+    out = []
+    for item in results:
+        if len(item) == 144:
+            out.append(kzg10.to_affine(np.frombuffer(item, dtype=G1_PROJECTIVE)).tobytes())
+        else:
+            q = synthetic.Q_MOD
+            rinv = pow(1 << 384, q - 2, q)
+            w = np.frombuffer(item, dtype="<u8").reshape(6, 6)
+            c = [sum(int(l) << (64 * i) for i, l in enumerate(row)) * rinv % q for row in w]  # X.c0, X.c1, Y.c0, Y.c1, Z.c0, Z.c1
+            X, Y, Z = (c[0], c[1]), (c[2], c[3]), (c[4], c[5])
+            if Z == (0, 0):
+                out.append(b"infinity")
+                continue
+            zi = synthetic._fq2_inv(Z)
+            zi2 = synthetic._fq2_mul(zi, zi)
+            out.append(repr((synthetic._fq2_mul(X, zi2), synthetic._fq2_mul(Y, synthetic._fq2_mul(zi2, zi)))).encode())
+    return out
 
 
 class ProofBatch:

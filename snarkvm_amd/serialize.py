@@ -71,27 +71,30 @@ def register_bases_serialized(data, npoints, compressed=False, validate=False, t
 
 
 G2_UNCOMPRESSED_SIZE = 192
+G2_COMPRESSED_SIZE = 96
 
 
-def g2_deserialize(data, validate=False):
-    """bytes -> G2_AFFINE record array (uncompressed encoding only, e.g. `beta-h.usrs`)."""
+def g2_deserialize(data, validate=False, compressed=False):
+    """bytes -> G2_AFFINE record array: uncompressed (192 B, e.g. `beta-h.usrs`) or compressed (96 B: x only; y is the Fq2
+    square root of x^3 + b' selected by the sign flag, recovered on the device)."""
     from .layout import G2_AFFINE
 
+    psz = G2_COMPRESSED_SIZE if compressed else G2_UNCOMPRESSED_SIZE
     buf = np.frombuffer(bytes(data), dtype=np.uint8)
-    if buf.shape[0] % G2_UNCOMPRESSED_SIZE:
+    if buf.shape[0] % psz:
         raise SerializationError("truncated input")
-    n = buf.shape[0] // G2_UNCOMPRESSED_SIZE
+    n = buf.shape[0] // psz
     out = np.zeros(n, dtype=G2_AFFINE)
-    _check(_lib.lib().snarkvm_hip_g2_deserialize(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(n),
-                                                ctypes.c_int(int(validate))))
+    fn = _lib.lib().snarkvm_hip_g2_deserialize_compressed if compressed else _lib.lib().snarkvm_hip_g2_deserialize
+    _check(fn(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(n), ctypes.c_int(int(validate))))
     return out
 
 
-def g2_serialize(points):
+def g2_serialize(points, compressed=False):
     from .layout import G2_AFFINE
 
     points = np.ascontiguousarray(points, dtype=G2_AFFINE).reshape(-1)
-    out = np.zeros(points.shape[0] * G2_UNCOMPRESSED_SIZE, dtype=np.uint8)
-    _check(_lib.lib().snarkvm_hip_g2_serialize(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(points.ctypes.data), ctypes.c_size_t(points.shape[0]),
-                                              ctypes.c_size_t(G2_AFFINE.itemsize)))
+    out = np.zeros(points.shape[0] * (G2_COMPRESSED_SIZE if compressed else G2_UNCOMPRESSED_SIZE), dtype=np.uint8)
+    fn = _lib.lib().snarkvm_hip_g2_serialize_compressed if compressed else _lib.lib().snarkvm_hip_g2_serialize
+    _check(fn(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(points.ctypes.data), ctypes.c_size_t(points.shape[0]), ctypes.c_size_t(G2_AFFINE.itemsize)))
     return out.tobytes()

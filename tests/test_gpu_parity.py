@@ -98,9 +98,37 @@ def test_ntt_2_24_properties():
     assert np.array_equal(z, x)
 
 
+def test_ntt_2_24_and_2_25_vs_oracle():
+    """The BASELINE size (three radix-2^8 passes) and the first size served by radix-2^9 passes, every element against the
+    oracle's `fft_in_place` / `ifft_in_place` restatement (all four transforms at 2^24, forward + coset inverse at 2^25)."""
+    for lg, kinds in ((24, [(NTTDirection.Forward, NTTType.Standard), (NTTDirection.Inverse, NTTType.Standard), (NTTDirection.Forward, NTTType.Coset),
+                            (NTTDirection.Inverse, NTTType.Coset)]),
+                      (25, [(NTTDirection.Forward, NTTType.Standard), (NTTDirection.Inverse, NTTType.Coset)])):
+        n = 1 << lg
+        x = _fr_vec(n, 4000 + lg)
+        for direction, kind in kinds:
+            y = x.copy()
+            plugin.NTT(n, y, NTTInputOutputOrder.NN, direction, kind)
+            assert np.array_equal(y, oracle.ntt(x, oracle.ORDER_NN, direction, kind)), (lg, direction, kind)
+
+
+def test_ntt_2_26_round_trip():
+    """The largest supported domain (2 GiB): forward + inverse and coset forward + coset inverse return the input."""
+    n = 1 << 26
+    x = _fr_vec(n, 4026)
+    y = x.copy()
+    plugin.NTT(n, y, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Standard)
+    assert not np.array_equal(y[:1024], x[:1024])
+    plugin.NTT(n, y, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Standard)
+    assert np.array_equal(y, x)
+    plugin.NTT(n, y, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Coset)
+    plugin.NTT(n, y, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Coset)
+    assert np.array_equal(y, x)
+
+
 def test_ntt_rejects_oversized_domain():
     with pytest.raises(_lib.HipError):
-        _lib.check(_lib.lib().snarkvm_ntt(None, ctypes.c_uint32(25), 0, 0, 0))
+        _lib.check(_lib.lib().snarkvm_ntt(None, ctypes.c_uint32(27), 0, 0, 0))
 
 
 def test_kat_intt8_and_domain_wrappers(golden):
@@ -647,7 +675,7 @@ def test_extension_abi_rejects_bad_arguments(golden):
     err(L.snarkvm_hip_fr_divide_by_vanishing(P(x), P(x), P(x), ctypes.c_size_t(8), ctypes.c_size_t(0), 0))    # empty domain
     err(L.snarkvm_hip_fr_lagrange_coefficients(P(x), ctypes.c_uint32(31), P(x), 0))                            # lg > 30
     err(L.snarkvm_hip_g1_group_ntt(P(out), ctypes.c_uint32(25), 0))                                            # lg > 24
-    err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(25), 0, 0, 0))                       # lg > 24: caller falls back
+    err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(27), 0, 0, 0))                       # lg > 26: caller falls back
     err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(4), 7, 0, 0))                        # bad enum
     err(L.snarkvm_hip_g1_serialize(P(x), P(bases), ctypes.c_size_t(1), ctypes.c_size_t(96), 0))                # stride < 104
 

@@ -262,3 +262,32 @@ def test_device_resident_round2_slice_and_openings(golden):
         want = oracle.g1_msm(powers_g[: wq.shape[0]], oracle.fr_op("to_bigint", wq), oracle.MSM_BATCHED)
         assert util.affine_equal(np.array([proof.w]), oracle.g1_to_affine(want))
     pw.close()
+
+
+@pytest.mark.parametrize("n,lg", [(5, 3), (8, 3), (9, 3), (1000, 8), (3 * 256 + 77, 8), (4 * 4096, 12), (4096 * 7 + 1, 12)])
+def test_evaluate_over_domain_incl_long_polynomials(n, lg):
+    """`Polynomial::evaluate_over_domain` (fft/polynomial/mod.rs:261-300): polynomials of degree >= |domain| are transformed
+    chunk by chunk and the evaluation vectors added (mod.rs:277-285) - restated here literally with the oracle's NTT and vector
+    addition; the device folds the coefficients first (remainder mod X^|D| - 1) and transforms once: same field elements."""
+    from snarkvm_amd import fft
+
+    D = 1 << lg
+    coeffs = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 8100 + n))
+    coeffs[-1, :] = 0  # a trailing zero coefficient: `degree()` is taken after trimming
+    coeffs[-1, 0] = 0
+    dom = fft.EvaluationDomain.new(D)
+    got = fft.evaluate_over_domain(coeffs, dom).evaluations
+    trimmed = coeffs[:-1]
+    if trimmed.shape[0] > D:
+        acc = np.zeros((D, 4), dtype=np.uint64)
+        for lo in range(0, trimmed.shape[0], D):
+            chunk = np.zeros((D, 4), dtype=np.uint64)
+            part = trimmed[lo : lo + D]
+            chunk[: part.shape[0]] = part
+            acc = oracle.fr_vec_op("add", acc, oracle.ntt(chunk))
+        want = acc
+    else:
+        pad = np.zeros((D, 4), dtype=np.uint64)
+        pad[: trimmed.shape[0]] = trimmed
+        want = oracle.ntt(pad)
+    assert np.array_equal(got, want)

@@ -112,3 +112,61 @@ def test_g2_uncompressed_on_device(golden):
     assert len(serialize.g2_deserialize(bytes(off))) == 1
     with pytest.raises(serialize.SerializationError):
         serialize.g2_deserialize(bytes(off), validate=True)
+
+
+def test_g2_compressed_on_device(golden):
+    """Compressed G2 points (96 B) through the device decoder / encoder: `Fp2::sqrt` + the sign rule of fp2.rs:240-250 on the
+    device against the Python oracle - the real `beta-h.usrs` point, generator multiples, their negatives (both sign flags),
+    infinity, and every decode error (both flag bits, x >= q, an x with no point on the curve, a point outside the subgroup)."""
+    from tests.test_gpu_parity import _g2_bases
+
+    raw = bytes(golden["beta_h_g2"])
+    beta_h = serialize.g2_deserialize(raw, validate=True)
+    pts = np.concatenate([beta_h, _g2_bases(golden, 30)])
+    neg = pts.copy()
+    ints = util.g2_affine_to_ints(pts)
+    q = pyref.Q_MOD
+    neg_ints = [(x, ((-y[0]) % q, (-y[1]) % q)) for x, y in ints]
+    neg = util.g2_affine_from_ints(neg_ints)
+    both = np.concatenate([pts, neg])
+    both_ints = ints + neg_ints
+    enc = serialize.g2_serialize(both, compressed=True)
+    assert len(enc) == 96 * len(both_ints)
+    for i, p in enumerate(both_ints):
+        assert enc[96 * i : 96 * i + 96] == pyref.g2_serialize_compressed(p), i
+    assert {enc[96 * i + 95] >> 7 for i in range(len(both_ints))} == {0, 1}
+    back = serialize.g2_deserialize(enc, validate=True, compressed=True)
+    assert util.g2_affine_to_ints(back) == both_ints
+    # infinity
+    inf = serialize.g2_deserialize(pyref.g2_serialize_compressed(None), compressed=True)
+    assert inf[0]["infinity"] == 1 and util.g2_affine_to_ints(inf) == [None]
+    both[2]["infinity"] = 1
+    e2 = serialize.g2_serialize(both[2:3], compressed=True)
+    assert e2 == pyref.g2_serialize_compressed(None)
+    # errors
+    bad = bytearray(enc[:96])
+    bad[95] |= 0xC0
+    with pytest.raises(serialize.SerializationError):
+        serialize.g2_deserialize(bytes(bad), compressed=True)
+    big = bytearray(enc[:96])
+    big[:48] = (q + 5).to_bytes(48, "little")
+    with pytest.raises(serialize.SerializationError):
+        serialize.g2_deserialize(bytes(big), compressed=True)
+    # an x coordinate whose x^3 + b' has no square root (found with the oracle)
+    x = (3, 1)
+    while pyref.fq2_sqrt(pyref.fq2_add(pyref.fq2_mul(pyref.fq2_mul(x, x), x), pyref.G2_B)) is not None:
+        x = (x[0] + 1, 1)
+    with pytest.raises(serialize.SerializationError):
+        serialize.g2_deserialize(x[0].to_bytes(48, "little") + x[1].to_bytes(48, "little"), compressed=True)
+    # on the curve but outside the prime-order subgroup: accepted unchecked, rejected with validation
+    x = (7, 2)
+    while True:
+        y = pyref.fq2_sqrt(pyref.fq2_add(pyref.fq2_mul(pyref.fq2_mul(x, x), x), pyref.G2_B))
+        if y is not None and pyref.g2_mul((x, y), pyref.R_MOD) is not None:
+            break
+        x = (x[0] + 1, 2)
+    off = pyref.g2_serialize_compressed((x, y))
+    got = serialize.g2_deserialize(off, compressed=True)
+    assert util.g2_affine_to_ints(got) == [pyref.g2_deserialize_compressed(off)]
+    with pytest.raises(serialize.SerializationError):
+        serialize.g2_deserialize(off, compressed=True, validate=True)

@@ -85,3 +85,43 @@ def test_g2_beta_h_bytes_decode(golden):
     assert p is not None and pyref.g2_is_on_curve(p)
     assert pyref.g2_serialize(p) == raw
     assert pyref.g2_deserialize(pyref.g2_serialize(None)) is None
+
+
+def test_fq2_sqrt_and_compressed_g2_oracle(golden):
+    """The Python oracle of the compressed G2 encoding, pinned on reference-held data: `Fp2::sqrt` (fp2.rs:208-230) returns a
+    root of every square and None for non-squares; compress -> decompress is the identity on the real `beta-h.usrs` point, on
+    the G2 generator's multiples and on their negatives (both values of the sign flag)."""
+    import random
+
+    rnd = random.Random(5)
+    q = pyref.Q_MOD
+    for _ in range(12):
+        a = (rnd.randrange(q), rnd.randrange(q))
+        sq = pyref.fq2_mul(a, a)
+        r = pyref.fq2_sqrt(sq)
+        assert r is not None and pyref.fq2_mul(r, r) == sq
+    assert pyref.fq2_sqrt((4, 0)) in ((2, 0), (q - 2, 0))
+    nonsquares = 0
+    for _ in range(24):
+        a = (rnd.randrange(q), rnd.randrange(1, q))
+        r = pyref.fq2_sqrt(a)
+        if r is None:
+            nonsquares += 1
+        else:
+            assert pyref.fq2_mul(r, r) == a
+    assert 4 <= nonsquares <= 20  # about half of Fq2 are non-squares
+    p = pyref.g2_deserialize(bytes(golden["beta_h_g2"]), validate=True)
+    pts = [p, pyref.g2_mul(p, 2), pyref.g2_mul(p, 12345)]
+    pts += [(x, ((-y[0]) % q, (-y[1]) % q)) for x, y in pts]
+    flags = set()
+    for pt in pts:
+        enc = pyref.g2_serialize_compressed(pt)
+        assert len(enc) == 96
+        flags.add(enc[95] >> 7)
+        assert pyref.g2_deserialize_compressed(enc, validate=True) == pt
+    assert flags == {0, 1}
+    assert pyref.g2_deserialize_compressed(pyref.g2_serialize_compressed(None)) is None
+    bad = bytearray(pyref.g2_serialize_compressed(p))
+    bad[95] |= 0xC0
+    with pytest.raises(pyref.SerializationError):
+        pyref.g2_deserialize_compressed(bytes(bad))

@@ -57,6 +57,46 @@ __global__ void __launch_bounds__(256, MINW) k_point(uint32_t* out, int iters, i
     out[tid] = x;
 }
 
+// i-cache experiment for the latency-bound tails: the same dependent chain of XYZZ additions executed by ONE wave, either
+// through one inlined call site inside a loop (44 KB of straight-line code, warm after the first trip) or through SITES distinct
+// inlined sites per trip (SITES x 44 KB: every addition streams cold code), or through one out-of-line function.
+__device__ __noinline__ g1_xyzz_t add_outlined(g1_xyzz_t a, const g1_xyzz_t b) {
+    a.add(b);
+    return a;
+}
+template <int SITES>
+__global__ void __launch_bounds__(64) k_sites(uint32_t* out, int iters, int mode) {
+    const uint32_t tid = threadIdx.x;
+    g1_xyzz_t acc = {seed_fq(tid + 11), seed_fq(tid + 13), seed_fq(tid + 17), seed_fq(tid + 19)};
+    g1_xyzz_t q = acc;
+    q.x = q.x + seed_fq(tid * 3 + 1);
+    for (int it = 0; it < iters; it++) {
+        if (mode == 1) {
+            acc = add_outlined(acc, q);
+        } else {
+#define ADD_SITE acc.add(q); asm volatile("" ::: "memory");
+            ADD_SITE
+            if (SITES >= 2) { ADD_SITE }
+            if (SITES >= 4) { ADD_SITE ADD_SITE }
+            if (SITES >= 8) { ADD_SITE ADD_SITE ADD_SITE ADD_SITE }
+        }
+    }
+    uint32_t x = 0;
+    for (int i = 0; i < 13; i++) x ^= acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+    out[tid] = x;
+}
+template <class K>
+static double time_single(K kern, int iters, int mode, uint32_t* d_out, hipEvent_t e0, hipEvent_t e1) {
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, d_out, 2, mode);
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, d_out, iters, mode);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3;
+}
+
 template <class K>
 static double run(K kern, int blocks, int iters, int op, uint32_t* d_out, hipEvent_t e0, hipEvent_t e1) {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d_out, 4, op);  // warm-up
@@ -95,5 +135,8 @@ int main() {
         hipLaunchKernelGGL((k_point<1, OP>), dim3(1), dim3(64), 0, 0, d_out, it, OP); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); \
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); printf("single wave, dependent chain: %-24s %.2f us per operation\n", pnames[OP], ms * 1e3 / it); }
     LAT(0) LAT(1) LAT(2)
+    printf("single wave, XYZZ additions, code locality: 1 inlined site in a loop %.2f us/add | 2 sites %.2f | 4 sites %.2f | 8 sites %.2f | one out-of-line function %.2f\n",
+           time_single(k_sites<1>, 64, 0, d_out, e0, e1) / 64, time_single(k_sites<2>, 32, 0, d_out, e0, e1) / 64, time_single(k_sites<4>, 16, 0, d_out, e0, e1) / 64,
+           time_single(k_sites<8>, 8, 0, d_out, e0, e1) / 64, time_single(k_sites<1>, 64, 1, d_out, e0, e1) / 64);
     return 0;
 }
