@@ -185,38 +185,9 @@ static inline size_t scan_tmp_elems(size_t n) {
     }
     return tot + 8;
 }
-// Small inputs (the bucket tables of a latency-bound MSM): one workgroup, one launch instead of three.
-static constexpr size_t SCAN_SMALL_MAX = (size_t)1 << 16;
-static __global__ void __launch_bounds__(1024) scan_small_kernel(const uint32_t* in, uint32_t* out, uint32_t n) {
-    __shared__ uint32_t wave_tot[16];
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += in[i];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d);
-        if (lane >= (uint32_t)d) inc += t;
-    }
-    if (lane == 63) wave_tot[wv] = inc;
-    __syncthreads();
-    uint32_t run = inc - s;
-    for (uint32_t k = 0; k < wv; k++) run += wave_tot[k];
-    for (uint32_t i = lo; i < hi; i++) {  // in place is fine: element i is read before it is written, by this thread only
-        const uint32_t v = in[i];
-        out[i] = run;
-        run += v;
-    }
-}
 // out may alias in
 static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp) {
     if (n == 0) return;
-    if (n <= SCAN_SMALL_MAX) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (uint32_t)n);
-        return;
-    }
     const size_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, tmp, n);
     if (blocks > 1) {

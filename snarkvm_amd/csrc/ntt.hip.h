@@ -128,7 +128,8 @@ __device__ __forceinline__ fr_t tw_lookup(const fr_mem_t* lo, const fr_mem_t* hi
 // ------------------------------------------------------------------------------------------
 struct ntt_lds_t {
     uint32_t* data;  // E elements of 9 limbs each (stride 9 words is coprime to the bank count; the limb offsets are immediates)
-    uint32_t* tw;    // 9 planes of NTT_LOCAL limbs (w_512 powers, internal form)
+    uint32_t* tw;    // 9 planes of NL = 2^(a-1) limbs: the powers of this pass' own root w_(2^a) (internal form)
+    int NL;
     int E;
     __device__ __forceinline__ fr_t get(int e) const {
         fr_t x;
@@ -143,7 +144,7 @@ struct ntt_lds_t {
     __device__ __forceinline__ fr_t twiddle(int idx) const {
         fr_t x;
 #pragma unroll
-        for (int l = 0; l < 9; l++) x.v[l] = tw[l * NTT_LOCAL + idx];
+        for (int l = 0; l < 9; l++) x.v[l] = tw[l * NL + idx];
         return x;
     }
 };
@@ -186,7 +187,7 @@ __device__ __forceinline__ void dif_group(fr_t* x, int s, int a, int lo, const n
             if (m & bit) continue;
             // pos = row mod half, half = 2^(a - 1 - (s + t)): the group-local bits below `bit`, then `lo`
             const int pos = ((m & (bit - 1)) << lo_bits) | lo;
-            const int tw_idx = (pos << (s + t)) << (NTT_MAX_RADIX_LG - a);
+            const int tw_idx = pos << (s + t);  // exponent of w_(2^a)
             lazy_butterfly(x[m], x[m | bit], s + t, tw_idx, L);
         }
     }
@@ -198,6 +199,7 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, n
     ntt_lds_t L;
     L.data = lds32;
     L.tw = lds32 + 9 * E;
+    L.NL = p.a ? (1 << (p.a - 1)) : 1;
     L.E = E;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const size_t tile = blockIdx.x;
@@ -221,10 +223,10 @@ static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, n
         in_col_stride = (size_t)1 << (p.lg_n - p.a1);
     }
     // local twiddles -> LDS planes
-    for (int i = tid; i < NTT_LOCAL; i += nthr) {
-        const fr_t w = fr_t::load(&tb.local[p.dir][i]);
+    for (int i = tid; i < L.NL; i += nthr) {  // w_(2^a)^i = w_512^(i << (9 - a))
+        const fr_t w = fr_t::load(&tb.local[p.dir][i << (NTT_MAX_RADIX_LG - p.a)]);
 #pragma unroll
-        for (int l = 0; l < 9; l++) L.tw[l * NTT_LOCAL + i] = w.v[l];
+        for (int l = 0; l < 9; l++) L.tw[l * L.NL + i] = w.v[l];
     }
     __syncthreads();
 
@@ -508,7 +510,7 @@ static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const nt
         int threads = (int)(E / 4);  // one radix-4 group per thread
         if (threads < 64) threads = 64;
         if (threads > 512) threads = 512;
-        const size_t shmem = (9 * E + 9 * NTT_LOCAL) * sizeof(uint32_t);
+        const size_t shmem = (9 * E + 9 * ((size_t)1 << (p.a ? p.a - 1 : 0))) * sizeof(uint32_t);  // a [2^8 x 8] tile + its twiddles: 78 KB, two workgroups per CU
         hipLaunchKernelGGL(ntt_pass_kernel_v2, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
     }
 }

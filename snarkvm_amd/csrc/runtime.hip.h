@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -821,20 +822,30 @@ static int batch_lanes(size_t npoints) {
     return l < 1 ? 1 : (l > device_t::LANES ? device_t::LANES : l);
 }
 static constexpr size_t MSM_SPLIT_MIN = (size_t)1 << 18;  // pairs per device below which a point-range split costs more than it saves
-static constexpr size_t MSM_CHUNK = (size_t)1 << 21;      // pairs per upload / compute chunk of an MSM whose bases arrive from the host
+static size_t msm_chunk_pairs() {  // pairs per upload / compute chunk of an MSM whose bases arrive from the host
+    static const int lg = getenv("SNARKVM_HIP_MSM_CHUNK_LG") ? atoi(getenv("SNARKVM_HIP_MSM_CHUNK_LG")) : 21;
+    return (size_t)1 << (lg < 16 ? 16 : (lg > 30 ? 30 : lg));
+}
+static double host_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 // The reference's FFI MSM (host bases, host scalars, no registration): G1: F = fq_t (stride >= 104), G2: F = fq2_t (>= 200).
 // A big call is cut into point-range chunks that are dealt round-robin to the devices (the reference's per-GPU slices,
-// snarkvm.cu:254-270) and, on each device, to two lanes in turn: while one lane's chunk is converted, sorted and accumulated,
-// the host is already copying the next chunk into the other lane's staging buffers - the upload (PCIe, ~2.4 ns per pair)
-// hides behind the compute (~2.4 ns per pair without precomputed tables) instead of preceding it.  Every chunk leaves only
-// its bit-plane sums; they are added on the host before the one Horner chain.
+// snarkvm.cu:254-270) and, on each device, to a ring of up to three lanes: an uploader thread copies chunk after chunk into
+// the lanes' staging buffers without a pause while the calling thread converts, sorts and accumulates the chunks that have
+// arrived - the upload (PCIe, ~2.4 ns per pair) is the critical path and the compute (~2.4 ns per pair without precomputed
+// tables) hides behind it.  Every chunk leaves only its bit-plane sums; they are added on the host before the one Horner chain.
 template <class F>
 static void msm_host_chunked(void* out, const void* points, size_t npoints, const void* scalars, size_t stride) {
     const size_t min_stride = 2 * sizeof(typename F::mem_t) + 8;
     if (stride < min_stride || (stride & 7)) throw hip_failure{hipErrorInvalidValue, "msm: bad ffi_affine_sz for this curve", __LINE__};
     const int nd = g_rt.ndev();
-    size_t nchunks = npoints < 2 * MSM_SPLIT_MIN ? 1 : (npoints + MSM_CHUNK - 1) / MSM_CHUNK;
+    static const int trace = getenv("SNARKVM_HIP_TRACE") ? atoi(getenv("SNARKVM_HIP_TRACE")) : 0;
+    const double t_begin = host_now_ms();
+    size_t nchunks = npoints < 2 * MSM_SPLIT_MIN ? 1 : (npoints + msm_chunk_pairs() - 1) / msm_chunk_pairs();
     if (nchunks == 1 && nd > 1 && npoints >= 2 * MSM_SPLIT_MIN) nchunks = 2;
     const int ndu = (int)(nchunks < (size_t)nd ? nchunks : (size_t)nd);
     std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
@@ -849,36 +860,131 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
         std::vector<size_t> mine;
         for (size_t i = (dev < 0 ? 0 : (size_t)dev); i < nchunks; i += (size_t)ndu) mine.push_back(i);
         lane_guard lg;
-        lg.acquire(dev, mine.size() > 1 ? 2 : 1);
+        lg.acquire(dev, mine.size() > 2 ? 3 : (int)mine.size());
         const int L = (int)lg.lanes.size();
+        const int phys = lg.lanes[0]->dev->physical;
         std::vector<msm_pending_t> pend(mine.size());
-        for (int l = 0; l < L; l++) {
-            lg.lanes[l]->begin_call();
-            lg.lanes[l]->pin.ensure(slot * ((mine.size() + L - 1) / L));
-        }
+        size_t max_cnt = 0;
         for (size_t j = 0; j < mine.size(); j++) {
-            const size_t lo = npoints * mine[j] / nchunks, hi = npoints * (mine[j] + 1) / nchunks, cnt = hi - lo;
-            lane_t& c = *lg.lanes[j % L];
-            const bool prof = nchunks == 1;
-            const size_t aff_bytes = (cnt * sizeof(aff_mem_t<F>) + 255) & ~(size_t)255;
-            c.bases_tmp.ensure(aff_bytes + cnt * stride);
-            c.scalars_tmp.ensure(cnt * 32);
-            uint8_t* raw = c.bases_tmp.template as<uint8_t>() + aff_bytes;
-            if (prof) c.phase_begin("msm_h2d");
-            HIP_TRY(hipMemcpyAsync(raw, (const uint8_t*)points + lo * stride, cnt * stride, hipMemcpyHostToDevice, c.stream));
-            HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, c.stream));
-            if (prof) c.phase_end();
-            if (prof) c.phase_begin("msm_convert_bases");
-            convert_bases<F>(c, raw, stride, cnt, c.bases_tmp.template as<aff_mem_t<F>>());
-            if (prof) c.phase_end();
-            pend[j] = msm_run<F>(c, c.bases_tmp.template as<aff_mem_t<F>>(), c.scalars_tmp.template as<uint4>(), cnt, c.pin.template as<uint8_t>() + slot * (j / L), 0,
-                                 nullptr, ~(size_t)0, 0, 1, 0, prof, 0);
+            const size_t cnt = npoints * (mine[j] + 1) / nchunks - npoints * mine[j] / nchunks;
+            max_cnt = cnt > max_cnt ? cnt : max_cnt;
         }
-        for (int l = 0; l < L; l++) HIP_TRY(hipStreamSynchronize(lg.lanes[l]->stream));
+        const size_t aff_bytes = (max_cnt * sizeof(aff_mem_t<F>) + 255) & ~(size_t)255;
+        for (int l = 0; l < L; l++) {
+            lane_t& c = *lg.lanes[l];
+            c.begin_call();
+            c.pin.ensure(slot * ((mine.size() + L - 1) / L));
+            c.bases_tmp.ensure(aff_bytes + max_cnt * stride);
+            c.scalars_tmp.ensure(max_cnt * 32);
+        }
+        auto chunk_lo = [&](size_t j) { return npoints * mine[j] / nchunks; };
+        auto chunk_cnt = [&](size_t j) { return npoints * (mine[j] + 1) / nchunks - npoints * mine[j] / nchunks; };
+        // upload of chunk j into its lane's staging buffers (host-blocking: the caller's memory is pageable)
+        auto upload = [&](size_t j, hipStream_t st) {
+            lane_t& c = *lg.lanes[j % L];
+            uint8_t* raw = c.bases_tmp.template as<uint8_t>() + aff_bytes;
+            HIP_TRY(hipMemcpyAsync(raw, (const uint8_t*)points + chunk_lo(j) * stride, chunk_cnt(j) * stride, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + chunk_lo(j) * 32, chunk_cnt(j) * 32, hipMemcpyHostToDevice, st));
+        };
+        auto compute = [&](size_t j, bool prof) {
+            lane_t& c = *lg.lanes[j % L];
+            uint8_t* raw = c.bases_tmp.template as<uint8_t>() + aff_bytes;
+            if (prof) c.phase_begin("msm_convert_bases");
+            convert_bases<F>(c, raw, stride, chunk_cnt(j), c.bases_tmp.template as<aff_mem_t<F>>());
+            if (prof) c.phase_end();
+            pend[j] = msm_run<F>(c, c.bases_tmp.template as<aff_mem_t<F>>(), c.scalars_tmp.template as<uint4>(), chunk_cnt(j), c.pin.template as<uint8_t>() + slot * (j / L),
+                                 0, nullptr, ~(size_t)0, 0, 1, 0, prof, 0);
+        };
+        if (mine.size() == 1) {
+            lane_t& c = *lg.lanes[0];
+            c.phase_begin("msm_h2d");
+            upload(0, c.stream);
+            c.phase_end();
+            compute(0, true);
+        } else {
+            // A dedicated uploader thread keeps PCIe busy back to back (the compute side blocks in the read-back that sizes the
+            // reduce rounds of every chunk): chunk j + 1 .. j + L - 1 are copied into the other lanes' staging buffers while
+            // chunk j is converted, sorted and accumulated.  up[j]: "chunk j is on the device" (event on the lane's second
+            // stream); used[j]: "the MSM of chunk j has consumed its staging buffers" (event on the lane's stream).
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<char> uploaded(mine.size(), 0), enqueued(mine.size(), 0);
+            std::vector<hipEvent_t> up(mine.size()), used(mine.size());
+            for (size_t j = 0; j < mine.size(); j++) {
+                up[j] = lg.lanes[j % L]->new_event();
+                used[j] = lg.lanes[j % L]->new_event();
+            }
+            std::exception_ptr up_err;
+            std::thread uploader([&] {
+                try {
+                    HIP_TRY(hipSetDevice(phys));
+                    for (size_t j = 0; j < mine.size(); j++) {
+                        lane_t& c = *lg.lanes[j % L];
+                        if (j >= (size_t)L) {  // the lane's previous chunk must have been consumed on the GPU
+                            {
+                                std::unique_lock<std::mutex> lk(mu);
+                                cv.wait(lk, [&] { return enqueued[j - L] != 0; });
+                            }
+                            if (enqueued[j - L] == 2) break;  // the compute side failed
+                            HIP_TRY(hipEventSynchronize(used[j - L]));
+                        }
+                        const double t0 = host_now_ms();
+                        upload(j, c.alt);
+                        HIP_TRY(hipEventRecord(up[j], c.alt));
+                        if (trace) fprintf(stderr, "[snarkvm_hip] chunk %zu (%zu pairs) dev %d lane %d: uploaded t+%.2f .. t+%.2f ms\n", mine[j], chunk_cnt(j), c.dev->logical, c.index, t0 - t_begin, host_now_ms() - t_begin);
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            uploaded[j] = 1;
+                        }
+                        cv.notify_all();
+                    }
+                } catch (...) {
+                    up_err = std::current_exception();
+                    std::lock_guard<std::mutex> lk(mu);
+                    for (auto& u : uploaded) u = 2;
+                    cv.notify_all();
+                }
+            });
+            std::exception_ptr cp_err;
+            try {
+                for (size_t j = 0; j < mine.size(); j++) {
+                    lane_t& c = *lg.lanes[j % L];
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return uploaded[j] != 0; });
+                        if (uploaded[j] == 2) break;
+                    }
+                    HIP_TRY(hipStreamWaitEvent(c.stream, up[j], 0));
+                    const double t0 = host_now_ms();
+                    compute(j, false);
+                    HIP_TRY(hipEventRecord(used[j], c.stream));
+                    if (trace) fprintf(stderr, "[snarkvm_hip] chunk %zu: enqueued t+%.2f .. t+%.2f ms\n", mine[j], t0 - t_begin, host_now_ms() - t_begin);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        enqueued[j] = 1;
+                    }
+                    cv.notify_all();
+                }
+            } catch (...) {
+                cp_err = std::current_exception();
+                std::lock_guard<std::mutex> lk(mu);
+                for (auto& e : enqueued) e = 2;
+                cv.notify_all();
+            }
+            uploader.join();
+            if (cp_err) std::rethrow_exception(cp_err);
+            if (up_err) std::rethrow_exception(up_err);
+        }
+        for (int l = 0; l < L; l++) {
+            HIP_TRY(hipStreamSynchronize(lg.lanes[l]->alt));
+            HIP_TRY(hipStreamSynchronize(lg.lanes[l]->stream));
+        }
+        const double t_sync = host_now_ms();
         {
             std::lock_guard<std::mutex> lk(acc_mu);
             for (auto& pd : pend) msm_collect<F>(*acc, pd);
         }
+        if (trace) fprintf(stderr, "[snarkvm_hip] all chunks done at t+%.2f ms, planes collected in %.2f ms\n", t_sync - t_begin, host_now_ms() - t_sync);
         for (int l = 0; l < L; l++) lg.lanes[l]->end_call();
     });
     acc->finish(out);
