@@ -183,42 +183,79 @@ static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, s
                                         int scalars_montgomery, int window_bits) {
     const size_t n = n0 + n1;
     const int nd = g_rt.ndev();
-    int parts = (int)(n / MSM_SPLIT_MIN);
-    if (parts > nd) parts = nd;
+    static const int trace = getenv("SNARKVM_HIP_TRACE") ? atoi(getenv("SNARKVM_HIP_TRACE")) : 0;
+    const double t_begin = host_now_ms();
+    // one part per device once every part keeps >= MSM_SPLIT_MIN pairs; big calls are cut further into scalar chunks whose
+    // upload (32 B per pair over PCIe) hides behind the previous chunk's accumulation (lane_ring_run)
+    size_t parts = n / MSM_SPLIT_MIN;
+    if (parts > (size_t)nd) parts = (size_t)nd;
     if (parts < 1) parts = 1;
+    const size_t chunk = msm_scalar_chunk_pairs();
+    if (n >= 2 * chunk && (n + chunk - 1) / chunk > parts) parts = (n + chunk - 1) / chunk;
+    const int ndu = (int)(parts < (size_t)nd ? parts : (size_t)nd);
     std::unique_ptr<msm_accum_t<fq_t>> acc(new msm_accum_t<fq_t>());
     std::mutex acc_mu;
     std::vector<int> devs;
-    if (parts == 1) {
+    if (ndu == 1) {
         devs.push_back(-1);  // any device with a free lane
     } else {
-        for (int d = 0; d < parts; d++) devs.push_back(d);
+        for (int d = 0; d < ndu; d++) devs.push_back(d);
     }
+    const size_t slot = msm_plane_bytes<fq_t>();
     for_each_device(devs, [&](int dev) {
-        const size_t part = parts == 1 ? 0 : (size_t)dev;
-        const size_t lo = n * part / parts, hi = n * (part + 1) / parts, cnt = hi - lo;
-        lane_guard lg(dev);
-        lane_t& c = lg.c();
-        c.begin_call();
-        const g1_aff_mem_t* base = h->d[c.dev->logical];
-        // slice [lo, hi) of the concatenation (range 0 | range 1)
-        const size_t a0 = lo < n0 ? lo : n0, a1 = hi < n0 ? hi : n0;  // part inside range 0
-        const size_t m0 = a1 - a0;
-        const g1_aff_mem_t* b0 = base + off0 + a0;
-        const g1_aff_mem_t* b1 = base + off1 + (lo > n0 ? lo - n0 : 0);
-        c.scalars_tmp.ensure(cnt * 32 + 32);
-        c.phase_begin("msm_h2d");
-        if (cnt) HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, c.stream));
-        c.phase_end();
-        c.pin.ensure(msm_plane_bytes<fq_t>());
-        const msm_pending_t pd = msm_run<fq_t>(c, m0 ? b0 : b1, c.scalars_tmp.as<uint4>(), cnt, c.pin.p, window_bits, b1, m0 ? m0 : ~(size_t)0,
-                                               scalars_montgomery, h->tables, h->n, parts == 1, h->table_bits);
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        std::vector<size_t> mine;
+        for (size_t i = (dev < 0 ? 0 : (size_t)dev); i < parts; i += (size_t)ndu) mine.push_back(i);
+        lane_guard lg;
+        lg.acquire(dev, mine.size() > 2 ? 3 : (int)mine.size());
+        const size_t L = lg.lanes.size();
+        std::vector<msm_pending_t> pend(mine.size());
+        size_t max_cnt = 0;
+        for (size_t j = 0; j < mine.size(); j++) {
+            const size_t cnt = n * (mine[j] + 1) / parts - n * mine[j] / parts;
+            max_cnt = cnt > max_cnt ? cnt : max_cnt;
+        }
+        for (size_t l = 0; l < L; l++) {
+            lane_t& c = *lg.lanes[l];
+            c.begin_call();
+            c.scalars_tmp.ensure(max_cnt * 32 + 32);
+            c.pin.ensure(slot * ((mine.size() + L - 1) / L));
+        }
+        const g1_aff_mem_t* base = h->d[lg.lanes[0]->dev->logical];
+        auto upload = [&](size_t j, hipStream_t st) {
+            lane_t& c = *lg.lanes[j % L];
+            const size_t lo = n * mine[j] / parts, hi = n * (mine[j] + 1) / parts;
+            if (hi > lo) HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, st));
+        };
+        auto compute = [&](size_t j, bool prof) {
+            lane_t& c = *lg.lanes[j % L];
+            // slice [lo, hi) of the concatenation (range 0 | range 1)
+            const size_t lo = n * mine[j] / parts, hi = n * (mine[j] + 1) / parts;
+            const size_t a0 = lo < n0 ? lo : n0, a1 = hi < n0 ? hi : n0;  // part inside range 0
+            const size_t m0 = a1 - a0;
+            const g1_aff_mem_t* b0 = base + off0 + a0;
+            const g1_aff_mem_t* b1 = base + off1 + (lo > n0 ? lo - n0 : 0);
+            pend[j] = msm_run<fq_t>(c, m0 ? b0 : b1, c.scalars_tmp.as<uint4>(), hi - lo, c.pin.as<uint8_t>() + slot * (j / L), window_bits, b1,
+                                    m0 ? m0 : ~(size_t)0, scalars_montgomery, h->tables, h->n, prof, h->table_bits);
+        };
+        if (mine.size() == 1) {
+            lane_t& c = *lg.lanes[0];
+            c.phase_begin("msm_h2d");
+            upload(0, c.stream);
+            c.phase_end();
+            compute(0, parts == 1);
+        } else {
+            lane_ring_run(lg, mine.size(), upload, [&](size_t j) { compute(j, false); }, trace, t_begin);
+        }
+        for (size_t l = 0; l < L; l++) {
+            HIP_TRY(hipStreamSynchronize(lg.lanes[l]->alt));
+            HIP_TRY(hipStreamSynchronize(lg.lanes[l]->stream));
+        }
         {
             std::lock_guard<std::mutex> lk(acc_mu);
-            msm_collect<fq_t>(*acc, pd);
+            for (auto& pd : pend) msm_collect<fq_t>(*acc, pd);
         }
-        c.end_call();
+        if (trace) fprintf(stderr, "[snarkvm_hip] registered MSM, host scalars: %zu chunk(s) done at t+%.2f ms\n", mine.size(), host_now_ms() - t_begin);
+        for (size_t l = 0; l < L; l++) lg.lanes[l]->end_call();
     });
     acc->finish(out);
 }

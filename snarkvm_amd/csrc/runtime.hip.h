@@ -826,10 +826,94 @@ static size_t msm_chunk_pairs() {  // pairs per upload / compute chunk of an MSM
     static const int lg = getenv("SNARKVM_HIP_MSM_CHUNK_LG") ? atoi(getenv("SNARKVM_HIP_MSM_CHUNK_LG")) : 21;
     return (size_t)1 << (lg < 16 ? 16 : (lg > 30 ? 30 : lg));
 }
+// pairs per scalar chunk of a host-scalar MSM over registered bases (SNARKVM_HIP_SCALAR_CHUNK_LG, default 2^22: the tail of
+// a chunk costs < 1 ms, its upload 2.4 ms)
+static size_t msm_scalar_chunk_pairs() {
+    static const int lg = getenv("SNARKVM_HIP_SCALAR_CHUNK_LG") ? atoi(getenv("SNARKVM_HIP_SCALAR_CHUNK_LG")) : 22;
+    return (size_t)1 << (lg < 18 ? 18 : lg > 30 ? 30 : lg);
+}
 static double host_now_ms() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// `count` chunks of one call on the lanes of `lg` (a ring: chunk j uses lane j mod L).  A dedicated uploader thread runs
+// upload(j, stream) - host-blocking copies of pageable caller memory - chunk after chunk, so PCIe stays busy back to back
+// while the calling thread runs compute(j) (kernel launches plus the read-back that sizes the reduce rounds) for the chunks
+// that have arrived.  up[j]: "chunk j is on the device" (event on the lane's second stream); used[j]: "the work of chunk j
+// has consumed the lane's staging buffers" (event on the lane's stream).
+template <class Upload, class Compute>
+static void lane_ring_run(lane_guard& lg, size_t count, Upload&& upload, Compute&& compute, int trace, double t_begin) {
+    const size_t L = lg.lanes.size();
+    const int phys = lg.lanes[0]->dev->physical;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> uploaded(count, 0), enqueued(count, 0);
+    std::vector<hipEvent_t> up(count), used(count);
+    for (size_t j = 0; j < count; j++) {
+        up[j] = lg.lanes[j % L]->new_event();
+        used[j] = lg.lanes[j % L]->new_event();
+    }
+    std::exception_ptr up_err, cp_err;
+    std::thread uploader([&] {
+        try {
+            HIP_TRY(hipSetDevice(phys));
+            for (size_t j = 0; j < count; j++) {
+                lane_t& c = *lg.lanes[j % L];
+                if (j >= L) {  // the lane's previous chunk must have been consumed on the GPU
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return enqueued[j - L] != 0; });
+                    }
+                    if (enqueued[j - L] == 2) break;  // the compute side failed
+                    HIP_TRY(hipEventSynchronize(used[j - L]));
+                }
+                const double t0 = host_now_ms();
+                upload(j, c.alt);
+                HIP_TRY(hipEventRecord(up[j], c.alt));
+                if (trace) fprintf(stderr, "[snarkvm_hip] chunk %zu dev %d lane %d: uploaded t+%.2f .. t+%.2f ms\n", j, c.dev->logical, c.index, t0 - t_begin, host_now_ms() - t_begin);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    uploaded[j] = 1;
+                }
+                cv.notify_all();
+            }
+        } catch (...) {
+            up_err = std::current_exception();
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& u : uploaded) u = 2;
+            cv.notify_all();
+        }
+    });
+    try {
+        for (size_t j = 0; j < count; j++) {
+            lane_t& c = *lg.lanes[j % L];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return uploaded[j] != 0; });
+                if (uploaded[j] == 2) break;
+            }
+            HIP_TRY(hipStreamWaitEvent(c.stream, up[j], 0));
+            const double t0 = host_now_ms();
+            compute(j);
+            HIP_TRY(hipEventRecord(used[j], c.stream));
+            if (trace) fprintf(stderr, "[snarkvm_hip] chunk %zu: enqueued t+%.2f .. t+%.2f ms\n", j, t0 - t_begin, host_now_ms() - t_begin);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                enqueued[j] = 1;
+            }
+            cv.notify_all();
+        }
+    } catch (...) {
+        cp_err = std::current_exception();
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& e : enqueued) e = 2;
+        cv.notify_all();
+    }
+    uploader.join();
+    if (cp_err) std::rethrow_exception(cp_err);
+    if (up_err) std::rethrow_exception(up_err);
 }
 
 // The reference's FFI MSM (host bases, host scalars, no registration): G1: F = fq_t (stride >= 104), G2: F = fq2_t (>= 200).
@@ -862,7 +946,6 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
         lane_guard lg;
         lg.acquire(dev, mine.size() > 2 ? 3 : (int)mine.size());
         const int L = (int)lg.lanes.size();
-        const int phys = lg.lanes[0]->dev->physical;
         std::vector<msm_pending_t> pend(mine.size());
         size_t max_cnt = 0;
         for (size_t j = 0; j < mine.size(); j++) {
@@ -902,78 +985,7 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
             c.phase_end();
             compute(0, true);
         } else {
-            // A dedicated uploader thread keeps PCIe busy back to back (the compute side blocks in the read-back that sizes the
-            // reduce rounds of every chunk): chunk j + 1 .. j + L - 1 are copied into the other lanes' staging buffers while
-            // chunk j is converted, sorted and accumulated.  up[j]: "chunk j is on the device" (event on the lane's second
-            // stream); used[j]: "the MSM of chunk j has consumed its staging buffers" (event on the lane's stream).
-            std::mutex mu;
-            std::condition_variable cv;
-            std::vector<char> uploaded(mine.size(), 0), enqueued(mine.size(), 0);
-            std::vector<hipEvent_t> up(mine.size()), used(mine.size());
-            for (size_t j = 0; j < mine.size(); j++) {
-                up[j] = lg.lanes[j % L]->new_event();
-                used[j] = lg.lanes[j % L]->new_event();
-            }
-            std::exception_ptr up_err;
-            std::thread uploader([&] {
-                try {
-                    HIP_TRY(hipSetDevice(phys));
-                    for (size_t j = 0; j < mine.size(); j++) {
-                        lane_t& c = *lg.lanes[j % L];
-                        if (j >= (size_t)L) {  // the lane's previous chunk must have been consumed on the GPU
-                            {
-                                std::unique_lock<std::mutex> lk(mu);
-                                cv.wait(lk, [&] { return enqueued[j - L] != 0; });
-                            }
-                            if (enqueued[j - L] == 2) break;  // the compute side failed
-                            HIP_TRY(hipEventSynchronize(used[j - L]));
-                        }
-                        const double t0 = host_now_ms();
-                        upload(j, c.alt);
-                        HIP_TRY(hipEventRecord(up[j], c.alt));
-                        if (trace) fprintf(stderr, "[snarkvm_hip] chunk %zu (%zu pairs) dev %d lane %d: uploaded t+%.2f .. t+%.2f ms\n", mine[j], chunk_cnt(j), c.dev->logical, c.index, t0 - t_begin, host_now_ms() - t_begin);
-                        {
-                            std::lock_guard<std::mutex> lk(mu);
-                            uploaded[j] = 1;
-                        }
-                        cv.notify_all();
-                    }
-                } catch (...) {
-                    up_err = std::current_exception();
-                    std::lock_guard<std::mutex> lk(mu);
-                    for (auto& u : uploaded) u = 2;
-                    cv.notify_all();
-                }
-            });
-            std::exception_ptr cp_err;
-            try {
-                for (size_t j = 0; j < mine.size(); j++) {
-                    lane_t& c = *lg.lanes[j % L];
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return uploaded[j] != 0; });
-                        if (uploaded[j] == 2) break;
-                    }
-                    HIP_TRY(hipStreamWaitEvent(c.stream, up[j], 0));
-                    const double t0 = host_now_ms();
-                    compute(j, false);
-                    HIP_TRY(hipEventRecord(used[j], c.stream));
-                    if (trace) fprintf(stderr, "[snarkvm_hip] chunk %zu: enqueued t+%.2f .. t+%.2f ms\n", mine[j], t0 - t_begin, host_now_ms() - t_begin);
-                    {
-                        std::lock_guard<std::mutex> lk(mu);
-                        enqueued[j] = 1;
-                    }
-                    cv.notify_all();
-                }
-            } catch (...) {
-                cp_err = std::current_exception();
-                std::lock_guard<std::mutex> lk(mu);
-                for (auto& e : enqueued) e = 2;
-                cv.notify_all();
-            }
-            uploader.join();
-            if (cp_err) std::rethrow_exception(cp_err);
-            if (up_err) std::rethrow_exception(up_err);
+            lane_ring_run(lg, mine.size(), upload, [&](size_t j) { compute(j, false); }, trace, t_begin);
         }
         for (int l = 0; l < L; l++) {
             HIP_TRY(hipStreamSynchronize(lg.lanes[l]->alt));
