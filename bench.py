@@ -25,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps streams onto 4 hardware queues by default; the lanes of concurrent callers (proofs64: 8 caller threads
+# per rank) want one each.  Read once at HIP initialisation, so it has to be in the environment before torch touches the GPU
+# (measured on proofs64, 8 callers: 97.7 -> 104 proofs/s).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -78,7 +82,7 @@ def main():
     ap.add_argument("--cpu-lg-msm", type=int, default=23)
     ap.add_argument("--cpu-lg-ntt", type=int, default=24)
     ap.add_argument("--proofs", type=int, default=64)
-    ap.add_argument("--proof-workers", type=int, default=4, help="concurrent caller threads per rank (proofs64)")
+    ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64)")
     args = ap.parse_args()
 
     import torch

@@ -335,43 +335,132 @@ __device__ __forceinline__ fq_t shfl_xor_field(const fq_t& a, int mask) {
     return r;
 }
 __device__ __forceinline__ fq2_t shfl_xor_field(const fq2_t& a, int mask) { return {shfl_xor_field(a.c0, mask), shfl_xor_field(a.c1, mask)}; }
-// Sum of `acc` over the lanes of a workgroup of 64 or 256 threads: 6 all-lane exchange levels inside each wave, then (256
-// threads) the four wave totals through LDS and two more levels on wave 0.  The result is valid in thread 0.  `sh`: 4 points.
+template <class F>
+__device__ __forceinline__ xyzz_t<F> shfl_xor_point(const xyzz_t<F>& a, int mask) {
+    return {shfl_xor_field(a.x, mask), shfl_xor_field(a.y, mask), shfl_xor_field(a.zz, mask), shfl_xor_field(a.zzz, mask)};
+}
+// DPP quad permutation (lanes 4k .. 4k + 3 read each other's registers inside the VALU: no LDS traffic); CTRL = the four
+// source lanes, two bits each.  quad_bcast<L>: every lane of the quad reads lane L.
+template <int CTRL>
+__device__ __forceinline__ fq_t quad_perm_field(const fq_t& a) {
+    fq_t r;
+#pragma unroll
+    for (int i = 0; i < fq_t::N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], CTRL, 0xf, 0xf, true);
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ fq2_t quad_perm_field(const fq2_t& a) {
+    return {quad_perm_field<CTRL>(a.c0), quad_perm_field<CTRL>(a.c1)};
+}
+template <int L, class F>
+__device__ __forceinline__ F quad_bcast(const F& a) {
+    return quad_perm_field<L * 0x55>(a);
+}
+__device__ __forceinline__ fq_t select_field(bool c, const fq_t& a, const fq_t& b) {  // c ? a : b
+    fq_t r;
+#pragma unroll
+    for (int i = 0; i < fq_t::N; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+__device__ __forceinline__ fq2_t select_field(bool c, const fq2_t& a, const fq2_t& b) {
+    return {select_field(c, a.c0, b.c0), select_field(c, a.c1, b.c1)};
+}
+template <class F>
+__device__ __forceinline__ xyzz_t<F> select_point(bool c, const xyzz_t<F>& a, const xyzz_t<F>& b) {
+    return {select_field(c, a.x, b.x), select_field(c, a.y, b.y), select_field(c, a.zz, b.zz), select_field(c, a.zzz, b.zzz)};
+}
+
+// acc += o (add-2008-s) computed by the FOUR lanes of a DPP quad together.  Precondition: the four lanes hold bit-identical
+// (acc, o); postcondition: they hold the bit-identical sum.  A serial tail addition is latency-bound (one wave issues one
+// instruction per ~4.5 cycles whatever the other 63 lanes do: 12.8 us per addition, tools/ecbench.hip), and in a tree
+// reduction the lanes hold redundant copies anyway - so the 14 field products of the formula are dealt to the four lanes as
+// four rounds of one product each:
+//   round 1   U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1      then  P = U2 - U1 (lanes 0, 1), R = S2 - S1 (lanes 2, 3)
+//   round 2   PP = P^2    | ZZ1 ZZ2     | R^2          | ZZZ1 ZZZ2
+//   round 3   PPP = P PP  | Q = U1 PP   | ZZ3 = ZZ1 ZZ2 PP | -
+//   round 4   ZZZ3 = ZZZ1 ZZZ2 PPP | -  | R (Q - X3)   | S1 PPP            with X3 = R^2 - PPP - 2 Q
+// Operands move between the lanes as DPP quad permutations.  Infinity operands are a final select; P = +-Q (U1 == U2) in any
+// quad sends the whole wave through the plain formula (wave-uniform branch; every lane of a quad takes the same path).
+template <class F>
+__device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
+    const uint32_t r = threadIdx.x & 3;
+    const bool inf1 = acc.is_inf(), inf2 = o.is_inf();
+    F a = select_field(r < 2, select_field(r == 0, acc.x, o.x), select_field(r == 2, acc.y, o.y));
+    F b = select_field(r < 2, select_field(r == 0, o.zz, acc.zz), select_field(r == 2, o.zzz, acc.zzz));
+    const F m1 = a * b;                          // U1 | U2 | S1 | S2
+    const F t = quad_perm_field<0xB1>(m1);       // U2 | U1 | S2 | S1   (lanes swapped inside pairs)
+    const F d = select_field((r & 1) != 0, m1, t) - select_field((r & 1) != 0, t, m1);  // P | P | R | R
+    const bool same_x = !inf1 && !inf2 && r < 2 && d.is_zero();
+    if (__ballot(same_x) != 0) {
+        acc.add(o);
+        return;
+    }
+    a = select_field((r & 1) == 0, d, select_field(r == 1, acc.zz, acc.zzz));
+    b = select_field((r & 1) == 0, d, select_field(r == 1, o.zz, o.zzz));
+    const F m2 = a * b;                          // PP | ZZ1 ZZ2 | R^2 | ZZZ1 ZZZ2
+    const F pp = quad_bcast<0>(m2);
+    a = select_field(r == 1, t, select_field(r == 2, quad_bcast<1>(m2), d));
+    const F m3 = a * pp;                         // PPP | Q | ZZ3 | (unused)
+    const F ppp = quad_bcast<0>(m3), q = quad_bcast<1>(m3);
+    const F x3 = m2 - ppp - q.dbl();             // X3 on lane 2
+    a = select_field(r == 0, quad_bcast<3>(m2), select_field(r == 2, d, t));
+    b = select_field(r == 2, q - x3, ppp);
+    const F m4 = a * b;                          // ZZZ3 | (unused) | R (Q - X3) | S1 PPP
+    xyzz_t<F> res;
+    res.x = quad_bcast<2>(x3);
+    res.y = quad_bcast<2>(m4) - quad_bcast<3>(m4);
+    res.zz = quad_bcast<2>(m3);
+    res.zzz = quad_bcast<0>(m4);
+    acc = select_point(inf2, acc, select_point(inf1, o, res));
+}
+// Sum of `acc` over the lanes of a workgroup of 64, 256 or 1024 threads; the result is valid in thread 0.  Level 1 (lane
+// pairs) is a plain addition with the operands in the same order on both lanes, so that from level 2 on the four lanes of a
+// quad hold bit-identical operands and share every addition (quad_add); the wave totals go through LDS to wave 0, whose quads
+// add them pairwise and finish with the same exchange levels.  `sh`: one point per wave.
 template <class F>
 __device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh) {
-#pragma unroll 1
-    for (int off = 32; off > 0; off >>= 1) {
-        xyzz_t<F> o;
-        o.x = shfl_xor_field(acc.x, off);
-        o.y = shfl_xor_field(acc.y, off);
-        o.zz = shfl_xor_field(acc.zz, off);
-        o.zzz = shfl_xor_field(acc.zzz, off);
-        acc.add(o);  // every lane of the wave ends with the wave's sum
+    {
+        const xyzz_t<F> o = shfl_xor_point(acc, 1);
+        const bool odd = (threadIdx.x & 1) != 0;
+        xyzz_t<F> lo = select_point(odd, o, acc);
+        lo.add(select_point(odd, acc, o));
+        acc = lo;
     }
+    {
+        const xyzz_t<F> o = shfl_xor_point(acc, 2);
+        const bool hi = (threadIdx.x & 2) != 0;
+        xyzz_t<F> lo = select_point(hi, o, acc);
+        quad_add(lo, select_point(hi, acc, o));
+        acc = lo;
+    }
+#pragma unroll 1
+    for (int off = 4; off < 64; off <<= 1) quad_add(acc, shfl_xor_point(acc, off));
     if (blockDim.x == 64) return;
-    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wv = threadIdx.x >> 6, nw = blockDim.x >> 6;  // 4 or 16 waves
     if ((threadIdx.x & 63) == 0) store_xyzz<F>(&sh[wv], acc);
     __syncthreads();
     if (threadIdx.x < 64) {
-        acc = load_xyzz<F>(&sh[threadIdx.x & 3]);
+        const uint32_t pair = (threadIdx.x >> 2) & (nw / 2 - 1);  // quad -> the pair of wave totals it adds
+        acc = load_xyzz<F>(&sh[2 * pair]);
+        quad_add(acc, load_xyzz<F>(&sh[2 * pair + 1]));
 #pragma unroll 1
-        for (int off = 2; off > 0; off >>= 1) {
-            xyzz_t<F> o;
-            o.x = shfl_xor_field(acc.x, off);
-            o.y = shfl_xor_field(acc.y, off);
-            o.zz = shfl_xor_field(acc.zz, off);
-            o.zzz = shfl_xor_field(acc.zzz, off);
-            acc.add(o);
-        }
+        for (uint32_t off = 4; off < 2 * nw; off <<= 1) quad_add(acc, shfl_xor_point(acc, (int)off));
     }
 }
+// Register budget of the tail kernels: the G1 kernels need ~270 registers without a bound and would then run ONE 256-thread
+// workgroup per CU - the 384 workgroups of a 2^15-bucket fold would take two rounds on 256 CUs; two waves per SIMD (256
+// registers) put them all on the chip at once.  The Fq2 kernels keep the full file.
+template <class F>
+struct TAIL_WAVES {
+    static constexpr int value = sizeof(F) <= 64 ? 2 : 1;
+};
 // 7a. grid (2^m + 2^hb, W): workgroups [0, 2^m) of a window fold columns (fixed lo -> L_lo, slot lo), workgroups
 // [2^m, 2^m + 2^hb) fold rows (fixed hi -> H_hi, slot 2^m + hi - 1; H_0 has weight 0 and no slot).  Bucket k = w * nb + b
 // holds cnt[k] partial sums at sums[start[k] ...].  out: per window 2^(m+1) dense slots (slot 2^(m+1) - 1 is unused).
 template <class F>
-__global__ void __launch_bounds__(256) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
+__global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
                                                        const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb) {
-    __shared__ xyzz_mem_t<F> sh[4];
+    __shared__ xyzz_mem_t<F> sh[16];
     const uint32_t nlo = 1u << m, nhi = 1u << hb;
     const uint32_t w = blockIdx.y;
     const uint32_t kbase = w << (m + hb);
@@ -402,10 +491,10 @@ __global__ void __launch_bounds__(256) msm_fold_kernel(const xyzz_mem_t<F>* __re
 //   else (small windows): tw = w, N = nb, entry i = the cnt[k] partial sums of bucket k = w * nb + i.
 // planes[tw * nbits + j] = sum of the entries of tw whose weight has bit j set.
 template <class F, bool DENSE>
-__global__ void __launch_bounds__(256) msm_bitplane_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
+__global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
                                                            const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ planes, uint32_t nb,
                                                            int m, int hb) {
-    __shared__ xyzz_mem_t<F> sh[4];
+    __shared__ xyzz_mem_t<F> sh[16];
     const uint32_t j = blockIdx.x, tw = blockIdx.y, nbits = gridDim.x;
     uint32_t N;
     size_t base;

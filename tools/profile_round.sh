@@ -15,9 +15,12 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python ben
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python bench.py $ARGS0 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python bench.py $ARGS0 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU -d $OUT/sq -o s -- python bench.py $ARGS0 > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/proofs -o p -- python bench.py --workload proofs64 --proof-workers 8 > $OUT/proofs64_under_rocprof.log 2>&1
 find $OUT -name "*.db" | head
 S=$(find $OUT/stats -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1); Q=$(find $OUT/sq -name "*.db" | head -1)
 [ -n "$S" ] && python tools/rocprof_summary.py stats $S > $OUT/${TAG}_rocprofv3_kernel_stats.txt
+P=$(find $OUT/proofs -name "*.db" | head -1)
+[ -n "$P" ] && python tools/rocprof_summary.py stats $P > $OUT/${TAG}_rocprofv3_kernel_stats_proofs64.txt
 [ -n "$F" ] && python tools/rocprof_summary.py pmc $F > $OUT/${TAG}_rocprofv3_pmc_fetch.txt
 [ -n "$W" ] && python tools/rocprof_summary.py pmc $W > $OUT/${TAG}_rocprofv3_pmc_write.txt
 [ -n "$Q" ] && python tools/rocprof_summary.py pmc $Q > $OUT/${TAG}_rocprofv3_pmc_sq_counters.txt
