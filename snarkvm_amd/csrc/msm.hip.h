@@ -112,13 +112,16 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     static const int env_S = getenv("SNARKVM_HIP_S") ? atoi(getenv("SNARKVM_HIP_S")) : 0;
     static const int env_S2 = getenv("SNARKVM_HIP_S2") ? atoi(getenv("SNARKVM_HIP_S2")) : 0;
     static const int env_L = getenv("SNARKVM_HIP_L") ? atoi(getenv("SNARKVM_HIP_L")) : 0;
-    // points per accumulate thread: long segments amortise the partial-sum flushes of big MSMs; a small MSM is latency-bound
-    // (S dependent additions of ~9.4 us each, tools/ecbench.hip), so its segments shrink until the grid fills two waves per
-    // SIMD (2^17 threads - what the kernel's ~190 VGPRs allow to be resident; a wave runs at full speed up to there)
+    // points per accumulate thread: long segments amortise the partial-sum flushes of big MSMs; two resident waves per SIMD
+    // (2^17 threads) hide the base gather.  Every thread leaves one partial sum per bucket it touches and the tail pays two
+    // general additions for each, so the smallest MSMs (<= 2^20 digit entries) trade the second wave for half the partial
+    // sums (measured at 2^16: accumulate +0.03 ms, tail -0.06 ms; one wave per SIMD still keeps the multiplier ~95 % busy,
+    // tools/ecbench.hip).
     {
         const size_t E = (size_t)p.Wd * n;
         p.S = E >= ((size_t)1 << 27) ? 128 : 64;
-        while (p.S > 4 && E / p.S < ((size_t)1 << 17)) p.S >>= 1;
+        while (p.S > 16 && E / p.S < ((size_t)1 << 17)) p.S >>= 1;
+        while (p.S > 4 && E / p.S < ((size_t)1 << 16)) p.S >>= 1;
     }
     if (env_S > 0) p.S = env_S;
     p.S2 = env_S2 > 1 ? env_S2 : 8;

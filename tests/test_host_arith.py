@@ -149,7 +149,7 @@ def test_msm_planner_invariants():
             assert small["c"] <= 16 and small["wide"] == 0
         forced = _plan(1000, window_bits=bits, tables=tables, table_bits=bits)
         assert forced["c"] == bits and forced["wide"] == 1
-    assert _plan(1 << 24, tables=12, table_bits=22)["S"] == 128 and _plan(1 << 16, tables=16)["S"] == 8 and _plan(1 << 14, tables=16)["S"] == 4
+    assert _plan(1 << 24, tables=12, table_bits=22)["S"] == 128 and _plan(1 << 16, tables=16)["S"] == 16 and _plan(1 << 14, tables=16)["S"] == 4
     d = _plan(1 << 20, window_bits=13, tables=16)  # request that does not divide the table width: largest divisor below
     assert d["c"] == 8 and d["W"] == 2
 

@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "../snarkvm_amd/csrc/ec.hip.h"
+#include "../snarkvm_amd/csrc/msm.hip.h"
 
 using namespace sv;
 
@@ -97,6 +97,42 @@ static double time_single(K kern, int iters, int mode, uint32_t* d_out, hipEvent
     return ms * 1e3;
 }
 
+// the tail's building blocks: a dependent chain of quad-cooperative additions (msm.hip.h::quad_add), and whole block sums
+// (mode 0: 64 threads, 1: 256 threads) of one point per lane
+__global__ void __launch_bounds__(256, 2) k_quad(uint32_t* out, int iters, int) {
+    const uint32_t tid = threadIdx.x >> 2;  // the four lanes of a quad hold identical operands
+    g1_xyzz_t acc = {seed_fq(tid + 11), seed_fq(tid + 13), seed_fq(tid + 17), seed_fq(tid + 19)};
+    g1_xyzz_t q = acc;
+    q.x = q.x + seed_fq(tid * 3 + 1);
+    for (int it = 0; it < iters; it++) quad_add(acc, q);
+    uint32_t x = 0;
+    for (int i = 0; i < 13; i++) x ^= acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+    out[threadIdx.x] = x;
+}
+__global__ void __launch_bounds__(256, 2) k_block_sum(uint32_t* out, int iters, int) {
+    __shared__ xyzz_mem_t<fq_t> sh[16];
+    const uint32_t tid = threadIdx.x;
+    uint32_t x = 0;
+    for (int it = 0; it < iters; it++) {
+        g1_xyzz_t acc = {seed_fq(tid + 11 + it), seed_fq(tid + 13), seed_fq(tid + 17), seed_fq(tid + 19)};
+        block_sum<fq_t>(acc, sh);
+        for (int i = 0; i < 13; i++) x ^= acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+        __syncthreads();
+    }
+    out[blockIdx.x * blockDim.x + tid] = x;
+}
+template <class K>
+static double time_block(K kern, int blocks, int threads, int iters, uint32_t* d_out, hipEvent_t e0, hipEvent_t e1) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, 2, 0);
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 0);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3 / iters;
+}
+
 template <class K>
 static double run(K kern, int blocks, int iters, int op, uint32_t* d_out, hipEvent_t e0, hipEvent_t e1) {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d_out, 4, op);  // warm-up
@@ -138,5 +174,9 @@ int main() {
     printf("single wave, XYZZ additions, code locality: 1 inlined site in a loop %.2f us/add | 2 sites %.2f | 4 sites %.2f | 8 sites %.2f | one out-of-line function %.2f\n",
            time_single(k_sites<1>, 64, 0, d_out, e0, e1) / 64, time_single(k_sites<2>, 32, 0, d_out, e0, e1) / 64, time_single(k_sites<4>, 16, 0, d_out, e0, e1) / 64,
            time_single(k_sites<8>, 8, 0, d_out, e0, e1) / 64, time_single(k_sites<1>, 64, 1, d_out, e0, e1) / 64);
+    printf("single wave, quad-cooperative XYZZ addition (4 lanes share the 14 products): %.2f us per addition\n", time_block(k_quad, 1, 64, 200, d_out, e0, e1));
+    printf("block_sum (1 plain level + quad levels): 64 threads %.1f us | 256 threads %.1f us | 384 blocks x 256 threads %.1f us | 512 blocks x 256 threads %.1f us\n",
+           time_block(k_block_sum, 1, 64, 20, d_out, e0, e1), time_block(k_block_sum, 1, 256, 20, d_out, e0, e1), time_block(k_block_sum, 384, 256, 20, d_out, e0, e1),
+           time_block(k_block_sum, 512, 256, 20, d_out, e0, e1));
     return 0;
 }
