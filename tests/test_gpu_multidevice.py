@@ -126,3 +126,70 @@ print("SET_OK")
 ''' % util.ROOT
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, cwd=util.ROOT)
     assert "SET_OK" in r.stdout, r.stdout + r.stderr
+
+
+RING_SCRIPT = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import cpu as oracle
+from oracle import pyref
+from snarkvm_amd import _lib, msm, plugin, synthetic
+from snarkvm_amd.layout import G2_AFFINE
+from tests import util
+
+assert msm.num_devices() == 1
+G = util.g1_generator_affine()
+n = (1 << 19) + 4099
+bases = oracle.g1_gen_bases(G, 1, n)
+sc = synthetic.random_fr_integers(n, 4242)
+sc[5] = 0
+sc[6] = [1, 0, 0, 0]
+def closed(s, start=1):
+    return oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(s, start=start), 4)))
+def eq(got, want):
+    return util.affine_equal(oracle.g1_to_affine(got), want)
+want = closed(sc)
+# first sighting: 9 chunks of <= 2^16 pairs through the three-lane ring (uploader thread + compute thread)
+assert eq(plugin.msm(bases, sc), want), "chunk ring, uncached"
+print("uncached ok")
+# second sighting registers the range; from then on only the scalars cross PCIe, in 3 chunks of <= 2^18
+assert eq(plugin.msm(bases, sc), want), "scalar chunks 1"
+assert eq(plugin.msm(bases, sc), want), "scalar chunks 2"
+print("cached ok")
+assert eq(plugin.msm(bases[17:17 + (1 << 19)], sc[: 1 << 19]), closed(sc[: 1 << 19], start=18)), "scalar chunks, slice"
+print("slice ok")
+# explicit handle, two base ranges with the boundary inside a chunk
+rb = msm.RegisteredBases(bases, tables=16)
+out = np.zeros(1, dtype=oracle.G1_PROJECTIVE)
+n0, n1, off1 = 300001, 228000, 77  # n0 + n1 <= len(sc)
+_lib.check(_lib.lib().snarkvm_hip_msm_registered_ex(ctypes.c_void_p(out.ctypes.data), rb._h, ctypes.c_size_t(3), ctypes.c_size_t(n0), ctypes.c_size_t(off1),
+                                                   ctypes.c_size_t(n1), ctypes.c_void_p(sc.ctypes.data), 0, 0, 0))
+k = (util.weighted_sum_mod_r(sc[:n0], start=4) + util.weighted_sum_mod_r(sc[n0:n0 + n1], start=off1 + 1)) %% pyref.R_MOD
+assert eq(out, oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(k, 4)))), "two ranges over scalar chunks"
+print("two ranges ok")
+rb.close()
+# G2 through the same ring (the reference's symbol shape, host buffers)
+raw = open(%r, "rb").read()
+g2 = np.zeros(1, dtype=G2_AFFINE)
+_lib.check(_lib.lib().snarkvm_hip_g2_deserialize(ctypes.c_void_p(g2.ctypes.data), ctypes.c_char_p(raw), ctypes.c_size_t(1), 0))
+m2 = (1 << 19) + 5
+g2b = np.concatenate([g2] * m2)
+g2sc = synthetic.random_fr_integers(m2, 99)
+ksum = 0
+for limb in range(4):
+    ksum += int(np.sum(g2sc[:, limb].astype(object))) << (64 * limb)
+got = oracle.g2_to_affine(msm.msm_g2(g2b, g2sc))
+want2 = oracle.g2_to_affine(oracle.g2_msm(g2[:1], np.array([[(ksum %% pyref.R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64)))
+assert got.tobytes() == want2.tobytes(), "G2 chunk ring"
+print("RING_OK")
+'''
+
+
+def test_chunk_ring_single_device():
+    """The pipelined host-buffer paths at test size: SNARKVM_HIP_MSM_CHUNK_LG=16 cuts a 2^19 `snarkvm_msm` into 9 chunks over
+    the three-lane ring (runtime.hip.h::lane_ring_run), SNARKVM_HIP_SCALAR_CHUNK_LG=18 cuts the cached call's scalars into 3."""
+    env = dict(os.environ, SNARKVM_HIP_DEVICES="0", SNARKVM_HIP_MSM_CHUNK_LG="16", SNARKVM_HIP_SCALAR_CHUNK_LG="18")
+    script = RING_SCRIPT % (util.ROOT, os.path.join(util.ROOT, "tests", "golden", "beta_h_g2.bin"))
+    r = subprocess.run([sys.executable, "-u", "-c", script], capture_output=True, text=True, env=env, timeout=1200, cwd=util.ROOT)
+    assert "RING_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -18,6 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLE
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/proofs -o p -- python bench.py --workload proofs64 --proof-workers 8 > $OUT/proofs64_under_rocprof.log 2>&1
 find $OUT -name "*.db" | head
 S=$(find $OUT/stats -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1); Q=$(find $OUT/sq -name "*.db" | head -1)
+[ -n "$S" ] && python tools/rocprof_summary.py schema $S > $OUT/rocpd_schema.txt
 [ -n "$S" ] && python tools/rocprof_summary.py stats $S > $OUT/${TAG}_rocprofv3_kernel_stats.txt
 P=$(find $OUT/proofs -name "*.db" | head -1)
 [ -n "$P" ] && python tools/rocprof_summary.py stats $P > $OUT/${TAG}_rocprofv3_kernel_stats_proofs64.txt
