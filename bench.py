@@ -293,9 +293,15 @@ def main():
             warm = hb.copy()
             plugin.msm(warm, hs)          # another host range of the same size: workspaces and pinned staging exist from here on
             del warm
+            fresh = hb.copy()
             t0 = time.perf_counter()
-            r_first = plugin.msm(hb, hs)  # first sighting of this host range: upload + conversion, chunked and overlapped
-            first = time.perf_counter() - t0
+            plugin.msm(fresh, hs)         # sample 1: a host range never seen before
+            firsts = [time.perf_counter() - t0]
+            del fresh
+            t0 = time.perf_counter()
+            r_first = plugin.msm(hb, hs)  # sample 2: first sighting of this host range: upload + conversion, chunked and overlapped
+            firsts.append(time.perf_counter() - t0)
+            first = min(firsts)           # two samples: the first pass of the HIP runtime over never-copied host pages can stall
             plugin.msm(hb, hs)            # second sighting: the range is registered in HBM (base cache)
             t0 = time.perf_counter()
             r_cached = plugin.msm(hb, hs)
@@ -303,7 +309,7 @@ def main():
             w = device_multiple_of_g(weighted_sum_mod_r(hs, start=1))
             if to_affine(r_first).tobytes() != w.tobytes() or to_affine(r_cached).tobytes() != w.tobytes():
                 raise SystemExit(f"bench.py: RESULT MISMATCH in snarkvm_msm at 2^{lg}")
-            ffi[f"snarkvm_msm_2p{lg}"] = {"first_call_ms": first * 1e3, "steady_state_ms": cached * 1e3, "pairs_per_s_first": m / first, "pairs_per_s_steady": m / cached}
+            ffi[f"snarkvm_msm_2p{lg}"] = {"first_call_ms": first * 1e3, "first_call_ms_samples": [f * 1e3 for f in firsts], "steady_state_ms": cached * 1e3, "pairs_per_s_first": m / first, "pairs_per_s_steady": m / cached}
         from snarkvm_amd.layout import NTTDirection, NTTInputOutputOrder, NTTType
         for lg in (16, 20, args.lg_ntt):
             y = x[: 1 << lg].copy()

@@ -112,16 +112,17 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     static const int env_S = getenv("SNARKVM_HIP_S") ? atoi(getenv("SNARKVM_HIP_S")) : 0;
     static const int env_S2 = getenv("SNARKVM_HIP_S2") ? atoi(getenv("SNARKVM_HIP_S2")) : 0;
     static const int env_L = getenv("SNARKVM_HIP_L") ? atoi(getenv("SNARKVM_HIP_L")) : 0;
-    // points per accumulate thread: long segments amortise the partial-sum flushes of big MSMs; two resident waves per SIMD
-    // (2^17 threads) hide the base gather.  Every thread leaves one partial sum per bucket it touches and the tail pays two
-    // general additions for each, so the smallest MSMs (<= 2^20 digit entries) trade the second wave for half the partial
-    // sums (measured at 2^16: accumulate +0.03 ms, tail -0.06 ms; one wave per SIMD still keeps the multiplier ~95 % busy,
-    // tools/ecbench.hip).
+    // points per accumulate thread.  Long segments amortise the partial-sum flushes (every thread leaves one partial sum per
+    // bucket it touches and the tail pays two general additions for each), but the grid should be whole rounds of one wave
+    // per SIMD (2^16 threads: one resident wave already keeps the multiplier ~95 % busy, tools/ecbench.hip): a grid of 1 088
+    // waves on 1 024 SIMDs runs for two rounds.  So: the fewest rounds k that keep S <= 64 (128 for the biggest MSMs), then
+    // the S that fills them - S = 16 at 2^16 x 16 tables, 64 from 2^18 on, 18 for 70 000 points.
     {
         const size_t E = (size_t)p.Wd * n;
-        p.S = E >= ((size_t)1 << 27) ? 128 : 64;
-        while (p.S > 16 && E / p.S < ((size_t)1 << 17)) p.S >>= 1;
-        while (p.S > 4 && E / p.S < ((size_t)1 << 16)) p.S >>= 1;
+        const size_t smax = E >= ((size_t)1 << 27) ? 128 : 64, round = (size_t)1 << 16;
+        const size_t k = (E + smax * round - 1) / (smax * round);
+        const size_t sfill = k ? (E + k * round - 1) / (k * round) : 4;
+        p.S = (uint32_t)(sfill < 4 ? 4 : sfill);
     }
     if (env_S > 0) p.S = env_S;
     p.S2 = env_S2 > 1 ? env_S2 : 8;

@@ -736,10 +736,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         {
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
             // (the tail kernels add up to TAIL_PARTIALS leftover partials per bucket themselves: one reduce round less)
-            // short segments (small MSMs) leave a few more: a reduce round (three launches, ~0.15 ms) costs more than the extra
-            // additions of the 256-thread fold; from 2^18 points on the round wins (measured at 2^20: 3.17 vs 3.31 ms)
+            // single-round MSMs (<= 2^22 digit entries) leave a few more: a reduce round (three launches, ~0.15 ms) costs more
+            // than the extra additions of the 256-thread fold; bigger ones win with the round (measured at 2^20: 3.17 vs 3.31 ms)
             static const size_t env_tailp = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 0;
-            const size_t tail_partials = env_tailp ? env_tailp : (pl.S <= 16 ? 16 : 4);
+            const size_t tail_partials = env_tailp ? env_tailp : ((size_t)pl.Wd * n <= ((size_t)1 << 22) ? 16 : 4);
             for (size_t m = max_bucket ? ((size_t)max_bucket - 1) / pl.S + 2 : 0; m > tail_partials; m = (m + pl.S2 - 1) / pl.S2) rounds++;
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());

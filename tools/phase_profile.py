@@ -31,7 +31,10 @@ def main():
         n = 1 << lg
         bits = 22 if lg >= 24 else 20 if lg >= 22 else 16
         tables = 16 if bits == 16 else -(-254 // bits)
-        rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=tables, window_bits=0 if bits == 16 else bits)
+        if os.environ.get("PHASE_TABLES"):  # experiments: e.g. PHASE_TABLES=17 -> 17 x 15-bit tables
+            tables = int(os.environ["PHASE_TABLES"])
+            bits = 256 // tables
+        rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=tables, window_bits=0 if bits * tables == 256 else bits)
         for _ in range(3):
             rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
         reps = 20
