@@ -292,8 +292,8 @@ def main():
             hb, hs = host_bases[:m], scalars[:m]
             warm = hb.copy()
             plugin.msm(warm, hs)          # another host range of the same size: workspaces and pinned staging exist from here on
-            del warm
-            fresh = hb.copy()
+            fresh = hb.copy()             # allocated while `warm` is alive: a different address (a reused address with the same
+            del warm                      # contents would be a second sighting and time the registration instead)
             t0 = time.perf_counter()
             plugin.msm(fresh, hs)         # sample 1: a host range never seen before
             firsts = [time.perf_counter() - t0]
@@ -301,7 +301,7 @@ def main():
             t0 = time.perf_counter()
             r_first = plugin.msm(hb, hs)  # sample 2: first sighting of this host range: upload + conversion, chunked and overlapped
             firsts.append(time.perf_counter() - t0)
-            first = min(firsts)           # two samples: the first pass of the HIP runtime over never-copied host pages can stall
+            first = min(firsts)           # two samples: a buffer the HIP runtime never copied from, and one it filled itself (D2H)
             plugin.msm(hb, hs)            # second sighting: the range is registered in HBM (base cache)
             t0 = time.perf_counter()
             r_cached = plugin.msm(hb, hs)

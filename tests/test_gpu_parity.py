@@ -422,6 +422,28 @@ def test_g2_msm_vs_oracle_standard_msm(golden, n):
     assert got.tobytes() == want.tobytes()
 
 
+def test_g2_msm_2_16_vs_oracle():
+    """BASELINE.json configs[4]'s G2 leg at its own size: 2^16 pairs (512 distinct multiples of the generator tiled, the shape
+    of the reference's MSM benches), host-buffer call and registered 16-table call, both == `standard::msm` of the oracle."""
+    from snarkvm_amd.msm import RegisteredBasesG2, msm_g2
+
+    n = 1 << 16
+    bases = synthetic.g2_points(n)
+    sc = synthetic.random_fr_integers(n, 1616)
+    sc[3] = 0
+    sc[4] = [1, 0, 0, 0]
+    want = oracle.g2_to_affine(oracle.g2_msm(bases.view(oracle.G2_AFFINE), sc, oracle.MSM_STANDARD)).tobytes()
+    assert oracle.g2_to_affine(msm_g2(bases, sc)).tobytes() == want
+    rg = RegisteredBasesG2(bases, tables=16)
+    try:
+        assert oracle.g2_to_affine(rg.msm(sc)).tobytes() == want
+        res = rg.msm_batch([sc[:40000], sc])
+        assert oracle.g2_to_affine(res[1:2]).tobytes() == want
+        assert oracle.g2_to_affine(res[0:1]).tobytes() == oracle.g2_to_affine(oracle.g2_msm(bases.view(oracle.G2_AFFINE)[:40000], sc[:40000], oracle.MSM_STANDARD)).tobytes()
+    finally:
+        rg.close()
+
+
 # ------------------------------------------------------------------------------------------ KZG10 commit
 def test_kzg10_commit_matches_reference_formula(golden):
     """KZG10::commit (polycommit/kzg10/mod.rs:98-156) = msm(powers[lz..], to_bigint(coeffs[lz..])) + msm(gamma powers,
