@@ -47,12 +47,18 @@ struct msm_plan_t {
     uint32_t bias[10]; // sum_w 2^(c-1+cw), 320-bit
 };
 
+// Window width of a table-less MSM (W = ceil(254 / c) windows).  The top window holds only 254 - c (W - 1) scalar bits (plus
+// the recoding carry), so for most c its few buckets receive n / 2 .. n / 8 entries each; two shapes keep the tail balanced:
+//   c <= 11 (n <= 2^17): no fold - one 256-thread workgroup per (window, bit) walks all partial sums of its window
+//            (msm_bitplane_kernel<F, false>), whatever their distribution over the buckets;
+//   c = 16 (beyond): 14 bits in the top window - every window is equally full (and fewer digit rows than c = 12 .. 15).
 static inline int msm_pick_c(size_t n) {
+    if (n > ((size_t)1 << 17)) return 16;
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
     int c = lg - 4;
     if (c < 2) c = 2;
-    if (c > 16) c = 16;
+    if (c > 11) c = 11;
     return c;
 }
 // tables == 1: W = ceil(254 / c) windows.  tables == J > 1 (registered bases with precomputed 2^(part * j) multiples,
@@ -458,33 +464,114 @@ template <class F>
 struct TAIL_WAVES {
     static constexpr int value = sizeof(F) <= 64 ? 2 : 1;
 };
+// In-place running sums of s[1 .. n] (s[0] = 0) by a workgroup of 64 or 256 threads: s[i] = s[1] + ... + s[i].  tmp: 256 words.
+__device__ __forceinline__ void block_running_sums(uint32_t* s, uint32_t n, uint32_t* tmp) {
+    const uint32_t B = blockDim.x, t = threadIdx.x;
+    const uint32_t per = (n + B - 1) / B;
+    const uint32_t lo = 1 + t * per, hi = lo + per < n + 1 ? lo + per : n + 1;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += s[i];
+    tmp[t] = sum;
+    __syncthreads();
+    if (t < 64) {  // exclusive scan of the B thread sums by one wave: B / 64 per lane, then a shuffle scan
+        const uint32_t e = B >> 6;
+        uint32_t v[4], own = 0;
+        for (uint32_t q = 0; q < e; q++) {
+            v[q] = tmp[t * e + q];
+            own += v[q];
+        }
+        uint32_t incl = own;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+            if (t >= (uint32_t)off) incl += u;
+        }
+        uint32_t run = incl - own;
+        for (uint32_t q = 0; q < e; q++) {
+            tmp[t * e + q] = run;
+            run += v[q];
+        }
+    }
+    __syncthreads();
+    uint32_t run = tmp[t];
+    for (uint32_t i = lo; i < hi; i++) {
+        run += s[i];
+        s[i] = run;
+    }
+    __syncthreads();
+}
+// the segment of position p in the offsets off[0 .. nseg] (off[0] = 0 <= p < off[nseg]): the largest i with off[i] <= p
+// (empty segments share their offset with the next one and are never returned)
+__device__ __forceinline__ uint32_t find_segment(const uint32_t* off, uint32_t nseg, uint32_t p) {
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+static constexpr uint32_t TAIL_MAX_SEG = 2048;  // buckets per fold column (2^hb, hb <= 11) / per unfolded window (2^10)
 // 7a. grid (2^m + 2^hb, W): workgroups [0, 2^m) of a window fold columns (fixed lo -> L_lo, slot lo), workgroups
 // [2^m, 2^m + 2^hb) fold rows (fixed hi -> H_hi, slot 2^m + hi - 1; H_0 has weight 0 and no slot).  Bucket k = w * nb + b
 // holds cnt[k] partial sums at sums[start[k] ...].  out: per window 2^(m+1) dense slots (slot 2^(m+1) - 1 is unused).
-template <class F>
+// The partial sums of a row are one contiguous range; those of a column (2^hb buckets at stride 2^m) are flattened through
+// running sums of their counts in LDS.  Either way lane t takes positions t, t + B, ... of the list: the work of a workgroup
+// is (partial sums of its row / column) / B whatever their distribution over the buckets - a bucket that received half of the
+// scalars (a witness full of ones) costs its row and its column a few more additions, not a reduce round with a host
+// read-back in front of it.
+// FLAT = false (big MSMs after their reduce rounds: <= TAIL_PARTIALS per bucket, thousands of buckets per column): lane ->
+// buckets i, i + B, ... of the column, no LDS staging.
+template <class F, bool FLAT>
 __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
                                                        const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb) {
     __shared__ xyzz_mem_t<F> sh[16];
+    __shared__ uint32_t s_off[FLAT ? TAIL_MAX_SEG + 1 : 1], s_start[FLAT ? TAIL_MAX_SEG : 1], s_tmp[FLAT ? 256 : 1];
     const uint32_t nlo = 1u << m, nhi = 1u << hb;
     const uint32_t w = blockIdx.y;
     const uint32_t kbase = w << (m + hb);
     const bool column = blockIdx.x < nlo;
     const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
     if (!column && fixed == 0) return;
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    if (column) {
-        // nhi buckets at stride 2^m: lane -> (bucket i, partial sub-range q0 + t * Q)
-        const uint32_t B = blockDim.x, Q = nhi >= B ? 1u : B / nhi;
-        for (uint32_t i = threadIdx.x % (B / Q); i < nhi; i += B / Q) {
-            const uint32_t k = kbase + (i << m) + fixed;
-            const uint32_t c = cnt[k], s0 = start[k];
-            for (uint32_t q = threadIdx.x / (B / Q); q < c; q += Q) acc.add(load_xyzz<F>(&sums[s0 + q]));
-        }
-    } else {
-        // the partial sums of the nlo consecutive buckets of a row are one contiguous range
+    if (!FLAT) {
+        xyzz_t<F> acc = xyzz_t<F>::inf();
+        // one loop for both shapes: a column is nhi buckets at stride 2^m, a row one contiguous range of partial sums
         const uint32_t k0 = kbase + (fixed << m);
-        const uint32_t p0 = start[k0], p1 = start[k0 + nlo - 1] + cnt[k0 + nlo - 1];
-        for (uint32_t pos = p0 + threadIdx.x; pos < p1; pos += blockDim.x) acc.add(load_xyzz<F>(&sums[pos]));
+        const uint32_t nouter = column ? nhi : 1u;
+        for (uint32_t i = column ? threadIdx.x : 0u; i < nouter; i += column ? blockDim.x : 1u) {
+            const uint32_t k = kbase + (i << m) + fixed;
+            const uint32_t q0 = column ? start[k] : start[k0] + threadIdx.x;
+            const uint32_t q1 = column ? q0 + cnt[k] : start[k0 + nlo - 1] + cnt[k0 + nlo - 1];
+            for (uint32_t q = q0; q < q1; q += column ? 1u : blockDim.x) acc.add(load_xyzz<F>(&sums[q]));
+        }
+        block_sum<F>(acc, sh);
+        if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
+        return;
+    }
+    uint32_t nseg;
+    if (column) {
+        for (uint32_t i = threadIdx.x; i < nhi; i += blockDim.x) {
+            const uint32_t k = kbase + (i << m) + fixed;
+            s_start[i] = start[k];
+            s_off[i + 1] = cnt[k];
+        }
+        if (threadIdx.x == 0) s_off[0] = 0;
+        __syncthreads();
+        block_running_sums(s_off, nhi, s_tmp);
+        nseg = nhi;
+    } else {
+        const uint32_t k0 = kbase + (fixed << m);
+        if (threadIdx.x == 0) {
+            s_start[0] = start[k0];
+            s_off[0] = 0;
+            s_off[1] = start[k0 + nlo - 1] + cnt[k0 + nlo - 1] - start[k0];
+        }
+        __syncthreads();
+        nseg = 1;
+    }
+    const uint32_t total = s_off[nseg];
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+        const uint32_t i = find_segment(s_off, nseg, p);
+        acc.add(load_xyzz<F>(&sums[s_start[i] + (p - s_off[i])]));
     }
     block_sum<F>(acc, sh);
     if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
@@ -492,32 +579,34 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
 // 7b. grid (nbits, tail windows).  Tail window tw holds N entries, entry i has weight i + 1:
 //   DENSE (after a fold): tw = 2 * w + sub; sub 0 = the L sums (N = 2^m), sub 1 = the H sums (N = 2^hb - 1); entry i is
 //          sums[(w << (m + 1)) + (sub << m) + i];
-//   else (small windows): tw = w, N = nb, entry i = the cnt[k] partial sums of bucket k = w * nb + i.
+//   else (small windows, nb <= 1024): tw = w, N = nb, entry i = the cnt[k] partial sums of bucket k = w * nb + i - one
+//          contiguous range for the whole window, walked position by position like a fold row (the bucket of a position comes
+//          from the window's `start` values in LDS).
 // planes[tw * nbits + j] = sum of the entries of tw whose weight has bit j set.
 template <class F, bool DENSE>
 __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
                                                            const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ planes, uint32_t nb,
                                                            int m, int hb) {
     __shared__ xyzz_mem_t<F> sh[16];
+    __shared__ uint32_t s_off[DENSE ? 1 : TAIL_MAX_SEG + 1];
     const uint32_t j = blockIdx.x, tw = blockIdx.y, nbits = gridDim.x;
-    uint32_t N;
-    size_t base;
+    xyzz_t<F> acc = xyzz_t<F>::inf();
     if (DENSE) {
         const uint32_t w = tw >> 1, sub = tw & 1;
-        N = sub ? (1u << hb) - 1 : (1u << m);
-        base = ((size_t)w << (m + 1)) + ((size_t)sub << m);
+        const uint32_t N = sub ? (1u << hb) - 1 : (1u << m);
+        const size_t base = ((size_t)w << (m + 1)) + ((size_t)sub << m);
+        for (uint32_t i = threadIdx.x; i < N; i += blockDim.x)
+            if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[base + i]));
     } else {
-        N = nb;
-        base = (size_t)tw * nb;
-    }
-    xyzz_t<F> acc = xyzz_t<F>::inf();
-    for (uint32_t i = threadIdx.x; i < N; i += 256) {
-        if (!(((i + 1) >> j) & 1)) continue;
-        if (DENSE) {
-            acc.add(load_xyzz<F>(&sums[base + i]));
-        } else {
-            const uint32_t c = cnt[base + i], s0 = start[base + i];
-            for (uint32_t q = 0; q < c; q++) acc.add(load_xyzz<F>(&sums[s0 + q]));
+        const size_t base = (size_t)tw * nb;
+        const uint32_t p0 = start[base];
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_off[i] = start[base + i] - p0;
+        if (threadIdx.x == 0) s_off[nb] = start[base + nb - 1] + cnt[base + nb - 1] - p0;
+        __syncthreads();
+        const uint32_t total = s_off[nb];
+        for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+            const uint32_t i = find_segment(s_off, nb, p);
+            if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[p0 + p]));
         }
     }
     block_sum<F>(acc, sh);

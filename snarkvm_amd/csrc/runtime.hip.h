@@ -586,6 +586,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         phase_end();
     }
     int rounds = 0;
+    const bool single_round = (size_t)pl.Wd * n <= ((size_t)1 << 22);  // see step 5
     {
         // ---- 2.-4. LDS-staged radix partition (msm_sort.hip.h) -> bucket-major `sorted` + boff; two levels, three when wide
         msm_radix_params_t rp;
@@ -728,19 +729,24 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                            c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
                            (uint8_t*)nullptr, nseg, LBL, 0);
         phase_end();
-        uint32_t max_bucket = 0;  // the number of reduce rounds follows the largest bucket (4-byte read-back)
-        HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // A single-round MSM (<= 2^22 digit entries: at most 2^16 accumulate threads) leaves at most 2^16 + nbt partial sums
+        // whatever the scalars are, and the tail kernels walk them position by position (msm.hip.h 7a/7b): no reduce round
+        // and no host read-back in the middle of the pipeline.  Bigger MSMs size their reduce rounds by the largest bucket
+        // (4-byte read-back): a round shrinks millions of partial sums to at most TAIL_PARTIALS per bucket before the fold
+        // reads them twice.
+        uint32_t max_bucket = 0;
+        if (!single_round) {
+            HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         // ---- 5. accumulate
         phase_begin("msm_accumulate");
         {
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
-            // (the tail kernels add up to TAIL_PARTIALS leftover partials per bucket themselves: one reduce round less)
-            // single-round MSMs (<= 2^22 digit entries) leave a few more: a reduce round (three launches, ~0.15 ms) costs more
-            // than the extra additions of the 256-thread fold; bigger ones win with the round (measured at 2^20: 3.17 vs 3.31 ms)
             static const size_t env_tailp = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 0;
-            const size_t tail_partials = env_tailp ? env_tailp : ((size_t)pl.Wd * n <= ((size_t)1 << 22) ? 16 : 4);
-            for (size_t m = max_bucket ? ((size_t)max_bucket - 1) / pl.S + 2 : 0; m > tail_partials; m = (m + pl.S2 - 1) / pl.S2) rounds++;
+            const size_t tail_partials = env_tailp ? env_tailp : 4;
+            if (!single_round)
+                for (size_t m = max_bucket ? ((size_t)max_bucket - 1) / pl.S + 2 : 0; m > tail_partials; m = (m + pl.S2 - 1) / pl.S2) rounds++;
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
@@ -776,11 +782,19 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     phase_begin("msm_bucket_reduce");
     if (fold) {
         c.fold_sums.ensure(((size_t)pl.W << (fold_m + 1)) * sizeof(xyzz_mem_t<F>));
-        // small MSMs are latency-bound (256 threads per output: short serial part); big ones throughput-bound (one wave per output)
-        const unsigned fold_threads = nbt >= (1u << 18) ? 64u : 256u;
-        hipLaunchKernelGGL((msm_fold_kernel<F>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in, cnt_in,
-                           c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
-        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(256), 0, st,
+        // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
+        // (<= 512 workgroups at two waves per SIMD); many windows (table-less small MSMs: 20 windows x 128 outputs) or many
+        // buckets are throughput-bound: one wave per output
+        const unsigned fold_blocks = ((1u << fold_m) + (1u << fold_hb)) * (unsigned)pl.W;
+        const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
+        if (single_round || fold_threads == 256u)  // flattened lists: any distribution, and 256 lanes busy on 128 buckets
+            hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in,
+                               cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
+        else
+            hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in,
+                               cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
+        const unsigned plane_threads = fold_m <= 6 ? 64u : 256u;  // <= 64 entries per plane: one wave
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(plane_threads), 0, st,
                            (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                            c.planes.as<xyzz_mem_t<F>>(), pl.nb, fold_m, fold_hb);
     } else {
