@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite output) into profiles/*_pmc_traffic.json:
-bytes of the largest (full-size) dispatch of each kernel.  FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE under-reports 16 B/lane
+bytes per full-size dispatch of each kernel.  FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE under-reports 16 B/lane
 streaming loads by 2x (MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are kept."""
 import json
 import sqlite3
@@ -20,8 +20,13 @@ def per_dispatch(path, counter):
         d = agg.setdefault(key, {})
         did = r[ix["dispatch_id"]] if "dispatch_id" in ix else len(d)
         d[did] = d.get(did, 0.0) + float(r[ix["value"]])
-    # the largest dispatch of each kernel = its full-size launch (the benchmark's one-point result checks launch the same kernels)
-    return {k: max(v.values()) * 1024.0 for k, v in agg.items()}
+    # mean over the full-size launches of each kernel (>= a quarter of its largest dispatch): the benchmark's one-point result
+    # checks launch the same kernels on a handful of elements and would dilute a plain average
+    out = {}
+    for k, v in agg.items():
+        big = [x for x in v.values() if x >= 0.25 * max(v.values())]
+        out[k] = sum(big) / len(big) * 1024.0
+    return out
 
 
 def main():
@@ -30,7 +35,7 @@ def main():
     w = per_dispatch(write_db, "WRITE_SIZE")
     out = {
         "source": source,
-        "units": "bytes of the largest dispatch of each kernel; FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE is "
+        "units": "bytes per full-size dispatch of each kernel (mean over the dispatches >= 1/4 of the largest); FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE is "
                  "doubled for 16 B/lane streaming loads on gfx950 (fetch_bytes_x2); gathers are quoted raw",
         "kernels": {k: {"fetch_bytes_raw": f.get(k, 0.0), "fetch_bytes_x2": 2 * f.get(k, 0.0), "write_bytes": w.get(k, 0.0)} for k in sorted(set(f) | set(w))},
     }
