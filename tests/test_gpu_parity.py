@@ -667,6 +667,37 @@ def test_msm_randomized_configurations(golden):
             assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(bases, sc)), want), ("ffi", case, n, kind)
 
 
+@pytest.mark.parametrize("n", [5000, 70000, 200000])
+def test_msm_skewed_scalars_every_tail_shape(n):
+    """The tail kernels take whatever partial sums the accumulate phase leaves (no reduce round below 2^22 digit entries).
+    Heavily skewed scalar vectors - all equal, two values, half ones, 90 % tiny - through the three shapes of the tail:
+    the unfolded bit planes of a table-less MSM (n <= 2^17: c <= 11), the one-wave fold of a table-less c = 16 MSM (200 000),
+    and the 256-thread fold over 16 registered tables; bases (i + 1) G, expected = (sum s_i (i + 1)) G by the oracle."""
+    G = util.g1_generator_affine()
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rng = np.random.default_rng(n)
+    uni = synthetic.random_fr_integers(n, 4000 + n)
+    vecs = {"all equal": np.tile(uni[:1], (n, 1)), "two values": uni[rng.integers(0, 2, n)]}
+    half = uni.copy()
+    half[rng.random(n) < 0.5] = [1, 0, 0, 0]
+    vecs["half ones"] = half
+    tiny = np.zeros_like(uni)
+    tiny[:, 0] = rng.integers(0, 256, n, dtype=np.uint64)
+    keep = rng.random(n) < 0.1
+    tiny[keep] = uni[keep]
+    vecs["90 % tiny"] = tiny
+    rb = RegisteredBases(bases, tables=16)
+    try:
+        for name, sc in vecs.items():
+            sc = np.ascontiguousarray(sc)
+            want = oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(sc, start=1), 4)))
+            fresh = bases.copy()  # a host range the base cache has not seen: the table-less path
+            assert util.affine_equal(oracle.g1_to_affine(plugin.msm(fresh, sc)), want), (name, "table-less")
+            assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc)), want), (name, "16 tables")
+    finally:
+        rb.close()
+
+
 def test_extension_abi_rejects_bad_arguments(golden):
     """Every extension entry point answers a malformed request with a non-zero RustError (never a crash, never a silent
     result): the caller's fallback logic depends on it (variable_base/mod.rs:39-43)."""
