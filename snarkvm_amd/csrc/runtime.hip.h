@@ -927,8 +927,13 @@ static void lane_ring_run(lane_guard& lg, size_t count, Upload&& upload, Compute
         cv.notify_all();
     }
     uploader.join();
-    if (cp_err) std::rethrow_exception(cp_err);
-    if (up_err) std::rethrow_exception(up_err);
+    if (cp_err || up_err) {  // nothing of this call may still be in flight when the lanes go back to the pool
+        for (lane_t* l : lg.lanes) {
+            (void)hipStreamSynchronize(l->alt);
+            (void)hipStreamSynchronize(l->stream);
+        }
+        std::rethrow_exception(cp_err ? cp_err : up_err);
+    }
 }
 
 // The reference's FFI MSM (host bases, host scalars, no registration): G1: F = fq_t (stride >= 104), G2: F = fq2_t (>= 200).
