@@ -76,12 +76,7 @@ RustError snarkvm_hip_synchronize(void) {
 
 // ---- registered bases ---------------------------------------------------------------------------------
 // tables 1 .. J-1 of one replica: table j = 2^table_bits * table j-1
-static void precompute_tables(lane_t& c, snarkvm_hip_bases* h, g1_aff_mem_t* d) {
-    for (int j = 1; j < h->tables; j++)
-        hipLaunchKernelGGL((precompute_table_kernel<fq_t>), dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, c.stream, d + (size_t)(j - 1) * h->n,
-                           d + (size_t)j * h->n, h->n, h->table_bits);
-    HIP_TRY(hipGetLastError());
-}
+static void precompute_tables(lane_t& c, snarkvm_hip_bases* h, g1_aff_mem_t* d) { precompute_tables_run<fq_t>(c, d, h->n, h->tables, h->table_bits); }
 // One replica per logical device.  Host source: every device uploads and converts for itself (in parallel).  Device source:
 // the owner converts and precomputes, the other devices receive the finished tables by peer copies over xGMI.
 static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points, size_t npoints, size_t ffi_affine_sz, int on_device, int tables,

@@ -52,10 +52,7 @@ RustError snarkvm_hip_register_bases_g2(snarkvm_hip_bases_g2_t** handle, const v
                 c.bases_tmp.ensure(npoints * ffi_affine_sz);
                 HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, c.stream));
                 convert_bases<fq2_t>(c, c.bases_tmp.as<uint8_t>(), ffi_affine_sz, npoints, h->d[dev]);
-                for (int j = 1; j < tables; j++)
-                    hipLaunchKernelGGL((precompute_table_kernel<fq2_t>), dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, c.stream,
-                                       h->d[dev] + (size_t)(j - 1) * npoints, h->d[dev] + (size_t)j * npoints, npoints, h->table_bits);
-                HIP_TRY(hipGetLastError());
+                precompute_tables_run<fq2_t>(c, h->d[dev], npoints, tables, h->table_bits);
                 HIP_TRY(hipStreamSynchronize(c.stream));
             });
         } catch (...) {

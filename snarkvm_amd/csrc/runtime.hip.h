@@ -829,6 +829,25 @@ static void convert_bases(lane_t& c, const uint8_t* d_in, size_t stride, size_t 
     HIP_TRY(hipGetLastError());
 }
 
+// Precomputed base tables of a registered vector: table j = 2^(table_bits * j) * P_i, from table j - 1 (msm.hip.h).  Long
+// vectors give every thread a run of points that share one inversion; a run of 1 keeps small vectors parallel.
+template <class F>
+static void precompute_tables_run(lane_t& c, aff_mem_t<F>* d, size_t n, int tables, int table_bits) {
+    if (tables <= 1 || !n) return;
+    int run = (int)(n >> 16);
+    run = run < 1 ? 1 : (run > PRE_RUN ? PRE_RUN : run);
+    const size_t slab = n < PRE_SLAB ? n : PRE_SLAB;
+    c.gen_pts.ensure(4 * slab * sizeof(typename F::mem_t));
+    for (int j = 1; j < tables; j++)
+        for (size_t lo = 0; lo < n; lo += PRE_SLAB) {
+            const size_t cnt = n - lo < PRE_SLAB ? n - lo : PRE_SLAB;
+            const size_t threads = (cnt + run - 1) / run;
+            hipLaunchKernelGGL((precompute_table_kernel<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, d + (size_t)(j - 1) * n + lo,
+                               d + (size_t)j * n + lo, cnt, table_bits, run, (typename F::mem_t*)c.gen_pts.p);
+        }
+    HIP_TRY(hipGetLastError());
+}
+
 // lanes a batch cycles through per device: more lanes hide more of the latency-bound tail of small MSMs, fewer keep the
 // workspace footprint of big ones down (a 2^24 lane holds ~4 GB)
 static int batch_lanes(size_t npoints) {

@@ -33,7 +33,7 @@ def main():
         tables = 16 if bits == 16 else -(-254 // bits)
         if os.environ.get("PHASE_TABLES"):  # experiments: e.g. PHASE_TABLES=17 -> 17 x 15-bit tables
             tables = int(os.environ["PHASE_TABLES"])
-            bits = 256 // tables
+            bits = int(os.environ.get("PHASE_BITS", 256 // tables))
         rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=tables, window_bits=0 if bits * tables == 256 else bits)
         for _ in range(3):
             rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
