@@ -548,10 +548,12 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
     c.part_a.ensure(T0_max * sizeof(xyzz_mem_t<F>));
     c.part_b.ensure(T1_max * sizeof(xyzz_mem_t<F>));
-    // tail geometry: windows of >= 2^11 buckets are first folded into two tail windows of 2^fold_m / 2^fold_hb - 1 entries
+    // tail geometry: windows of >= 2^11 buckets are first folded into two tail windows of 2^fold_m / 2^fold_hb - 1 entries; so are
+    // smaller windows when there are too few (window, bit) pairs to spread an unfolded tail over the chip (registered tables
+    // below 4 096 points: 2 windows x 8 bits would be 16 workgroups walking every partial sum; the fold gives 48)
     const int K = pl.c - 1;
     const int fold_m = (K + 1) / 2, fold_hb = K - fold_m;
-    const bool fold = K >= 11;
+    const bool fold = K >= 11 || (K >= 4 && pl.c * pl.W < 128);
     const int tail_windows = fold ? 2 * pl.W : pl.W;
     const int nbits = fold ? fold_m + 1 : pl.c;  // weights run up to 2^fold_m (L sums) / 2^(c-1) (plain buckets)
     pd.tail_windows = tail_windows;
@@ -896,11 +898,13 @@ static void lane_ring_run(lane_guard& lg, size_t count, Upload&& upload, Compute
             for (size_t j = 0; j < count; j++) {
                 lane_t& c = *lg.lanes[j % L];
                 if (j >= L) {  // the lane's previous chunk must have been consumed on the GPU
+                    char state;
                     {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [&] { return enqueued[j - L] != 0; });
+                        state = enqueued[j - L];
                     }
-                    if (enqueued[j - L] == 2) break;  // the compute side failed
+                    if (state == 2) break;  // the compute side failed
                     HIP_TRY(hipEventSynchronize(used[j - L]));
                 }
                 const double t0 = host_now_ms();

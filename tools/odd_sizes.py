@@ -11,7 +11,7 @@ _lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(buf.data_ptr()
 sc = synthetic.random_fr_integers(nmax, 5)
 d_sc = torch.from_numpy(sc.view(np.int64)).cuda(); torch.cuda.synchronize()
 rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=nmax, tables=16)
-for n in [40000, 65536, 66000, 70000, 100000, 131072, 140000, 200000, 262144, 270000, 400000, 524288]:
+for n in [256, 1024, 2048, 4095, 4096, 8192, 16384, 40000, 65536, 66000, 70000, 100000, 131072, 140000, 200000, 262144, 270000, 400000, 524288]:
     for _ in range(3): rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
     t0 = time.perf_counter()
     for _ in range(20): rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
