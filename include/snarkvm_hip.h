@@ -63,7 +63,7 @@ RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoint
 /* Multi-GPU: like the reference (snarkvm.cu:254-295) a call of >= 2^19 pairs is cut into point-range chunks that are dealt
  * to every selected device (and to two lanes per device, so that the upload of one chunk overlaps the computation of the
  * previous one); the per-chunk partial results are combined on the host.
- * Base cache: a host base range passed a SECOND time is kept in HBM (converted, with 16 precomputed tables, on every device)
+ * Base cache: a host base range passed a SECOND time is kept in HBM (converted, with precomputed tables - 17 x 15-bit below 2^18 points, 16 x 16, 13 x 20 from 2^21, 12 x 22 from 2^23 - on every device)
  * and later calls whose bases are a slice of it skip upload and conversion - the reference's callers always pass slices of
  * one long-lived `powers_of_beta_g` vector (kzg10/mod.rs:117-119).  A hit is verified against raw copies of every 64th point
  * of the slice; the memory behind a cached range must not be mutated in between at other positions.  Results are unchanged.

@@ -322,7 +322,7 @@ RustError snarkvm_hip_msm_registered_batch_ex(void* outs, const snarkvm_hip_base
 // ---- the reference's FFI MSM (host bases + host scalars) -----------------------------------------------------------------
 // Base cache behind the unmodified FFI.  The reference's callers pass slices of ONE long-lived vector
 // (`powers_of_beta_g[lz .. lz + len]`, kzg10/mod.rs:117-119) and its GPU path re-uploads them on every call.  Here a host
-// range that is seen a SECOND time is registered (converted, with 16 precomputed tables, on every device) and later calls
+// range that is seen a SECOND time is registered (converted, with precomputed tables, on every device) and later calls
 // whose base range lies inside it skip the upload, the conversion and most of the Horner chain.  A hit is verified against
 // raw copies of every CACHE_STEP-th point of the range that falls inside the requested slice (a slice > 1024 points always
 // contains at least 16 of them); a mismatch drops the entry.  Host pointers are only compared, never dereferenced outside
@@ -377,11 +377,13 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
                 base_cache_drop(i);
                 break;
             }
-            // table geometry by size, as measured (profiles/r01_size_sweep.md): 12 x 22-bit windows from 2^23 points, 13 x 20-bit from
-            // 2^21, else the configured count of 256 / tables-bit tables
+            // table geometry by size, as measured (profiles/r02_size_sweep.md): 12 x 22-bit windows from 2^23 points, 13 x 20-bit from
+            // 2^21, 17 x 15-bit below 2^18 (half the buckets of 16 x 16: the whole fold is one round of 256 workgroups), else the
+            // configured count of 256 / tables-bit tables
             int tables = base_cache_tables(), bits = 0;
             if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 23)) tables = 12, bits = 22;
             else if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 21)) tables = 13, bits = 20;
+            else if (tables == 16 && g_base_cache[i].n < ((size_t)1 << 18)) tables = 17, bits = 15;
             const size_t need = (size_t)tables * g_base_cache[i].n * sizeof(g1_aff_mem_t);
             if (need > base_cache_cap()) return nullptr;
             for (;;) {  // make room: least recently used registered entries go first
