@@ -608,7 +608,10 @@ static __global__ void msm_alloc_seg_kernel(const uint32_t* __restrict__ boff, u
     }
     cnt[k] = c;
 }
-template <class F, int MINW>  // MINW: waves per SIMD asked of the register allocator (3 -> <= 168 VGPRs for G1)
+// PREFETCH (single-round MSMs: one wave per SIMD, nothing else hides the base gather): the slot of entry pos + 1 is requested
+// before the addition of entry pos starts, so its ~2 us of HBM latency run under the ~9 us of arithmetic.  Big MSMs keep two
+// resident waves per SIMD instead (the extra 24 registers of the prefetched slot were measured: no gain there).
+template <class F, int MINW, bool PREFETCH>  // MINW: waves per SIMD asked of the register allocator (3 -> <= 168 VGPRs for G1)
 __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff_mem_t<F>* __restrict__ bases,
                                                                  const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
@@ -624,6 +627,15 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
     uint32_t k = find_bucket(boff, nbt, lo);  // the non-empty bucket that contains entry `lo`
     uint32_t kend = boff[k + 1];
     xyzz_t<F> acc = xyzz_t<F>::inf();
+    auto slot_of = [&](uint32_t e) -> const aff_mem_t<F>* {
+        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
+        const uint32_t tbl = v / n;
+        const uint32_t idx = (v - tbl * n) & debug_idx_mask;  // bases come in up to two segments (mask: timing experiments only)
+        return (idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride;
+    };
+    uint32_t e_next = sorted[lo];
+    aff_mem_t<F> raw_next;
+    if (PREFETCH) raw_next = *slot_of(e_next);
     for (uint32_t pos = lo; pos < hi; pos++) {
         if (pos >= kend) {  // bucket k ends inside this segment: flush and move to the bucket of `pos`
             store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);
@@ -633,11 +645,18 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
                 kend = boff[k + 1];
             } while (pos >= kend);
         }
-        const uint32_t e = sorted[pos];
-        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
-        const uint32_t tbl = v / n;
-        const uint32_t idx = (v - tbl * n) & debug_idx_mask;  // bases come in up to two segments (mask: timing experiments only)
-        const aff_mem_t<F> raw = *((idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride);
+        const uint32_t e = e_next;
+        aff_mem_t<F> raw;
+        if (PREFETCH) {
+            raw = raw_next;
+            if (pos + 1 < hi) {
+                e_next = sorted[pos + 1];
+                raw_next = *slot_of(e_next);
+            }
+        } else {
+            raw = *slot_of(e);
+            if (pos + 1 < hi) e_next = sorted[pos + 1];
+        }
         acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
     }
     store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);

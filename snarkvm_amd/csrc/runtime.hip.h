@@ -755,9 +755,15 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             // timing experiment only (wrong results): restrict the gather to the first 2^k bases to separate ALU time from HBM gather time
             static const uint32_t dbg_mask = getenv("SNARKVM_HIP_DEBUG_IDX_MASK") ? (uint32_t)strtoul(getenv("SNARKVM_HIP_DEBUG_IDX_MASK"), nullptr, 0) : 0xffffffffu;
             // (a 3-waves-per-SIMD build of this kernel - 168 VGPRs - and a software-pipelined gather were measured: no gain)
-            hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                               d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                               c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
+            static const int prefetch_env = getenv("SNARKVM_HIP_PREFETCH") ? atoi(getenv("SNARKVM_HIP_PREFETCH")) : 1;
+            if (single_round && prefetch_env)
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                                   d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
+            else
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                                   d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
         }
         phase_end();
     }
