@@ -801,7 +801,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         else
             hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in,
                                cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
-        const unsigned plane_threads = fold_m <= 6 ? 64u : 256u;  // <= 64 entries per plane: one wave
+        const unsigned plane_threads = fold_m <= 6 ? 64u : fold_m == 7 ? 128u : 256u;  // one lane per entry of a plane (<= 2^fold_m)
         hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(plane_threads), 0, st,
                            (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                            c.planes.as<xyzz_mem_t<F>>(), pl.nb, fold_m, fold_hb);

@@ -29,7 +29,7 @@ def main():
     torch.cuda.synchronize()
     for lg in sizes:
         n = 1 << lg
-        bits = 22 if lg >= 24 else 20 if lg >= 22 else 16
+        bits = 22 if lg >= 23 else 20 if lg >= 21 else 16 if lg >= 18 else 15  # the base cache's geometry rule (api.hip)
         tables = 16 if bits == 16 else -(-254 // bits)
         if os.environ.get("PHASE_TABLES"):  # experiments: e.g. PHASE_TABLES=17 -> 17 x 15-bit tables
             tables = int(os.environ["PHASE_TABLES"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Size sweep on one MI355X: G1 MSM (registered bases with precomputed tables: 16 x 16-bit below 2^22, 13 x 20-bit at
+"""Size sweep on one MI355X: G1 MSM (registered bases with precomputed tables: 17 x 15-bit below 2^18, 16 x 16-bit below 2^21, 13 x 20-bit at
 2^22, 12 x 22-bit at 2^24 - the rule bench.py applies; synchronous and pipelined batch of 8) and Fr NTT (device resident,
 NN forward) for 2^14 .. 2^24.  Prints a markdown table (committed under profiles/)."""
 import ctypes
@@ -33,7 +33,7 @@ def main():
     for lg in range(14, 25, 2):
         n = 1 << lg
         reps = 3 if lg >= 22 else 8
-        bits = 22 if lg >= 24 else 20 if lg >= 22 else 16
+        bits = 22 if lg >= 23 else 20 if lg >= 21 else 16 if lg >= 18 else 15  # the base cache's geometry rule (api.hip)
         tables = 16 if bits == 16 else -(-254 // bits)
         rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=tables, window_bits=0 if bits == 16 else bits)
         rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
