@@ -321,7 +321,7 @@ def main():
                 raise SystemExit(f"bench.py: snarkvm_ntt round trip failed at 2^{lg}")
             ffi[f"snarkvm_ntt_2p{lg}"] = {"ms": d * 1e3, "elements_per_s": (1 << lg) / d}
         ffi["note"] = ("host buffers in and out through the reference's FFI symbols; MSM first_call = unknown base range (2.4 GB over PCIe at 2^24, "
-                       "overlapped with the computation in 2^21-pair chunks), steady_state = the range was passed before and lives in HBM with 16 tables")
+                       "overlapped with the computation in 2^21-pair chunks), steady_state = the range was passed before and lives in HBM with precomputed tables")
         extra["end_to_end_ffi"] = ffi
         checks["ffi"] = "snarkvm_msm first / cached calls == closed form at every size; snarkvm_ntt round trips"
         del host_bases
