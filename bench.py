@@ -415,6 +415,12 @@ def main():
             prods = nn * (args.lg_ntt / 2.0 + 2.0 + 0.5)
             alu_ntt = {"fr_products_per_launch": prods, "mads_per_launch": prods * 153.0, "peak_mads_per_s": ceil["v_mad_u64_u32_per_s"],
                        "mad_frac": prods * 153.0 / (ntt_kernel_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"]}
+            if ceil.get("fr_ntt_element_passes_per_s"):
+                # the same accounting as the accumulate kernel: work / time / the register-resident rate of the kernel's own arithmetic
+                passes = (args.lg_ntt + 7) // 8 if args.lg_ntt <= 24 else 3  # ntt_make_plan: radix <= 2^8 up to 2^24, 2^9 beyond
+                alu_ntt["element_passes_per_launch"] = float(passes * nn)
+                alu_ntt["element_pass_ceiling_per_s"] = ceil["fr_ntt_element_passes_per_s"]
+                alu_ntt["frac"] = passes * nn / (ntt_kernel_ms * 1e-3) / ceil["fr_ntt_element_passes_per_s"]
         out = {
             "metric": "BLS12-377 G1 MSM scalar-point pairs/sec (+ Fr NTT elements/sec in ntt_*)",
             "value": pairs_per_s,

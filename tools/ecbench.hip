@@ -133,6 +133,39 @@ static double time_block(K kern, int blocks, int threads, int iters, uint32_t* d
     return ms * 1e3 / iters;
 }
 
+// The arithmetic of one radix-2^8 NTT pass on a pair of elements, register resident (no LDS, no memory): 8 lazy DIF butterflies
+// (ntt.hip.h::lazy_butterfly: add_lazy, sub_lazy + 2^s r, mul_lazy by a twiddle) followed by the closing product and the
+// conditional subtraction of both outputs.  Chip-wide rate in G butterflies/s = the arithmetic ceiling of ntt_pass_kernel_v2.
+__device__ __forceinline__ fr_t seed_fr(uint32_t s) {
+    fr_t a;
+    for (int i = 0; i < 9; i++) {
+        s = s * 1664525u + 1013904223u;
+        a.v[i] = s & LIMB_MASK;
+    }
+    a.v[8] &= 0x000fffffu;  // < r
+    return a;
+}
+template <int MINW>
+__global__ void __launch_bounds__(256, MINW) k_ntt_pass(uint32_t* out, int iters, int) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    fr_t u = seed_fr(tid * 3 + 1), v = seed_fr(tid * 7 + 5);
+    const fr_t w = seed_fr(tid * 11 + 3), wc = seed_fr(tid * 13 + 7);
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            uint32_t kp[9];
+            fr_t::mod_shl(kp, st);
+            const fr_t sum = fr_t::add_lazy(u, v);
+            v = fr_t::sub_lazy(u, v, kp).mul_lazy(w);
+            u = sum;
+        }
+        u = u.mul_lazy(wc).reduce_lazy();
+        v = v.mul_lazy(wc).reduce_lazy();
+    }
+    uint32_t x = 0;
+    for (int i = 0; i < 9; i++) x ^= u.v[i] ^ v.v[i];
+    out[tid] = x;
+}
 template <class K>
 static double run(K kern, int blocks, int iters, int op, uint32_t* d_out, hipEvent_t e0, hipEvent_t e1) {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d_out, 4, op);  // warm-up
@@ -174,6 +207,14 @@ int main() {
     printf("single wave, XYZZ additions, code locality: 1 inlined site in a loop %.2f us/add | 2 sites %.2f | 4 sites %.2f | 8 sites %.2f | one out-of-line function %.2f\n",
            time_single(k_sites<1>, 64, 0, d_out, e0, e1) / 64, time_single(k_sites<2>, 32, 0, d_out, e0, e1) / 64, time_single(k_sites<4>, 16, 0, d_out, e0, e1) / 64,
            time_single(k_sites<8>, 8, 0, d_out, e0, e1) / 64, time_single(k_sites<1>, 64, 1, d_out, e0, e1) / 64);
+    {
+        const int it = 200;
+        double r[4] = {run(k_ntt_pass<1>, cus * 1 * 4, it, 0, d_out, e0, e1), run(k_ntt_pass<2>, cus * 2 * 4, it, 0, d_out, e0, e1),
+                       run(k_ntt_pass<3>, cus * 3 * 4, it, 0, d_out, e0, e1), run(k_ntt_pass<4>, cus * 4 * 4, it, 0, d_out, e0, e1)};
+        // one iteration = 8 butterflies + 2 closing products on a pair = one pass over two elements
+        printf("%-24s %10.2f %10.2f %10.2f %10.2f   (G element-passes/s: 8 lazy butterflies + 2 closing products per pair of Fr elements)\n",
+               "Fr NTT pass arithmetic", 2 * r[0], 2 * r[1], 2 * r[2], 2 * r[3]);
+    }
     printf("single wave, quad-cooperative XYZZ addition (4 lanes share the 14 products): %.2f us per addition\n", time_block(k_quad, 1, 64, 200, d_out, e0, e1));
     printf("block_sum (1 plain level + quad levels): 64 threads %.1f us | 256 threads %.1f us | 384 blocks x 256 threads %.1f us | 512 blocks x 256 threads %.1f us\n",
            time_block(k_block_sum, 1, 64, 20, d_out, e0, e1), time_block(k_block_sum, 1, 256, 20, d_out, e0, e1), time_block(k_block_sum, 384, 256, 20, d_out, e0, e1),
