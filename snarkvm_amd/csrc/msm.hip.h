@@ -195,9 +195,46 @@ static inline size_t scan_tmp_elems(size_t n) {
     }
     return tot + 8;
 }
+// Mid-size scans (2 049 .. 33 792 counters: the bucket tables of a small MSM) in ONE launch: a 1 024-thread workgroup stages the
+// array in LDS (<= 132 KB), every thread scans its own run of `per` words (per odd: conflict-free strides), the thread totals
+// are scanned by shuffles, and the result goes back through LDS.  Three launches (tiles, tile sums, add) otherwise.
+static constexpr uint32_t SCAN_ONE_THREADS = 1024, SCAN_ONE_MAX = 33 * SCAN_ONE_THREADS;
+static __global__ void __launch_bounds__(1024) scan_one_block_kernel(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t per) {
+    extern __shared__ uint32_t scan_sm[];
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < n; i += SCAN_ONE_THREADS) scan_sm[i] = in[i];
+    __syncthreads();
+    const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += scan_sm[i];
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+        if ((t & 63) >= (uint32_t)off) incl += u;
+    }
+    if ((t & 63) == 63) wave_tot[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (t >> 6); w++) base += wave_tot[w];
+    uint32_t run = base + incl - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = scan_sm[i];
+        scan_sm[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += SCAN_ONE_THREADS) out[i] = scan_sm[i];
+}
 // out may alias in
 static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp) {
     if (n == 0) return;
+    static const int one_launch = getenv("SNARKVM_HIP_SCAN1") ? atoi(getenv("SNARKVM_HIP_SCAN1")) : 1;  // A/B switch
+    if (one_launch && n > (size_t)SCAN_TILE && n <= (size_t)SCAN_ONE_MAX) {
+        const uint32_t per = (uint32_t)((n + SCAN_ONE_THREADS - 1) / SCAN_ONE_THREADS) | 1u;
+        hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(SCAN_ONE_THREADS), (size_t)n * 4, st, in, out, (uint32_t)n, per);
+        return;
+    }
     const size_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, tmp, n);
     if (blocks > 1) {

@@ -302,6 +302,7 @@ static void tu_kernel_attributes(int logical) {
     std::lock_guard<std::mutex> lk(mu);
     if ((int)done.size() <= logical) done.resize(logical + 1, 0);
     if (done[logical]) return;
+    HIP_TRY(hipFuncSetAttribute((const void*)scan_one_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCAN_ONE_MAX * 4)));
 #ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 #endif
