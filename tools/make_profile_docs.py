@@ -76,7 +76,7 @@ c = b["cpu_baseline"]
 s += f"| CPU restatement on the same box ({c['cores']} threads of {c['host_cores']}) | MSM {c['value']:.3e} pairs/s, NTT {c['ntt_value']:.3e} elements/s ({c['sample']}) |\n"
 s += f"| GPU / CPU | MSM {b['vs_cpu_baseline']:.0f}x, NTT {b['ntt_vs_cpu_baseline']:.0f}x |\n"
 s += f"| checks run by the bench | " + "; ".join(f"{k}: {v}" for k, v in b["checks"].items()) + " |\n"
-s += "\nRound 1 -> round 2 on the same quantities: MSM 2^24 35.3 -> 33.6-35.1 ms/step (box to box); scalar-read phase 0.28 -> 0.52-0.54 of the HBM\nroofline; synchronous 2^16 MSM 1.06 -> 0.49 ms (17 x 15-bit tables; 0.55 with 16 x 16); `snarkvm_msm` 2^16 4.4 -> 1.5 ms uncached / 0.6 ms cached, 2^24 88.8 -> 60-62 ms\nuncached / 47-49 ms cached; proof-shaped replay 19.2 -> 12.4 ms (one caller), 8.8 ms per proof with 8 callers (113 proofs/s); registration of 2^24 bases\n(12 tables) 1.6 -> 0.6 s.\n\n"
+s += "\nRound 1 -> round 2 on the same quantities: MSM 2^24 35.3 -> 33.6-35.1 ms/step (box to box); scalar-read phase 0.28 -> 0.52-0.54 of the HBM\nroofline; synchronous 2^16 MSM 1.06 -> 0.48 ms (17 x 15-bit tables; 0.54 with 16 x 16); `snarkvm_msm` 2^16 4.4 -> 1.5 ms uncached / 0.6 ms cached, 2^24 88.8 -> 60-62 ms\nuncached / 47-49 ms cached; proof-shaped replay 19.2 -> 12.5 ms (one caller), 8.7-8.9 ms per proof with 8 callers (112-116 proofs/s); registration of 2^24 bases\n(12 tables) 1.6 -> 0.6 s.\n\n"
 s += "Files: `r02_rocprofv3_kernel_stats.txt` (bench.py --steps 3; the `full-size launches` columns leave out the one-point result checks),\n`r02_rocprofv3_kernel_stats_proofs64.txt`, `r02_rocprofv3_pmc_{fetch,write,sq_counters}.txt`, `r02_pmc_traffic.json`, `r02_small_msm_phases.md`,\n`r02_ffi_host_buffers.md`, `r02_size_sweep.md`, `r02_skewed_scalars.md`, `r02_proofs64.md`, `r02_ecbench_alu_ceilings.txt`,\n`r02_microbench_wallclock_calibration.txt`, `r02_alu_ceilings.json`, `r02_accumulate_levers.md`, `r02_pytest_gpu.log`.\n"
 w("r02_summary.md", s)
 print("ok")
