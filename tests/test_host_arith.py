@@ -150,6 +150,8 @@ def test_msm_planner_invariants():
         forced = _plan(1000, window_bits=bits, tables=tables, table_bits=bits)
         assert forced["c"] == bits and forced["wide"] == 1
     assert _plan(1 << 24, tables=12, table_bits=22)["S"] == 128 and _plan(1 << 16, tables=16)["S"] == 16 and _plan(1 << 14, tables=16)["S"] == 4
+    # table-less window choice: c <= 11 (unfolded tail) up to 2^17 points, 16 beyond (the top window stays full)
+    assert _plan(1 << 12)["c"] == 8 and _plan(1 << 16)["c"] == 11 and _plan(1 << 17)["c"] == 11 and _plan((1 << 17) + 1)["c"] == 16 and _plan(1 << 21)["c"] == 16
     # segments fill whole rounds of one wave per SIMD: no 1 088-wave grids on 1 024 SIMDs
     assert _plan(70000, tables=16)["S"] == 18 and _plan(1 << 18, tables=16)["S"] == 64 and _plan(1 << 19, tables=16)["S"] == 64 and _plan((1 << 18) + 5, tables=16)["S"] == 33
     d = _plan(1 << 20, window_bits=13, tables=16)  # request that does not divide the table width: largest divisor below
