@@ -38,6 +38,7 @@ def main():
     print(f"mode: {mode}; chunk lg: {os.environ.get('SNARKVM_HIP_MSM_CHUNK_LG', '21 (default)')}")
     print("| lg n | snarkvm_msm ms (host bases + scalars) | pairs/s | snarkvm_ntt ms (host vector) | elements/s |")
     print("|---|---|---|---|---|")
+    rows_poly = []
     for lg in sizes:
         n = 1 << lg
         plugin.msm(bases[:n], sc[:n])
@@ -54,6 +55,27 @@ def main():
             plugin.NTT(n, y, NTTInputOutputOrder.NN, NTTDirection.Forward if i % 2 == 0 else NTTDirection.Inverse, NTTType.Standard)
         dn = (time.perf_counter() - t0) / reps
         print(f"| {lg} | {dt * 1e3:.2f} | {n / dt:.3e} | {dn * 1e3:.2f} | {n / dn:.3e} |")
+        rows_poly.append((lg, n))
+    # snarkvm_polymul: PolyMultiplier::multiply of k coefficient vectors of n / k elements each on the 2^lg domain (host buffers in,
+    # the full-domain product out); the upload of operand i + 1 overlaps the transform of operand i (polynomial.cuh:136-242)
+    print()
+    print("| lg domain | operands | snarkvm_polymul ms | PCIe bytes (in + out) | effective GB/s |")
+    print("|---|---|---|---|---|")
+    for lg, n in rows_poly:
+        for k in (2, 4):
+            polys = [np.ascontiguousarray(x[i * (n // k): (i + 1) * (n // k)]) for i in range(k)]
+            out = np.zeros((n, 4), dtype=np.uint64)
+            out[:] = 0  # touched pages, like Rust's vec![zero; domain] (lib.rs:126-127); calloc'ed pages fault during the download
+            pp = (ctypes.c_void_p * k)(*[p.ctypes.data for p in polys])
+            pl = (ctypes.c_size_t * k)(*[p.shape[0] for p in polys])
+            call = lambda: _lib.check(L.snarkvm_polymul(ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(k), pp, pl, ctypes.c_size_t(0), None, None, ctypes.c_uint32(lg)))  # noqa: E731
+            call()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                call()
+            dp = (time.perf_counter() - t0) / 3
+            moved = 32 * (n + n)
+            print(f"| {lg} | {k} x 2^{lg} / {k} | {dp * 1e3:.2f} | {moved / 1e6:.0f} MB | {moved / dp / 1e9:.1f} |")
 
 
 if __name__ == "__main__":
