@@ -320,6 +320,19 @@ def main():
             if not np.array_equal(y, x[: 1 << lg]):
                 raise SystemExit(f"bench.py: snarkvm_ntt round trip failed at 2^{lg}")
             ffi[f"snarkvm_ntt_2p{lg}"] = {"ms": d * 1e3, "elements_per_s": (1 << lg) / d}
+        for lg in (16, 20, args.lg_ntt):  # PolyMultiplier::multiply of two coefficient vectors of 2^(lg-1) elements on the 2^lg domain
+            m = 1 << lg
+            ops = [np.ascontiguousarray(x[: m // 2]), np.ascontiguousarray(x[m // 2 : m])]
+            prod = np.zeros((m, 4), dtype=np.uint64)
+            prod[:] = 0  # touched pages, like Rust's vec![zero; domain] (lib.rs:126-127)
+            pp = (ctypes.c_void_p * 2)(*[o.ctypes.data for o in ops])
+            pl = (ctypes.c_size_t * 2)(*[o.shape[0] for o in ops])
+            args_c = (ctypes.c_void_p(prod.ctypes.data), ctypes.c_size_t(2), pp, pl, ctypes.c_size_t(0), None, None, ctypes.c_uint32(lg))
+            _lib.check(L.snarkvm_polymul(*args_c))
+            t0 = time.perf_counter()
+            _lib.check(L.snarkvm_polymul(*args_c))
+            d = time.perf_counter() - t0
+            ffi[f"snarkvm_polymul_2p{lg}"] = {"ms": d * 1e3, "operands": 2, "pcie_bytes": 64 * m}
         ffi["note"] = ("host buffers in and out through the reference's FFI symbols; MSM first_call = unknown base range (2.4 GB over PCIe at 2^24, "
                        "overlapped with the computation in 2^21-pair chunks), steady_state = the range was passed before and lives in HBM with precomputed tables")
         extra["end_to_end_ffi"] = ffi

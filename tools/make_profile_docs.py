@@ -26,6 +26,7 @@ b = last_json("bench_default.json")
 ffi = b["end_to_end_ffi"]
 rows = "".join(f"| {k} | {v['first_call_ms']:.2f} ({', '.join(f'{x:.2f}' for x in v['first_call_ms_samples'])}) | {v['steady_state_ms']:.2f} |\n" for k, v in ffi.items() if k.startswith("snarkvm_msm"))
 rown = "".join(f"| {k} | {v['ms']:.2f} | {v['elements_per_s']:.3e} |\n" for k, v in ffi.items() if k.startswith("snarkvm_ntt"))
+rown += "".join(f"| {k} (2 operands) | {v['ms']:.2f} | {v['pcie_bytes'] / v['ms'] / 1e6:.1f} GB/s of PCIe payload |\n" for k, v in ffi.items() if k.startswith("snarkvm_polymul"))
 w("r02_ffi_host_buffers.md", "# Round 2 - the reference's FFI symbols end to end (host buffers in, host buffers out), one MI355X\n\n"
   "## `tools/bench_ffi.py`, base cache off: upload + conversion + table-less MSM on every call\n\n" + clean("ffi_uncached.md") +
   "\nRound 1: 2^16 4.4 ms, 2^24 88.8 ms.  At 2^24 the 2^21-pair chunks go through a three-lane ring fed by an uploader thread\n"
