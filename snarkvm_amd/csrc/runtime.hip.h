@@ -475,15 +475,12 @@ struct msm_accum_t {
     }
     // total = sum_p 2^p at[p], Jacobian memory image (the reference's Projective; infinity = (0, 1, 0))
     void finish(void* out) const {
-        jac_t<F> j = {F::zero(), F::one(), F::zero()};
+        xyzz_t<F> t = xyzz_t<F>::inf();  // the chain stays in XYZZ (9 products per doubling, 14 per addition, no conversions)
         for (int p = top; p >= 0; p--) {
-            j = j.dbl();  // 2M + 5S (projective.rs:302-339)
-            if (used[p]) {
-                xyzz_t<F> t = xyzz_t<F>::from_jacobian(j);
-                t.add(at[p]);
-                j = t.to_jacobian();
-            }
+            t = t.dbl();
+            if (used[p]) t.add(at[p]);
         }
+        const jac_t<F> j = t.to_jacobian();
         uint32_t w[3 * F::MEM_WORDS];
         j.x.to_raw_words(w);
         j.y.to_raw_words(w + F::MEM_WORDS);
