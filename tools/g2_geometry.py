@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""G2 MSM of 2^16 pairs over registered bases for several table geometries (tables x window bits): 17 x 15 wins (2^14 buckets:
+the fold is one round), which is what snarkvm_amd/proofs.py registers."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from snarkvm_amd import synthetic
 from snarkvm_amd.msm import RegisteredBasesG2

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Synchronous G1 MSM latency over registered bases (16 x 16-bit tables) at sizes between the powers of two: the accumulate
+segment length fills whole rounds of one wave per SIMD, so the curve has no steps (profiles/r02_size_sweep.md)."""
 import ctypes, sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from snarkvm_amd import _lib, synthetic
 from snarkvm_amd.layout import G1_AFFINE
