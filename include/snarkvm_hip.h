@@ -43,7 +43,7 @@ enum NTTType { Standard = 0, Coset = 1 };                    /* lib.rs:36-40 */
  * Montgomery form, host memory).  NN/Forward/Standard == EvaluationDomain::fft_in_place;
  * Inverse includes the 1/n scaling; Forward+Coset multiplies x[j] by 22^j first; Inverse+Coset
  * multiplies the result by 22^-j (fft/domain.rs:201-206, 403-443).  Returns an error for
- * lg_domain_size > 24 (the caller then uses its CPU path). */
+ * lg_domain_size > 26 (the caller then uses its CPU path). */
 RustError snarkvm_ntt(void *inout, uint32_t lg_domain_size, enum NTTInputOutputOrder ntt_order,
                       enum NTTDirection ntt_direction, enum NTTType ntt_type);
 
@@ -63,12 +63,16 @@ RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoint
 /* Multi-GPU: like the reference (snarkvm.cu:254-295) a call of >= 2^19 pairs is cut into point-range chunks that are dealt
  * to every selected device (and to two lanes per device, so that the upload of one chunk overlaps the computation of the
  * previous one); the per-chunk partial results are combined on the host.
- * Base cache: a host base range passed a SECOND time is kept in HBM (converted, with precomputed tables - 17 x 15-bit below 2^18 points, 16 x 16, 13 x 20 from 2^21, 12 x 22 from 2^23 - on every device)
- * and later calls whose bases are a slice of it skip upload and conversion - the reference's callers always pass slices of
- * one long-lived `powers_of_beta_g` vector (kzg10/mod.rs:117-119).  A hit is verified against raw copies of every 64th point
- * of the slice; the memory behind a cached range must not be mutated in between at other positions.  Results are unchanged.
- * SNARKVM_HIP_BASE_CACHE=0 disables it (=1/2/4/8/16 selects the table count), SNARKVM_HIP_BASE_CACHE_MB caps the HBM bytes per
- * device (default 65536). */
+ * Ownership: like the reference's symbol the call is STATELESS - `points_with_infinity` and `scalars` are only read during the
+ * call and nothing about them is retained after return.
+ * Opt-in extension (off unless SNARKVM_HIP_BASE_CACHE=1/2/4/8/16 is set in the environment): a host base range passed a SECOND
+ * time with the same address and length is kept in HBM (converted, with precomputed tables - 17 x 15-bit below 2^18 points,
+ * 16 x 16, 13 x 20 from 2^21, 12 x 22 from 2^23 - on every device) and later calls whose bases are a slice of it skip upload
+ * and conversion - the reference's callers always pass slices of one long-lived `powers_of_beta_g` vector
+ * (kzg10/mod.rs:117-119).  By setting the variable the caller promises that such vectors are immutable while the process
+ * uses them (a hit is verified against raw copies of every 64th point of the slice, which cannot catch every mutation);
+ * host memory is only read inside the slice the current call passed.  SNARKVM_HIP_BASE_CACHE_MB caps the HBM bytes per device
+ * (default 65536).  Code that can be changed should call snarkvm_hip_register_bases* + snarkvm_hip_msm_registered*. */
 
 /* ---------------------------------------------------------------------------------------------
  * Part 2 - extension ABI (device-resident data, SRS registration, instrumentation)

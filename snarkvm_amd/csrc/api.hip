@@ -320,20 +320,27 @@ RustError snarkvm_hip_msm_registered_batch_ex(void* outs, const snarkvm_hip_base
 }
 
 // ---- the reference's FFI MSM (host bases + host scalars) -----------------------------------------------------------------
-// Base cache behind the unmodified FFI.  The reference's callers pass slices of ONE long-lived vector
-// (`powers_of_beta_g[lz .. lz + len]`, kzg10/mod.rs:117-119) and its GPU path re-uploads them on every call.  Here a host
-// range that is seen a SECOND time is registered (converted, with precomputed tables, on every device) and later calls
-// whose base range lies inside it skip the upload, the conversion and most of the Horner chain.  A hit is verified against
-// raw copies of every CACHE_STEP-th point of the range that falls inside the requested slice (a slice > 1024 points always
-// contains at least 16 of them); a mismatch drops the entry.  Host pointers are only compared, never dereferenced outside
-// the call that passed them.  SNARKVM_HIP_BASE_CACHE=0 turns it off, =<tables> selects 1 / 2 / 4 / 8 / 16 tables;
+// `snarkvm_msm` is STATELESS by default, like the reference's symbol (the callee must not retain the caller's
+// pointers): bases and scalars are uploaded, converted and summed on every call and nothing is remembered after return.
+//
+// Opt-in base cache (SNARKVM_HIP_BASE_CACHE=1 / 2 / 4 / 8 / 16; an EXTENSION with its own contract): the
+// reference's callers pass slices of ONE long-lived vector (`powers_of_beta_g[lz .. lz + len]`, kzg10/mod.rs:117-119).  With
+// the cache on, a host range that is passed a SECOND time - the same address and length - is registered (converted, with
+// precomputed tables, on every device) from the memory of THAT call, and later calls whose base range lies inside it skip
+// the upload, the conversion and most of the Horner chain.  A hit is verified against raw copies of every CACHE_STEP-th
+// point of the requested slice (a slice > 1024 points always contains at least 16 of them); a mismatch drops the entry.  The
+// contract the caller accepts by setting the variable: the vector is immutable and outlives the process's use of it (true
+// of an SRS; not checkable from here).  Host memory is only ever read inside the slice the current call passed.  A
+// registration that fails (HBM exhausted) marks the entry do-not-retry and the call takes the stateless path.
 // SNARKVM_HIP_BASE_CACHE_MB caps the device bytes per device (default 65536); least recently used ranges go first.
+// Callers that can change their code should use snarkvm_hip_register_bases* + snarkvm_hip_msm_registered* instead.
 struct base_cache_entry {
     const uint8_t* host = nullptr;
     size_t n = 0, stride = 0;
     std::shared_ptr<snarkvm_hip_bases> h;  // null: seen once, not registered yet (shared: a running call keeps a dropped entry's tables alive)
     std::vector<uint8_t> samples;     // 97 bytes (x, y, infinity) of points 0, CACHE_STEP, 2 * CACHE_STEP, ...
     uint64_t last_use = 0;
+    bool failed = false;              // registration failed once (out of memory): never retried
     size_t bytes() const { return h ? (size_t)h->tables * h->n * sizeof(g1_aff_mem_t) : 0; }
 };
 static constexpr size_t CACHE_STEP = 64, CACHE_MAX = 8;
@@ -341,7 +348,7 @@ static std::mutex g_cache_mu;
 static std::vector<base_cache_entry> g_base_cache;
 static uint64_t g_cache_tick = 0;
 static int base_cache_tables() {
-    static const int t = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 16;
+    static const int t = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 0;  // off unless asked for
     return (t == 1 || t == 2 || t == 4 || t == 8 || t == 16) ? t : 0;
 }
 static size_t base_cache_cap() {
@@ -372,11 +379,11 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
             break;
         }
         g_base_cache[i].last_use = ++g_cache_tick;
-        if (!g_base_cache[i].h) {  // second sighting: register the whole remembered range (all of it is verified first)
-            if (!samples_match(g_base_cache[i], 0, g_base_cache[i].n)) {
-                base_cache_drop(i);
-                break;
-            }
+        if (!g_base_cache[i].h) {
+            // second sighting.  Only the memory of THIS call may be read: the range is registered when the call passes exactly
+            // the remembered range (every sample of it was just verified above); a sub-slice of a range that is not registered
+            // yet takes the stateless path.
+            if (g_base_cache[i].failed || off != 0 || npoints != g_base_cache[i].n) return nullptr;
             // table geometry by size, as measured (profiles/r02_size_sweep.md): 12 x 22-bit windows from 2^23 points, 13 x 20-bit from
             // 2^21, 17 x 15-bit below 2^18 (half the buckets of 16 x 16: the whole fold is one round of 256 workgroups), else the
             // configured count of 256 / tables-bit tables
@@ -397,8 +404,13 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
                 if (lru < i) i--;
             }
             snarkvm_hip_bases_t* nh = nullptr;
-            // throws on failure: nothing leaks, the entry stays unregistered
-            register_bases_impl(&nh, g_base_cache[i].host, g_base_cache[i].n, g_base_cache[i].stride, 0, tables, bits);
+            try {
+                register_bases_impl(&nh, points, npoints, stride, 0, tables, bits);
+            } catch (...) {  // nothing leaks (register_bases_impl frees its replicas); this call and later ones go stateless
+                (void)hipGetLastError();
+                g_base_cache[i].failed = true;
+                return nullptr;
+            }
             g_base_cache[i].h = std::shared_ptr<snarkvm_hip_bases>(nh, [](snarkvm_hip_bases* b) { snarkvm_hip_free_bases(b); });
         }
         offset = off;

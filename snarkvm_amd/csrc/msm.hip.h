@@ -7,22 +7,18 @@
 // reference's, the affine normalisation is identical (that is what the reference's tests compare,
 // variable_base/mod.rs:96-105,116-117).
 //
-// Pipeline (all on device, one stream; sizes for n = 2^24, c = 16):
-//   1 digits    scalar-read phase: each 32-byte scalar is read once (coalesced, staged through LDS) and
-//               recoded into W = ceil(254/c) signed c-bit digits with the bias trick
-//               (s' = s + sum_w 2^(c-1+cw); digit_w = ((s' >> cw) & (2^c-1)) - 2^(c-1)), written as u16
-//               [W][n].  HBM-bound: 32n B read + 2Wn B written.
-//   2 histogram per (chunk, window) workgroup: LDS histogram of 2^(c-1) bucket counters, no global atomics.
-//   3 rank      per bucket: exclusive prefix of its counts over the chunks (-> rank of each chunk's run) + size.
-//   4 scatter   per (chunk, window): LDS scan + cursors; writes point index | sign<<31 grouped by bucket into the
-//               workgroup's private region (chunk-major layout: a bucket's entries are nchunks short runs).
-//   5 accumulate  each bucket gets ceil(size/S) threads; a thread adds <= S points (gathered 96-byte
-//               affine bases, XYZZ mixed addition) and writes a partial sum.  Balanced for any scalar
-//               distribution; ALU-bound (~10 Fq multiplications per point).
-//   6 reduce    rounds of the same kernel over the partials (ceil(count/S2) threads per bucket) until one
-//               sum per bucket is left.
-//   7 bucket reduction  sum_b (b+1) B_b per window by chunked running sums, chunk offset applied with a
-//               small double-and-add; 8 window sum (LDS tree); 9 Horner across windows -> Jacobian.
+// Pipeline (all on one stream of one lane; runtime.hip.h::msm_run enqueues it, DESIGN.md 3.2 has the sizes):
+//   1 scalar read   wide windows (c > 16, registered tables): radix_hist1_fused_kernel (msm_sort.hip.h) reads every 32-byte
+//               scalar once, recodes it in registers into signed c-bit digits with the bias trick
+//               (s' = s + sum_w 2^(c-1+cw); digit_w = ((s' >> cw) & (2^c-1)) - 2^(c-1)) and counts level-1 bins in LDS -
+//               no digit matrix exists.  c <= 16: msm_digits_kernel writes u16 digits [rows][n].
+//   2-4 sort    LDS-staged radix partition of the (index | sign, bucket) entries: two levels, three for wide windows
+//               (msm_sort.hip.h); output is bucket-major `sorted` + bucket offsets `boff`.
+//   5 accumulate  msm_accumulate_seg_kernel: balanced segments - thread t owns S consecutive sorted entries, gathers the
+//               bases, XYZZ mixed additions, one partial sum per bucket touched.  Integer-ALU bound.
+//   6 reduce    msm_reduce_kernel rounds (only for > 2^22 digit entries): partial sums per bucket -> <= tail_partials.
+//   7 fold + bit planes  msm_fold_kernel (two-axis row / column sums of a window), msm_bitplane_kernel (sum_i (i+1) P_i as
+//               sum_j 2^j S_j); 8 the Horner chain over <= ~270 bit-plane sums runs on the host (runtime.hip.h msm_accum_t).
 // Digit zero is skipped (batched.rs:350: bucket index wraps to u32::MAX and is ignored).
 #pragma once
 #include <stdlib.h>

@@ -61,6 +61,12 @@ static RustError from_failure(const hip_failure& f) {
     return fail((int)f.e, buf);
 }
 
+static double host_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 // ------------------------------------------------------------------------------------------------
 // runtime: devices, lanes (the reference's (dev, stream) resource tokens), staging buffers
 // ------------------------------------------------------------------------------------------------
@@ -145,6 +151,7 @@ struct lane_t {
     inline void begin_call();
     inline void phase_begin(const char* name);
     inline void phase_end();
+    inline void phase_host(const char* name, double ms);
     inline void end_call();
 };
 
@@ -344,10 +351,16 @@ struct lane_guard {
             if (!d) d = g_rt.devs[s % nd].get();
         }
         if (!n) n = d->take(got, want);
+        try {  // a failure below must not leak the tokens: the destructor of a throwing constructor never runs
+            HIP_TRY(hipSetDevice(d->physical));
+            d->init();
+            tu_kernel_attributes(d->logical);
+        } catch (...) {
+            for (int i = 0; i < n; i++) d->give(got[i]);
+            if (prev_device >= 0) (void)hipSetDevice(prev_device);
+            throw;
+        }
         for (int i = 0; i < n; i++) lanes.push_back(got[i]);
-        HIP_TRY(hipSetDevice(d->physical));
-        d->init();
-        tu_kernel_attributes(d->logical);
     }
     lane_t& c() { return *lanes[0]; }
     ~lane_guard() {
@@ -371,6 +384,10 @@ inline void lane_t::phase_end() {
     if (!g_rt.profiling.load(std::memory_order_relaxed) || phases.empty()) return;
     HIP_TRY(hipEventRecord(phases.back().e1, stream));
 }
+inline void lane_t::phase_host(const char* name, double ms) {  // a phase that ran on the calling thread (no events)
+    if (!g_rt.profiling.load(std::memory_order_relaxed)) return;
+    phases.push_back(phase_rec{name, nullptr, nullptr, ms});
+}
 static void ntt_tw_release(device_t* dev, std::vector<void*>& leases) { ntt_tw_release_entries(dev->tw, leases); }
 inline void lane_t::end_call() {
     if (!tw_leases.empty()) {
@@ -381,10 +398,12 @@ inline void lane_t::end_call() {
     HIP_TRY(hipStreamSynchronize(stream));
     std::vector<std::pair<std::string, double>> out;
     for (auto& r : phases) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
-        r.ms = ms;
-        out.emplace_back(r.name, (double)ms);
+        if (r.e0) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+            r.ms = ms;
+        }
+        out.emplace_back(r.name, r.ms);
     }
     std::lock_guard<std::mutex> lk(g_rt.prof_mu);
     g_rt.last_phases.swap(out);
@@ -750,8 +769,11 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
-            // timing experiment only (wrong results): restrict the gather to the first 2^k bases to separate ALU time from HBM gather time
+#ifdef SV_BENCH  // profiling builds only (wrong results): restrict the gather to the first 2^k bases to separate ALU time from HBM gather time
             static const uint32_t dbg_mask = getenv("SNARKVM_HIP_DEBUG_IDX_MASK") ? (uint32_t)strtoul(getenv("SNARKVM_HIP_DEBUG_IDX_MASK"), nullptr, 0) : 0xffffffffu;
+#else
+            constexpr uint32_t dbg_mask = 0xffffffffu;
+#endif
             // (a 3-waves-per-SIMD build of this kernel - 168 VGPRs - and a software-pipelined gather were measured: no gain)
             static const int prefetch_env = getenv("SNARKVM_HIP_PREFETCH") ? atoi(getenv("SNARKVM_HIP_PREFETCH")) : 1;
             if (single_round && prefetch_env)
@@ -820,12 +842,12 @@ static void msm_run_sync(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_
     c.pin.ensure(msm_plane_bytes<F>());
     const msm_pending_t pd = msm_run<F>(c, d_bases, d_scalars, n, c.pin.p, window_bits, d_bases1, n0, scalars_montgomery, tables, table_stride, true, table_bits);
     HIP_TRY(hipStreamSynchronize(c.stream));
-    c.phase_begin("msm_host_finish");
-    c.phase_end();
+    const double t0 = host_now_ms();
     msm_accum_t<F>* acc = new msm_accum_t<F>();
     std::unique_ptr<msm_accum_t<F>> hold(acc);
     msm_collect<F>(*acc, pd);
     acc->finish(out);
+    c.phase_host("msm_host_finish", host_now_ms() - t0);  // the Horner chain over the bit planes, on the calling thread
 }
 
 template <class F>
@@ -871,11 +893,6 @@ static size_t msm_chunk_pairs() {  // pairs per upload / compute chunk of an MSM
 static size_t msm_scalar_chunk_pairs() {
     static const int lg = getenv("SNARKVM_HIP_SCALAR_CHUNK_LG") ? atoi(getenv("SNARKVM_HIP_SCALAR_CHUNK_LG")) : 22;
     return (size_t)1 << (lg < 18 ? 18 : lg > 30 ? 30 : lg);
-}
-static double host_now_ms() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
 // `count` chunks of one call on the lanes of `lg` (a ring: chunk j uses lane j mod L).  A dedicated uploader thread runs

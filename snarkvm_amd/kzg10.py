@@ -77,8 +77,36 @@ class KZGRandomness:
     def empty(cls):
         return cls()
 
+    @staticmethod
+    def calculate_hiding_polynomial_degree(hiding_bound):  # data_structures.rs:340-343
+        return hiding_bound + 1
+
+    @classmethod
+    def rand(cls, hiding_bound, rng):
+        """data_structures.rs:351-356 -> DensePolynomial::rand(hiding_bound + 1) (fft/polynomial/dense.rs:120-127): a polynomial
+        of DEGREE hiding_bound + 1, i.e. hiding_bound + 2 uniformly random coefficients, the leading one re-sampled while it
+        is zero.  `rng(k)` returns k random Fr elements as (k, 4) Montgomery limbs."""
+        d = cls.calculate_hiding_polynomial_degree(hiding_bound)
+        c = np.array(rng(d + 1), dtype=np.uint64, copy=True).reshape(-1, 4)
+        if c.shape[0] != d + 1:
+            raise PCError(f"rng returned {c.shape[0]} elements, {d + 1} requested")
+        while not c[d].any():  # "In the extremely unlikely event, sample again."
+            c[d] = np.asarray(rng(1), dtype=np.uint64).reshape(-1, 4)[0]
+        return cls(np.ascontiguousarray(c))
+
+    def degree(self):
+        return max(self.blinding_polynomial.shape[0] - 1, 0)
+
     def is_hiding(self):  # data_structures.rs:335-337: the blinding polynomial is non-zero
         return bool(np.asarray(self.blinding_polynomial).any())
+
+
+def check_hiding_bound(hiding_poly_degree, num_powers):
+    """kzg10/mod.rs:417-427: committing to a hiding polynomial of degree d needs d + 1 powers of beta * gamma * G."""
+    if hiding_poly_degree == 0:
+        raise PCError("HidingBoundIsZero")
+    if hiding_poly_degree >= num_powers:
+        raise PCError(f"HidingBoundToolarge: hiding_poly_degree {hiding_poly_degree}, num_powers {num_powers}")
 
 
 class KZGProof:
@@ -113,11 +141,8 @@ class KZG10:
         if hiding_bound is not None:
             if rng is None:
                 raise PCError("MissingRng")
-            # KZGRandomness::rand(hiding_degree, false, rng) samples hiding_degree + 1 coefficients (data_structures.rs:344-350)
-            randomness = KZGRandomness(np.ascontiguousarray(rng(hiding_bound + 1), dtype=np.uint64).reshape(-1, 4))
-            deg = randomness.blinding_polynomial.shape[0] - 1
-            if deg + 1 > powers.powers_of_beta_times_gamma_g.shape[0]:  # check_hiding_bound (mod.rs:417-427)
-                raise PCError("HidingBoundToolarge")
+            randomness = KZGRandomness.rand(hiding_bound, rng)  # degree hiding_bound + 1 (data_structures.rs:351-356)
+            check_hiding_bound(randomness.degree(), powers.powers_of_beta_times_gamma_g.shape[0])  # mod.rs:138-141
         blind = randomness.blinding_polynomial
         scalars = np.concatenate([plain, blind]) if blind.shape[0] else plain
         out = np.zeros(1, dtype=G1_PROJECTIVE)
@@ -147,10 +172,9 @@ class KZG10:
         if hiding_bound is not None:
             if rng is None:
                 raise PCError("MissingRng")
-            randomness = KZGRandomness(np.ascontiguousarray(rng(hiding_bound + 1), dtype=np.uint64).reshape(-1, 4))
+            randomness = KZGRandomness.rand(hiding_bound, rng)
             k = randomness.blinding_polynomial.shape[0]
-            if k > powers.powers_of_beta_times_gamma_g.shape[0]:
-                raise PCError("HidingBoundToolarge")
+            check_hiding_bound(randomness.degree(), powers.powers_of_beta_times_gamma_g.shape[0])
             blind = torch.from_numpy(randomness.blinding_polynomial.view(np.uint8).reshape(-1).copy()).to(flat.device)
             flat = torch.cat([flat, blind])
         torch.cuda.current_stream().synchronize()  # the library runs on its own stream
@@ -176,7 +200,8 @@ class KZG10:
         if hiding_bound is not None:
             if rng is None:
                 raise PCError("MissingRng")
-            randomness = KZGRandomness(np.ascontiguousarray(rng(hiding_bound + 1), dtype=np.uint64).reshape(-1, 4))
+            randomness = KZGRandomness.rand(hiding_bound, rng)  # mod.rs:186-192
+            check_hiding_bound(randomness.degree(), lagrange_basis.powers_of_beta_times_gamma_g.shape[0])
         blind = randomness.blinding_polynomial
         scalars = np.concatenate([evaluations, blind]) if blind.shape[0] else evaluations
         out = np.zeros(1, dtype=G1_PROJECTIVE)

@@ -188,9 +188,8 @@ class SonicKZG10:
             if p.hiding_bound is not None:
                 if rng is None:
                     raise PCError("MissingRng")
-                randomness = KZGRandomness(np.ascontiguousarray(rng(p.hiding_bound + 1), dtype=np.uint64).reshape(-1, 4))  # data_structures.rs:344-350
-                if randomness.blinding_polynomial.shape[0] > view.gamma_n:  # check_hiding_bound (kzg10/mod.rs:417-427)
-                    raise PCError("HidingBoundToolarge")
+                randomness = KZGRandomness.rand(p.hiding_bound, rng)  # degree hiding_bound + 1 (data_structures.rs:351-356)
+                kzg10.check_hiding_bound(randomness.degree(), view.gamma_n)  # kzg10/mod.rs:417-427
             blind = randomness.blinding_polynomial
             off0.append(view.off + lz)
             n0.append(plain.shape[0])

@@ -96,7 +96,7 @@ print("MULTI_OK")
 
 
 def test_two_logical_devices_end_to_end():
-    env = dict(os.environ, SNARKVM_HIP_DEVICES="0,0")
+    env = dict(os.environ, SNARKVM_HIP_DEVICES="0,0", SNARKVM_HIP_BASE_CACHE="16")  # the opt-in base cache: its multi-device path stays covered
     script = SCRIPT % (util.ROOT, os.path.join(util.ROOT, "tests", "golden", "beta_h_g2.bin"))
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=1200, cwd=util.ROOT)
     assert "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
@@ -189,7 +189,7 @@ print("RING_OK")
 def test_chunk_ring_single_device():
     """The pipelined host-buffer paths at test size: SNARKVM_HIP_MSM_CHUNK_LG=16 cuts a 2^19 `snarkvm_msm` into 9 chunks over
     the three-lane ring (runtime.hip.h::lane_ring_run), SNARKVM_HIP_SCALAR_CHUNK_LG=18 cuts the cached call's scalars into 3."""
-    env = dict(os.environ, SNARKVM_HIP_DEVICES="0", SNARKVM_HIP_MSM_CHUNK_LG="16", SNARKVM_HIP_SCALAR_CHUNK_LG="18")
+    env = dict(os.environ, SNARKVM_HIP_DEVICES="0", SNARKVM_HIP_MSM_CHUNK_LG="16", SNARKVM_HIP_SCALAR_CHUNK_LG="18", SNARKVM_HIP_BASE_CACHE="16")
     script = RING_SCRIPT % (util.ROOT, os.path.join(util.ROOT, "tests", "golden", "beta_h_g2.bin"))
     r = subprocess.run([sys.executable, "-u", "-c", script], capture_output=True, text=True, env=env, timeout=1200, cwd=util.ROOT)
     assert "RING_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -66,15 +66,20 @@ def test_ntt_all_orders(lg):
             assert np.array_equal(got, oracle.ntt(x, order, d, oracle.STANDARD)), (lg, order, d)
 
 
-@pytest.mark.parametrize("lg", [20, 22])
+@pytest.mark.parametrize("lg", [20, 21, 22, 23])
 def test_ntt_large_vs_oracle(lg):
+    """BASELINE configs[2] (domain sizes 2^18 - 2^24): every size of the range that the lg 0..19 sweep above and the 2^24 test
+    below do not cover - pass splits 7+7+6, 7+7+7, 8+7+7, 8+8+7 - every element of all four transforms against the oracle,
+    like the reference's own sweep (fft/domain.rs:1140-1218), plus the round trips."""
     n = 1 << lg
     x = _fr_vec(n, 300 + lg)
-    got = x.copy()
-    plugin.NTT(n, got, NTTInputOutputOrder.NN, NTTDirection.Forward, NTTType.Standard)
-    assert np.array_equal(got, oracle.ntt(x))
-    plugin.NTT(n, got, NTTInputOutputOrder.NN, NTTDirection.Inverse, NTTType.Standard)
-    assert np.array_equal(got, x)
+    for d in (NTTDirection.Forward, NTTDirection.Inverse):
+        for t in (NTTType.Standard, NTTType.Coset):
+            got = x.copy()
+            plugin.NTT(n, got, NTTInputOutputOrder.NN, d, t)
+            assert np.array_equal(got, oracle.ntt(x, oracle.ORDER_NN, d, t)), (lg, d, t)
+            plugin.NTT(n, got, NTTInputOutputOrder.NN, NTTDirection.Inverse if d == NTTDirection.Forward else NTTDirection.Forward, t)
+            assert np.array_equal(got, x), (lg, d, t, "round trip")
 
 
 def test_ntt_2_24_properties():
@@ -391,6 +396,72 @@ def test_msm_2_24_wide_closed_form():
     rb.close()
 
 
+def _pseudo_random_bases(n, seed):
+    """P_i = k_i G with k_i uniform in [0, r) (SplitMix64 stream): unstructured bases like the reference's differential test
+    (msm/variable_base/mod.rs:109-119 samples random points), built on the device by FixedBase::msm (group.hip.h) and
+    normalised by the device's batch to_affine.  Returns (Rust-layout affine bases, k as Fr Montgomery limbs)."""
+    from snarkvm_amd import group, kzg10
+
+    k = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, seed))
+    tab = group.FixedBase.get_window_table(253, 8, util.g1_generator_affine())
+    return kzg10.to_affine(group.FixedBase.msm(253, 8, tab, k)), k
+
+
+def _inner_product_mod_r(a_mont, b_mont):
+    """sum_i a_i b_i in Fr for two (n, 4) Montgomery vectors -> canonical (1, 4) limbs (oracle field ops, tree sum)."""
+    p = oracle.fr_op("mul", np.ascontiguousarray(a_mont), np.ascontiguousarray(b_mont))
+    while p.shape[0] > 1:
+        if p.shape[0] & 1:
+            p = np.vstack([p, np.zeros((1, 4), dtype=np.uint64)])
+        p = oracle.fr_op("add", np.ascontiguousarray(p[0::2]), np.ascontiguousarray(p[1::2]))
+    return oracle.fr_op("to_bigint", p)
+
+
+def test_msm_2_20_pseudo_random_bases():
+    """BASELINE configs[1] size 2^20 on UNSTRUCTURED bases P_i = k_i G: sum_i s_i P_i = (sum_i s_i k_i mod r) G.  Removes the
+    dependence of every large-size check on the one base family (i + 1) G.  Table-less FFI path (host buffers, chunked),
+    registered 16 x 16-bit tables, and the oracle's batched::msm on a 2^16 slice of the same vectors."""
+    n = 1 << 20
+    bases, k = _pseudo_random_bases(n, 0xBA5E5)
+    # sanity of the construction itself against the oracle (first points)
+    first = oracle.g1_to_affine(np.concatenate([oracle.g1_mul(util.g1_generator_affine(), oracle.fr_op("to_bigint", k[i:i + 1])[0]) for i in range(4)]))
+    assert util.affine_equal(bases[:4], first)
+    sc = synthetic.random_fr_integers(n, 0x5CA1A)
+    want = oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), _inner_product_mod_r(oracle.fr_op("from_bigint", sc), k)[0]))
+    assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(bases, sc)), want)
+    rb = RegisteredBases(bases, tables=16)
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc)), want)
+    m = 1 << 16
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc[:m])), oracle.g1_to_affine(oracle.g1_msm(bases[:m], sc[:m], oracle.MSM_BATCHED)))
+    rb.close()
+
+
+def test_msm_2_22_own_plan_closed_form():
+    """2^22 pairs over the plan that size gets (13 tables x 20-bit windows, three sort levels, S = 64, reduce rounds) - the
+    geometry was only exercised at n = 40 000 before.  Uniform and witness-like scalars, closed form over bases (i + 1) G; and
+    pseudo-random bases through the same geometry at 2^21."""
+    import torch
+
+    n = 1 << 22
+    buf = _device_bases(n, start=1)
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=13, window_bits=20)
+    del buf
+    for sc in (synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE + 22), synthetic.witness_like_scalars(n, 2222)):
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        got = rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
+        kk = util.weighted_sum_mod_r(sc, start=1)
+        assert util.affine_equal(oracle.g1_to_affine(got), oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), util.limbs(kk, 4))))
+    rb.close()
+    m = 1 << 21
+    bases, k = _pseudo_random_bases(m, 0xBA5E6)
+    sc = synthetic.random_fr_integers(m, 0x5CA1B)
+    rb = RegisteredBases(bases, tables=13, window_bits=20)
+    want = oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), _inner_product_mod_r(oracle.fr_op("from_bigint", sc), k)[0]))
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc)), want)
+    rb.close()
+
+
 # ------------------------------------------------------------------------------------------ G2
 def _g2_bases(golden, n):
     from oracle import cpu as o
@@ -457,13 +528,15 @@ def test_kzg10_commit_matches_reference_formula(golden):
     coeffs = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 4242))
     coeffs[:37] = 0                                              # leading zeros are skipped (mod.rs:455-467)
     coeffs[100] = 0
-    blind = oracle.fr_op("from_bigint", synthetic.random_fr_integers(3, 99))
+    blind = oracle.fr_op("from_bigint", synthetic.random_fr_integers(4, 99))
     for hiding in (None, 2):
         comm, rand = kzg10.KZG10.commit(pw, coeffs, hiding, (lambda k: blind[:k]) if hiding is not None else None)
         want = oracle.g1_msm(powers_g[37:], oracle.fr_op("to_bigint", coeffs[37:]), oracle.MSM_BATCHED)
         if hiding is not None:
-            assert rand.blinding_polynomial.shape[0] == hiding + 1
-            want = oracle.g1_add(want, oracle.g1_msm(gamma_g, oracle.fr_op("to_bigint", blind[: hiding + 1]), oracle.MSM_BATCHED))
+            # KZGRandomness::rand -> DensePolynomial::rand(hiding + 1): degree hiding + 1, hiding + 2 coefficients
+            # (kzg10/data_structures.rs:351-356, fft/polynomial/dense.rs:120-127)
+            assert rand.blinding_polynomial.shape[0] == hiding + 2
+            want = oracle.g1_add(want, oracle.g1_msm(gamma_g[: hiding + 2], oracle.fr_op("to_bigint", blind[: hiding + 2]), oracle.MSM_BATCHED))
         assert util.affine_equal(oracle.g1_to_affine(comm), oracle.g1_to_affine(want))
         # device-side `From<Projective> for Affine` agrees with the oracle's normalisation
         assert util.affine_equal(kzg10.to_affine(comm), oracle.g1_to_affine(want))
@@ -492,11 +565,11 @@ def test_varuna_proof_shaped_workload(golden):
         return oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, seed))
 
     def check_commit(coeffs, hiding, seed):
-        blind = rnd(3, seed)
+        blind = rnd(4, seed)
         comm, _ = kzg10.KZG10.commit(pw, coeffs, hiding, (lambda k: blind[:k]) if hiding is not None else None)
         want = oracle.g1_msm(powers_g[: coeffs.shape[0]], oracle.fr_op("to_bigint", coeffs), oracle.MSM_BATCHED)
         if hiding is not None:
-            want = oracle.g1_add(want, oracle.g1_msm(gamma_g, oracle.fr_op("to_bigint", blind[: hiding + 1]), oracle.MSM_BATCHED))
+            want = oracle.g1_add(want, oracle.g1_msm(gamma_g[: hiding + 2], oracle.fr_op("to_bigint", blind[: hiding + 2]), oracle.MSM_BATCHED))
         assert util.affine_equal(oracle.g1_to_affine(comm), oracle.g1_to_affine(want))
 
     def check_ntt(x, direction, kind=NTTType.Standard):
@@ -594,8 +667,9 @@ def test_g2_registered_tables_vs_oracle(golden, tables, window_bits):
 
 
 def test_ffi_base_cache_is_transparent(tmp_path):
-    """SNARKVM_HIP_BASE_CACHE: the unmodified `snarkvm_msm` FFI reusing device copies of base ranges it has seen - same
-    results for repeated calls, sub-slices with an offset, a superseding bigger range, and memory that changed in place."""
+    """SNARKVM_HIP_BASE_CACHE (opt-in extension; `snarkvm_msm` is stateless without it): the FFI reusing device copies of base
+    ranges it has seen - same results for repeated calls, sub-slices with an offset, a superseding bigger range, and memory
+    that changed in place.  Registration only ever reads the slice the registering call passed."""
     import subprocess
     import sys
 
@@ -617,7 +691,9 @@ check(bases[:9000], sc[:9000])          # hit
 check(bases[100:5100], sc[:5000])       # hit with an offset that is not a sampled position
 check(bases[1:1100], sc[:1099])         # short slice between sampled positions: still >= 16 samples inside
 check(bases, sc)                        # bigger range supersedes the first one (first sighting again)
-check(bases[4096:12000], sc[:7904])     # second sighting of the big range: registered; hit starting on a sampled point
+check(bases[4096:12000], sc[:7904])     # sub-slice of a range that is not registered yet: stateless path (only this slice may be read)
+check(bases, sc)                        # second sighting of exactly the big range: registered from this call's memory
+check(bases[4096:12000], sc[:7904])     # hit starting on a sampled point
 check(bases, sc)                        # hit on the whole range
 bases[8192] = bases[1]                  # the memory changes in place at a sampled position
 check(bases, sc)                        # detected -> dropped, uncached path
@@ -633,6 +709,23 @@ print("CACHE_OK")
     env = dict(os.environ, SNARKVM_HIP_BASE_CACHE="4")
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
     assert "CACHE_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_ffi_msm_is_stateless_by_default():
+    """the callee must not retain the caller's pointers.  Without SNARKVM_HIP_BASE_CACHE in the environment
+    `snarkvm_msm` re-reads its operands on every call: a base changed in place between two calls (at a position the opt-in
+    cache would not sample) changes the result accordingly."""
+    if os.environ.get("SNARKVM_HIP_BASE_CACHE", "0") not in ("", "0"):
+        pytest.skip("the opt-in base cache is enabled in this environment")
+    n = 20000
+    bases = oracle.g1_gen_bases(util.g1_generator_affine(), 3, n)
+    sc = synthetic.random_fr_integers(n, 1357)
+    for _ in range(3):
+        _check(bases, sc, VariableBase.msm(bases, sc))
+    bases[8191] = bases[2]
+    bases[8192] = bases[1]
+    for _ in range(2):
+        _check(bases, sc, VariableBase.msm(bases, sc))
 
 
 def test_msm_randomized_configurations(golden):

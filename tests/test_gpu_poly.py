@@ -250,7 +250,7 @@ def test_device_resident_round2_slice_and_openings(golden):
     want = oracle.g1_msm(powers_g[: h0.shape[0]], oracle.fr_op("to_bigint", h0), oracle.MSM_BATCHED)
     assert util.affine_equal(oracle.g1_to_affine(comm), oracle.g1_to_affine(want))
     # hiding commit from the device vector equals the host-path commit
-    blind = _rnd(2, 77)
+    blind = _rnd(3, 77)
     c_dev, _ = kzg10.KZG10.commit_device(pw, quot, 1, lambda k: blind[:k])
     c_host, _ = kzg10.KZG10.commit(pw, got_h0, 1, lambda k: blind[:k])
     assert util.affine_equal(oracle.g1_to_affine(c_dev), oracle.g1_to_affine(c_host))

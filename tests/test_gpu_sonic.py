@@ -63,7 +63,7 @@ def test_sonic_commit_and_batch_open_match_reference_formulas():
     shifted_gamma = {b: oracle.g1_gen_bases(G, 20000 + b, 4) for b in bounds}
     lag = {64: oracle.g1_gen_bases(G, 30000, 64)}
     ck = sonic_pc.CommitterUnionKey(powers, gamma, shifted, shifted_gamma, bounds, lag)
-    blinds = iter([_rnd(3, 11), _rnd(2, 12), _rnd(4, 13)])
+    blinds = iter([_rnd(4, 11), _rnd(3, 12), _rnd(5, 13)])  # hiding_bound + 2 coefficients each (degree hiding_bound + 1)
     rng = lambda k: next(blinds)[:k]  # noqa: E731
     p_plain = _rnd(N, 1)
     p_lead = _rnd(300, 2)
@@ -83,7 +83,7 @@ def test_sonic_commit_and_batch_open_match_reference_formulas():
     comms, rands = sonic_pc.SonicKZG10.commit(N - 1, ck, polys, rng)
     assert [c.label for c in comms] == [p.label for p in polys] and [c.degree_bound for c in comms] == [None, None, 200, bounds[-1], None, None]
     b = [r.blinding_polynomial for r in rands]
-    assert b[0].shape[0] == 0 and b[1].shape[0] == 3 and b[2].shape[0] == 2 and b[5].shape[0] == 4
+    assert b[0].shape[0] == 0 and b[1].shape[0] == 4 and b[2].shape[0] == 3 and b[5].shape[0] == 5
     start = bounds[-1] - 200
     want = [
         _expect_commit(powers, p_plain, gamma, None),
