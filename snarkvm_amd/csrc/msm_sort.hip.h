@@ -23,14 +23,76 @@ namespace sv {
 static constexpr int SORT_TILE = 8192;     // items per workgroup tile
 static constexpr int SORT_THREADS = 256;   // 32 items per thread
 
+// Fused multi-instance MSM (runtime.hip.h::msm_run, `multi`): K independent MSMs over slices of ONE registered base vector
+// (the commitments of a prover round, sonic_pc/mod.rs:186-245) share one launch sequence.  The instances are laid side by side
+// in a padded concatenation (every instance starts on a multiple of SORT_TILE positions; the padding holds zero digits, which
+// touch no bucket), the instance id is the top key of the radix partition (bucket window = instance: K x 2^(c-1) buckets), and
+// an entry's virtual index is the SLOT of its base in the handle's table array (table * h.n + base index), so everything after
+// level 1 - the further sort levels, the accumulate grid, the fold and the bit planes - runs unchanged on K "windows".
+struct msm_inst_t {
+    const uint4* scalars;  // device pointer: n scalars of 32 B
+    uint32_t n;            // scalars of the instance
+    uint32_t n0;           // scalars [0, n0) pair with bases off0 + i, the others with off1 + (i - n0) (KZG10's two base ranges)
+    uint32_t off0, off1;   // base indices relative to the registered vector
+    uint32_t pstart;       // first position of the instance in the padded concatenation (a multiple of SORT_TILE)
+    uint32_t ptiles;       // padded length / SORT_TILE
+};
 struct msm_radix_params_t {
-    size_t n;              // scalars
+    size_t n;              // scalars (multi: padded positions of all instances)
     int c, W, J;           // window bits, bucket windows, base tables (digit row j*W + w feeds window w)
     int HB, LB;            // bucket index = (bin << LB) | rem, bin < 2^HB (level-1 key), rem < 2^LB (<= 7: one more level, <= 14: two)
     uint32_t nb;           // 2^(c-1)
     uint32_t tiles_per_row;  // ceil(n / SORT_TILE)
     uint32_t TPW;          // level-1 tiles per window = J * tiles_per_row
+    const msm_inst_t* inst = nullptr;  // multi: K + 1 entries (the last one is a sentinel with pstart = n); window = instance, W == 1
+    uint32_t ninst = 0;
+    uint32_t hn = 0;       // multi: points of the registered vector (virtual index = table * hn + base index)
 };
+// One level-1 tile: digits [lo, hi) of one digit row feeding bucket window w; its counters live at cbase + bin * TPW + tw.
+struct l1_tile_t {
+    uint32_t w, tw, TPW, j;
+    size_t cbase;     // first counter of window w
+    size_t row;       // first digit of the tile's row (index into the digit matrix)
+    size_t lo, hi;
+    uint32_t inst_idx;  // multi: the instance
+};
+__device__ __forceinline__ l1_tile_t l1_decode_tile(const msm_radix_params_t& p, uint32_t g) {
+    l1_tile_t t;
+    const uint32_t B1 = 1u << p.HB;
+    if (!p.inst) {
+        t.w = g / p.TPW;
+        t.tw = g - t.w * p.TPW;
+        t.TPW = p.TPW;
+        t.j = t.tw / p.tiles_per_row;
+        const uint32_t tt = t.tw - t.j * p.tiles_per_row;
+        t.cbase = (size_t)t.w * B1 * p.TPW;
+        t.row = (size_t)(t.j * p.W + t.w) * p.n;
+        t.lo = (size_t)tt * SORT_TILE;
+        t.hi = (t.lo + SORT_TILE < p.n) ? t.lo + SORT_TILE : p.n;
+        t.inst_idx = 0;
+        return t;
+    }
+    // multi: the tiles of instance k are [J * pstart_k / TILE, J * pstart_(k+1) / TILE), table-major inside the instance
+    const uint32_t J = (uint32_t)p.J;
+    uint32_t lo = 0, hi = p.ninst;  // invariant: J * pstart[lo] / TILE <= g < J * pstart[hi] / TILE
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (J * (p.inst[mid].pstart / SORT_TILE) <= g) lo = mid; else hi = mid;
+    }
+    const msm_inst_t in = p.inst[lo];
+    const uint32_t tw0 = J * (in.pstart / SORT_TILE);
+    t.w = lo;
+    t.inst_idx = lo;
+    t.tw = g - tw0;
+    t.TPW = J * in.ptiles;
+    t.j = t.tw / in.ptiles;
+    const uint32_t tt = t.tw - t.j * in.ptiles;
+    t.cbase = (size_t)B1 * tw0;
+    t.row = (size_t)t.j * p.n;
+    t.lo = (size_t)in.pstart + (size_t)tt * SORT_TILE;
+    t.hi = t.lo + SORT_TILE;  // padded: always a whole tile
+    return t;
+}
 
 // decode one digit: returns false for digit zero; else bucket index b (0-based) and the sign
 __device__ __forceinline__ bool digit_bucket(uint32_t u, int half, uint32_t& b, uint32_t& neg) {
@@ -73,20 +135,16 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist1_kernel(const DT* __r
                                                                    msm_radix_params_t p) {
     __shared__ uint32_t hist[256];
     const uint32_t B1 = 1u << p.HB;
-    const uint32_t g = blockIdx.x;            // global level-1 tile
-    const uint32_t w = g / p.TPW, tw = g - w * p.TPW;
-    const uint32_t j = tw / p.tiles_per_row, t = tw - j * p.tiles_per_row;
+    const l1_tile_t tl = l1_decode_tile(p, blockIdx.x);
     for (uint32_t i = threadIdx.x; i < B1; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    const size_t lo = (size_t)t * SORT_TILE;
-    const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
     const int half = 1 << (p.c - 1);
-    for_each_digit_t<DT>(digits + (size_t)(j * p.W + w) * p.n, p.n, lo, hi, [&](uint32_t u, size_t) {
+    for_each_digit_t<DT>(digits + tl.row, p.n, tl.lo, tl.hi, [&](uint32_t u, size_t) {
         uint32_t b, neg;
         if (digit_bucket(u, half, b, neg)) atomicAdd(&hist[b >> p.LB], 1u);
     });
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < B1; i += blockDim.x) counts1[((size_t)w * B1 + i) * p.TPW + tw] = hist[i];
+    for (uint32_t i = threadIdx.x; i < B1; i += blockDim.x) counts1[tl.cbase + (size_t)i * tl.TPW + tl.tw] = hist[i];
 }
 
 // ---- level 1 scatter: stage the tile in LDS grouped by bin, then write whole runs
@@ -115,14 +173,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* 
     __shared__ RT sl_[SORT_TILE];
     __shared__ uint8_t sbin_[SORT_TILE];
     const uint32_t B1 = 1u << p.HB;
-    const uint32_t g = blockIdx.x;
-    const uint32_t w = g / p.TPW, tw = g - w * p.TPW;
-    const uint32_t j = tw / p.tiles_per_row, t = tw - j * p.tiles_per_row;
+    const l1_tile_t tl = l1_decode_tile(p, blockIdx.x);
     // this tile's histogram was computed by radix_hist1_kernel; its global run starts are off1[...]
-    const size_t lo = (size_t)t * SORT_TILE;
-    const size_t hi = (lo + SORT_TILE < p.n) ? lo + SORT_TILE : p.n;
+    const size_t lo = tl.lo, hi = tl.hi;
     const int half = 1 << (p.c - 1);
-    const DT* row = digits + (size_t)(j * p.W + w) * p.n;
+    const DT* row = digits + tl.row;
     // full aligned tile: issue this thread's 16-byte digit loads before anything else
     constexpr int DPV = 16 / (int)sizeof(DT);  // digits per 16-byte load
     const bool vec = (p.n & (DPV - 1)) == 0 && hi - lo == SORT_TILE;
@@ -135,22 +190,32 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* 
     }
     {
         const uint32_t i = threadIdx.x;  // SORT_THREADS == 256 >= B1: one bin per thread
-        const uint32_t cnt = (i < B1) ? counts1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
-        gbase[i] = (i < B1) ? off1[((size_t)w * B1 + i) * p.TPW + tw] : 0u;
+        const uint32_t cnt = (i < B1) ? counts1[tl.cbase + (size_t)i * tl.TPW + tl.tw] : 0u;
+        gbase[i] = (i < B1) ? off1[tl.cbase + (size_t)i * tl.TPW + tl.tw] : 0u;
         lcount[i] = cnt;
         const uint32_t start = block_excl_scan(cnt, wave_tot);
         lstart[i] = start;
         cursor[i] = start;
     }
     __syncthreads();
-    const uint32_t voff = (uint32_t)((size_t)j * p.n);
+    // virtual index of digit position i: single MSM: table * n + i; multi: the slot of the base in the handle's table array
+    // (table * hn + base index), two base ranges per instance
+    const bool multi = p.inst != nullptr;
+    msm_inst_t in;
+    if (multi) in = p.inst[tl.inst_idx];
+    const uint32_t voff = multi ? tl.j * p.hn : (uint32_t)((size_t)tl.j * p.n);
     const uint32_t lmask = (1u << p.LB) - 1;
     auto place = [&](uint32_t u, size_t i) {
         uint32_t b, neg;
         if (digit_bucket(u, half, b, neg)) {
             const uint32_t bin = b >> p.LB;
             const uint32_t pos = atomicAdd(&cursor[bin], 1u);
-            sv_[pos] = (voff + (uint32_t)i) | neg;
+            uint32_t vi = (uint32_t)i;
+            if (multi) {
+                const uint32_t idx = vi - in.pstart;
+                vi = idx < in.n0 ? in.off0 + idx : in.off1 + (idx - in.n0);
+            }
+            sv_[pos] = (voff + vi) | neg;
             sl_[pos] = (RT)(b & lmask);
             sbin_[pos] = (uint8_t)bin;
         }
@@ -429,6 +494,60 @@ static __global__ void radix_bin_layout_kernel(const uint32_t* __restrict__ off1
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nbins) return;
     binstart[q] = (q < nbins) ? off1[(size_t)q * TPW] : off1[ncounts1 - 1] + counts1[ncounts1 - 1];
+}
+// multi: bin q = k * B1 + bin of instance k starts at off1[B1 * J * pstart_k / TILE + bin * J * ptiles_k]
+static __global__ void radix_bin_layout_multi_kernel(const uint32_t* __restrict__ off1, const uint32_t* __restrict__ counts1, size_t ncounts1,
+                                              uint32_t* __restrict__ binstart, uint32_t nbins, msm_radix_params_t p) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nbins) return;
+    if (q == nbins) {
+        binstart[q] = off1[ncounts1 - 1] + counts1[ncounts1 - 1];
+        return;
+    }
+    const uint32_t B1 = 1u << p.HB, k = q >> p.HB, bin = q & (B1 - 1);
+    const msm_inst_t in = p.inst[k];
+    const uint32_t J = (uint32_t)p.J;
+    binstart[q] = off1[(size_t)B1 * J * (in.pstart / SORT_TILE) + (size_t)bin * J * in.ptiles];
+}
+// multi: the scalar-read phase of a fused batch.  One thread per padded position: recode the scalar into its J digit rows
+// (u16, row-major over the padded positions); padding positions get the zero digit.  A block of 256 positions lies inside one
+// instance (instances start on multiples of SORT_TILE), so the instance search is block-uniform.
+static __global__ void __launch_bounds__(256) msm_digits_multi_kernel(const msm_inst_t* __restrict__ inst, uint32_t ninst,
+                                                               uint16_t* __restrict__ digits, msm_digit_params_t p) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;  // p.n = padded positions, a multiple of 256
+    const uint32_t g0 = blockIdx.x * 256u;
+    uint32_t lo = 0, hi = ninst;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (inst[mid].pstart <= g0) lo = mid; else hi = mid;
+    }
+    const msm_inst_t in = inst[lo];
+    const uint32_t idx = g - in.pstart;
+    const uint32_t half = 1u << (p.c - 1);
+    if (idx >= in.n) {
+        for (int w = 0; w < p.W; w++) digits[(size_t)w * p.n + g] = (uint16_t)half;
+        return;
+    }
+    const uint4 q0 = in.scalars[2 * (size_t)idx], q1 = in.scalars[2 * (size_t)idx + 1];
+    uint32_t s[11] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, 0u, 0u, 0u};
+    if (p.montgomery) {
+        fr_t c32 = fr_t::zero();
+        c32.v[0] = 32;
+        (fr_t::unpack(s) * c32).pack(s);
+    }
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        carry += (uint64_t)s[k] + p.bias[k];
+        s[k] = (uint32_t)carry;
+        carry >>= 32;
+    }
+    const uint32_t mask = (1u << p.c) - 1;
+    for (int w = 0; w < p.W; w++) {
+        const int bit = p.c * w, wi = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)s[wi] | ((uint64_t)s[wi + 1] << 32);
+        digits[(size_t)w * p.n + g] = (uint16_t)((uint32_t)(two >> sh) & mask);
+    }
 }
 static __global__ void radix_bin_tiles_kernel(const uint32_t* __restrict__ binstart, uint32_t* __restrict__ ntiles, uint32_t nbins) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;

@@ -516,8 +516,10 @@ struct msm_pending_t {
     // position of plane (tw, j): DENSE (folded): tw = 2 w + sub -> c w + sub m + j; else tw = w -> c w + j
     int c = 0, m = 0;
     bool folded = false;
+    int ninst = 0;  // fused multi-instance run: window w IS instance w (every instance has ONE bucket window at bit position 0)
     int pos(int idx) const {
         const int tw = idx / nbits, j = idx % nbits;
+        if (ninst) return (tw & 1) * m + j;
         return folded ? c * (tw >> 1) + (tw & 1) * m + j : c * tw + j;
     }
 };
@@ -526,6 +528,20 @@ static void msm_collect(msm_accum_t<F>& acc, const msm_pending_t& pd) {
     const xyzz_mem_t<F>* pl = (const xyzz_mem_t<F>*)pd.planes;
     for (int i = 0; i < pd.nplanes; i++) acc.add(pd.pos(i), load_xyzz<F>(&pl[i]));
 }
+// the planes of instance `inst` of a fused multi-instance run (2 * nbits consecutive planes)
+template <class F>
+static void msm_collect_inst(msm_accum_t<F>& acc, const msm_pending_t& pd, int inst) {
+    const xyzz_mem_t<F>* pl = (const xyzz_mem_t<F>*)pd.planes;
+    const int per = 2 * pd.nbits;
+    for (int i = inst * per; i < (inst + 1) * per; i++) acc.add(pd.pos(i), load_xyzz<F>(&pl[i]));
+}
+// host description of a fused multi-instance run (msm_sort.hip.h: msm_inst_t)
+struct msm_multi_t {
+    const msm_inst_t* d_inst = nullptr;  // device table, K + 1 entries (sentinel: pstart = npad)
+    uint32_t K = 0;
+    size_t npad = 0;  // padded positions of all instances (multiple of SORT_TILE)
+    size_t hn = 0;    // points of the registered vector: virtual index = table * hn + base index
+};
 
 // Device side of one MSM on lane `c`: d_bases = converted device bases; d_scalars = device scalars (32 B each).  Everything
 // is enqueued on the lane's stream, ending with the copy of the bit-plane sums into `host_planes` (pinned, >=
@@ -537,7 +553,10 @@ static size_t msm_plane_bytes() {
 template <class F>
 static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* host_planes, int window_bits,
                              const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
-                             size_t table_stride = 0, bool profile = true, int table_bits = 0) {
+                             size_t table_stride = 0, bool profile = true, int table_bits = 0, const msm_multi_t* mu = nullptr) {
+    // mu != nullptr: fused multi-instance run (msm_sort.hip.h): n = mu->npad padded positions, d_bases = the handle's table array,
+    // d_scalars unused (the instance table carries the pointers), one bucket window per instance; host_planes holds
+    // mu->K * 2 * (fold_m + 1) planes.
     auto phase_begin = [&](const char* name) { if (profile) c.phase_begin(name); };
     auto phase_end = [&]() { if (profile) c.phase_end(); };
     msm_pending_t pd;
@@ -545,13 +564,16 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     if (n0 > n) n0 = n;
     if (n == 0) return pd;  // no planes: the sum is the point at infinity
     if (n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: npoints must be < 2^31", __LINE__};
-    const msm_plan_t pl = msm_make_plan(n, window_bits, tables, table_bits);
+    const msm_plan_t pl = msm_make_plan(n, mu ? table_bits : window_bits, tables, table_bits);
     const bool wide = pl.c > 16;  // u32 digits, three-level sort
+    if (mu && (wide || pl.W != 1 || pl.c < 12 || (size_t)pl.J * mu->hn >= ((size_t)1 << 31) || n != mu->npad || n % SORT_TILE))
+        throw hip_failure{hipErrorInvalidValue, "msm: geometry not eligible for a fused multi-instance run", __LINE__};
     if ((size_t)pl.Wd * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: windows * npoints must be < 2^32", __LINE__};
     if ((size_t)pl.J * n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: tables * npoints must be < 2^31", __LINE__};
     hipStream_t st = c.stream;
     const size_t E_max = (size_t)pl.Wd * n;
-    const uint32_t nbt = pl.nbt;
+    const uint32_t nwin = mu ? mu->K : (uint32_t)pl.W;  // bucket windows of the tail (multi: one per instance)
+    const uint32_t nbt = nwin * pl.nb;
 
     c.scan_tmp.ensure((scan_tmp_elems((size_t)nbt + 1)) * 4);
     c.boff.ensure(((size_t)nbt + 2) * 4);
@@ -571,7 +593,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     const int K = pl.c - 1;
     const int fold_m = (K + 1) / 2, fold_hb = K - fold_m;
     const bool fold = K >= 11 || (K >= 4 && pl.c * pl.W < 128);
-    const int tail_windows = fold ? 2 * pl.W : pl.W;
+    const int tail_windows = fold ? 2 * (int)nwin : (int)nwin;
     const int nbits = fold ? fold_m + 1 : pl.c;  // weights run up to 2^fold_m (L sums) / 2^(c-1) (plain buckets)
     pd.tail_windows = tail_windows;
     pd.nbits = nbits;
@@ -579,14 +601,15 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     pd.c = pl.c;
     pd.m = fold_m;
     pd.folded = fold;
-    if (pd.nplanes > MSM_MAX_POS || pl.c * (pl.W - 1) + (fold ? fold_m : 0) + nbits > MSM_MAX_POS)
+    pd.ninst = mu ? (int)mu->K : 0;
+    if ((!mu && pd.nplanes > MSM_MAX_POS) || pl.c * (pl.W - 1) + (fold ? fold_m : 0) + nbits > MSM_MAX_POS)
         throw hip_failure{hipErrorInvalidValue, "msm: window geometry exceeds the tail's bit-position range", __LINE__};
     c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
 
     // 1. scalar read.  Wide windows: fused with the level-1 partition below (the digits never exist in memory); otherwise the
     // stand-alone digit kernel writes the [rows][n] digit matrix.
     static const int fused_env = getenv("SNARKVM_HIP_FUSED") ? atoi(getenv("SNARKVM_HIP_FUSED")) : 1;
-    const bool fused = wide && fused_env && pl.c <= 22 && pl.Wd <= FUSED_MAX_ROWS;  // level-1 key of <= 7 bits: FUSED_G * 2^HB <= FUSED_THREADS
+    const bool fused = !mu && wide && fused_env && pl.c <= 22 && pl.Wd <= FUSED_MAX_ROWS;  // level-1 key of <= 7 bits: FUSED_G * 2^HB <= FUSED_THREADS
     msm_digit_params_t dp;
     memcpy(dp.bias, pl.bias, sizeof dp.bias);
     dp.c = pl.c;
@@ -597,15 +620,22 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         phase_begin("msm_digits");
         c.digits.ensure(E_max * (wide ? sizeof(uint32_t) : sizeof(uint16_t)));
         size_t blocks = (n + 255) / 256;
+        if (mu)
+            hipLaunchKernelGGL(msm_digits_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mu->d_inst, mu->K, c.digits.as<uint16_t>(), dp);
         if (blocks > 256 * 16) blocks = 256 * 16;
-        if (wide)
+        if (mu)
+            ;
+        else if (wide)
             hipLaunchKernelGGL((msm_digits_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint32_t>(), dp);
         else
             hipLaunchKernelGGL((msm_digits_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
         phase_end();
     }
     int rounds = 0;
-    const bool single_round = (size_t)pl.Wd * n <= ((size_t)1 << 22);  // see step 5
+    // see step 5; a fused multi-instance run never reads back either: its instances are small (<= 2^18 points each), so the
+    // flattened-list fold takes whatever partial sums the accumulate grid leaves
+    const bool single_round = mu || (size_t)pl.Wd * n <= ((size_t)1 << 22);
+    const bool prefetch_ok = (size_t)pl.Wd * n <= ((size_t)1 << 22);  // one wave per SIMD: nothing else hides the gather
     {
         // ---- 2.-4. LDS-staged radix partition (msm_sort.hip.h) -> bucket-major `sorted` + boff; two levels, three when wide
         msm_radix_params_t rp;
@@ -613,6 +643,11 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         rp.c = pl.c;
         rp.W = pl.W;
         rp.J = pl.J;
+        if (mu) {
+            rp.inst = mu->d_inst;
+            rp.ninst = mu->K;
+            rp.hn = (uint32_t)mu->hn;
+        }
         const int LBL = K < 7 ? K : 7;  // key bits of the last level
         rp.LB = wide ? 14 : LBL;        // bits left below the level-1 key
         rp.HB = K - rp.LB;
@@ -620,9 +655,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         rp.tiles_per_row = fused ? (uint32_t)((n + FUSED_TILE - 1) / FUSED_TILE) : (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
         rp.TPW = (uint32_t)pl.J * rp.tiles_per_row;
         const uint32_t B1 = 1u << rp.HB;
-        const uint32_t nbins = (uint32_t)pl.W * B1;
-        const size_t ncounts1 = (size_t)nbins * rp.TPW;
-        const size_t tiles1 = (size_t)pl.W * rp.TPW;
+        const uint32_t nbins = nwin * B1;
+        // single: W windows x B1 bins x TPW tiles; multi: the windows (instances) partition the J * npad / TILE tiles among themselves
+        const size_t ncounts1 = (size_t)(mu ? B1 : nbins) * rp.TPW;
+        const size_t tiles1 = (size_t)(mu ? 1 : pl.W) * rp.TPW;
         const uint32_t nseg_last = wide ? nbins << 7 : nbins;  // segments feeding the last level
         const size_t tiles2_max = E_max / SORT_TILE + nseg_last + 1;
         c.counts.ensure(ncounts1 * 4);
@@ -690,7 +726,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             hipLaunchKernelGGL((radix_scatter1_kernel<uint16_t, uint8_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint16_t>(),
                                counts1, off1, c.rv1.as<uint32_t>(), c.rl1.as<uint8_t>(), rp);
         }
-        if (!fused)
+        if (mu)
+            hipLaunchKernelGGL(radix_bin_layout_multi_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, off1, counts1, ncounts1,
+                               c.rbinstart.as<uint32_t>(), nbins, rp);
+        else if (!fused)
             hipLaunchKernelGGL(radix_bin_layout_kernel, dim3((nbins + 1 + 255) / 256), dim3(256), 0, st, off1, counts1, ncounts1, c.rbinstart.as<uint32_t>(),
                                nbins, rp.TPW);
         phase_end();
@@ -776,14 +815,17 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
 #endif
             // (a 3-waves-per-SIMD build of this kernel - 168 VGPRs - and a software-pipelined gather were measured: no gain)
             static const int prefetch_env = getenv("SNARKVM_HIP_PREFETCH") ? atoi(getenv("SNARKVM_HIP_PREFETCH")) : 1;
-            if (single_round && prefetch_env)
+            // multi: an entry's virtual index is the slot of its base in the handle's table array (d_bases[table * hn + index])
+            const uint32_t vn = mu ? (uint32_t)mu->hn : (uint32_t)n, vn0 = mu ? 0xffffffffu : (uint32_t)n0;
+            const size_t vstride = mu ? mu->hn : table_stride;
+            if (single_round && prefetch_ok && prefetch_env)
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                                   d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
+                                   d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride, dbg_mask);
             else
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                                   d_bases1 ? d_bases1 : d_bases, (uint32_t)n0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, (uint32_t)n, table_stride, dbg_mask);
+                                   d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride, dbg_mask);
         }
         phase_end();
     }
@@ -809,17 +851,17 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     // 7.-9. fold -> bit-plane sums -> (host) Horner
     phase_begin("msm_bucket_reduce");
     if (fold) {
-        c.fold_sums.ensure(((size_t)pl.W << (fold_m + 1)) * sizeof(xyzz_mem_t<F>));
+        c.fold_sums.ensure(((size_t)nwin << (fold_m + 1)) * sizeof(xyzz_mem_t<F>));
         // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
         // (<= 512 workgroups at two waves per SIMD); many windows (table-less small MSMs: 20 windows x 128 outputs) or many
         // buckets are throughput-bound: one wave per output
-        const unsigned fold_blocks = ((1u << fold_m) + (1u << fold_hb)) * (unsigned)pl.W;
+        const unsigned fold_blocks = ((1u << fold_m) + (1u << fold_hb)) * (unsigned)nwin;
         const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
         if (single_round || fold_threads == 256u)  // flattened lists: any distribution, and 256 lanes busy on 128 buckets
-            hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in,
+            hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, pin, start_in,
                                cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
         else
-            hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)pl.W), dim3(fold_threads), 0, st, pin, start_in,
+            hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, pin, start_in,
                                cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
         const unsigned plane_threads = fold_m <= 6 ? 64u : fold_m == 7 ? 128u : 256u;  // one lane per entry of a plane (<= 2^fold_m)
         hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(plane_threads), 0, st,
@@ -1068,6 +1110,21 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
 
 // A batch of independent MSMs over one registered base vector, fanned out over devices x lanes (see
 // snarkvm_hip_msm_registered_batch).  outs: count Jacobian memory images.
+//
+// Instances of up to 2^18 pairs over windowed tables (one bucket window per table set: the geometries registered for proof-sized
+// commitments, 17 x 15 / 16 x 16 bit) are FUSED: the instances a device received travel as groups through ONE launch sequence
+// each (msm_sort.hip.h: instance id = top key of the radix partition, one accumulate grid, one fold and one bit-plane launch
+// for the whole group, then one host finish per instance).  A prover round is such a batch (sonic_pc/mod.rs:186-245: the
+// commitments of a round are independent MSMs over one committer key).  Per instance the fused run leaves fewer partial sums
+// for the tail (the accumulate grid is sized for the group, not per instance) and ~25 launches are shared by the group.
+static constexpr size_t MSM_FUSE_MAX_PAIRS = (size_t)1 << 18;   // per instance
+static constexpr size_t MSM_FUSE_MAX_ENTRIES = (size_t)1 << 26;  // digit entries (tables x padded pairs) per fused group
+static constexpr size_t MSM_FUSE_MAX_K = 32;
+static constexpr size_t MSM_FUSE_PLANES = 20;                    // >= 2 * (fold_m + 1) planes per instance for windows of <= 16 bits
+static bool msm_fuse_enabled() {
+    static const int env = getenv("SNARKVM_HIP_FUSE_BATCH") ? atoi(getenv("SNARKVM_HIP_FUSE_BATCH")) : 1;  // A/B switch
+    return env != 0;
+}
 template <class F>
 static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, const size_t* offsets, const size_t* npoints, const void* const* scalars,
                           int scalars_on_device, int scalars_montgomery, int window_bits, const size_t* off1 = nullptr, const size_t* n1 = nullptr) {
@@ -1094,39 +1151,121 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
         if (!per_dev[d].empty()) devs.push_back(d);
     const size_t slot = msm_plane_bytes<F>();
     const size_t out_bytes = sizeof(jac_mem_t<F>);
+    // geometry of the handle eligible for fused groups: one bucket window of 12 .. 16 bits per table set, slots addressable in 31 bits
+    const bool fusable_handle = msm_fuse_enabled() && h.tables > 1 && h.table_bits >= 12 && h.table_bits <= 16 && (window_bits == 0 || window_bits == h.table_bits) &&
+                                (size_t)h.tables * h.n < ((size_t)1 << 31) && h.n < ((size_t)1 << 31);
+    auto padded = [](size_t n) { return (n + SORT_TILE - 1) / SORT_TILE * SORT_TILE; };
     for_each_device(devs, [&](int dev) {
         const std::vector<size_t>& mine = per_dev[dev];
+        // jobs of this device: fused groups of small instances (in order of appearance), single instances otherwise
+        std::vector<std::vector<size_t>> jobs;
+        {
+            std::vector<size_t> group;
+            size_t group_entries = 0;
+            auto flush = [&] {
+                if (group.size() == 1) jobs.push_back(group);  // a lone instance takes the single-MSM path (its own planner)
+                else if (!group.empty()) jobs.push_back(group);
+                group.clear();
+                group_entries = 0;
+            };
+            for (size_t k : mine) {
+                const bool small = fusable_handle && total(k) > 0 && total(k) <= MSM_FUSE_MAX_PAIRS;
+                if (!small) {
+                    jobs.push_back({k});
+                    continue;
+                }
+                const size_t e = padded(total(k)) * (size_t)h.tables;
+                if (!group.empty() && (group.size() >= MSM_FUSE_MAX_K || group_entries + e > MSM_FUSE_MAX_ENTRIES)) flush();
+                group.push_back(k);
+                group_entries += e;
+            }
+            flush();
+        }
         lane_guard lg;
-        lg.acquire(dev, nlanes < (int)mine.size() ? nlanes : (int)mine.size());
+        lg.acquire(dev, nlanes < (int)jobs.size() ? nlanes : (int)jobs.size());
         const int L = (int)lg.lanes.size();
-        std::vector<msm_pending_t> pend(mine.size());
-        std::vector<hipEvent_t> done(mine.size());
+        std::vector<msm_pending_t> pend(jobs.size());
+        std::vector<hipEvent_t> done(jobs.size());
+        // pinned staging per lane: the bit planes of its jobs, then the instance tables of its fused jobs
+        std::vector<size_t> plane_off(jobs.size()), table_off(jobs.size()), lane_bytes(L, 0);
+        for (size_t i = 0; i < jobs.size(); i++) {
+            const size_t K = jobs[i].size();
+            plane_off[i] = lane_bytes[i % L];
+            lane_bytes[i % L] += K > 1 ? K * MSM_FUSE_PLANES * sizeof(xyzz_mem_t<F>) : slot;
+            table_off[i] = lane_bytes[i % L];
+            lane_bytes[i % L] += K > 1 ? ((K + 1) * sizeof(msm_inst_t) + 255) / 256 * 256 : 0;
+        }
         for (int l = 0; l < L; l++) {
             lg.lanes[l]->begin_call();
-            lg.lanes[l]->pin.ensure(slot * ((mine.size() + L - 1) / L));
+            lg.lanes[l]->pin.ensure(lane_bytes[l] ? lane_bytes[l] : 256);
         }
-        for (size_t i = 0; i < mine.size(); i++) {
-            const size_t k = mine[i];
+        for (size_t i = 0; i < jobs.size(); i++) {
             lane_t& c = *lg.lanes[i % L];
-            const uint4* d_sc = (const uint4*)scalars[k];
-            if (!scalars_on_device && total(k)) {
-                // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
-                c.scalars.ensure(total(k) * 32);
-                HIP_TRY(hipMemcpyAsync(c.scalars.p, scalars[k], total(k) * 32, hipMemcpyHostToDevice, c.stream));
-                d_sc = c.scalars.template as<uint4>();
+            uint8_t* host_planes = c.pin.template as<uint8_t>() + plane_off[i];
+            if (jobs[i].size() == 1) {
+                const size_t k = jobs[i][0];
+                const uint4* d_sc = (const uint4*)scalars[k];
+                if (!scalars_on_device && total(k)) {
+                    // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
+                    c.scalars.ensure(total(k) * 32);
+                    HIP_TRY(hipMemcpyAsync(c.scalars.p, scalars[k], total(k) * 32, hipMemcpyHostToDevice, c.stream));
+                    d_sc = c.scalars.template as<uint4>();
+                }
+                pend[i] = msm_run<F>(c, h.d[dev] + offsets[k], d_sc, total(k), host_planes, window_bits, n1 ? h.d[dev] + off1[k] : nullptr,
+                                     n1 ? npoints[k] : ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits);
+            } else {
+                // fused group: instance table (pinned -> device), scalars of host callers packed into the lane's scalar buffer
+                const size_t K = jobs[i].size();
+                msm_inst_t* tab = (msm_inst_t*)(c.pin.template as<uint8_t>() + table_off[i]);
+                size_t npad = 0, sc_bytes = 0;
+                for (size_t q = 0; q < K; q++) sc_bytes += total(jobs[i][q]) * 32;
+                if (!scalars_on_device) c.scalars.ensure(sc_bytes);
+                size_t sc_off = 0;
+                for (size_t q = 0; q < K; q++) {
+                    const size_t k = jobs[i][q];
+                    msm_inst_t& in = tab[q];
+                    in.n = (uint32_t)total(k);
+                    in.n0 = n1 ? (uint32_t)npoints[k] : in.n;
+                    in.off0 = (uint32_t)offsets[k];
+                    in.off1 = n1 ? (uint32_t)off1[k] : 0u;
+                    in.pstart = (uint32_t)npad;
+                    in.ptiles = (uint32_t)(padded(total(k)) / SORT_TILE);
+                    npad += padded(total(k));
+                    if (scalars_on_device) {
+                        in.scalars = (const uint4*)scalars[k];
+                    } else {
+                        uint8_t* dst = c.scalars.template as<uint8_t>() + sc_off;
+                        HIP_TRY(hipMemcpyAsync(dst, scalars[k], total(k) * 32, hipMemcpyHostToDevice, c.stream));
+                        in.scalars = (const uint4*)dst;
+                        sc_off += total(k) * 32;
+                    }
+                }
+                tab[K] = msm_inst_t{nullptr, 0, 0, 0, 0, (uint32_t)npad, 0};  // sentinel
+                c.poly[4].ensure((K + 1) * sizeof(msm_inst_t));
+                HIP_TRY(hipMemcpyAsync(c.poly[4].p, tab, (K + 1) * sizeof(msm_inst_t), hipMemcpyHostToDevice, c.stream));
+                msm_multi_t mu;
+                mu.d_inst = c.poly[4].template as<msm_inst_t>();
+                mu.K = (uint32_t)K;
+                mu.npad = npad;
+                mu.hn = h.n;
+                pend[i] = msm_run<F>(c, h.d[dev], nullptr, npad, host_planes, 0, nullptr, ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits, &mu);
+                if ((size_t)pend[i].nplanes > K * MSM_FUSE_PLANES) throw hip_failure{hipErrorInvalidValue, "msm batch: plane staging too small", __LINE__};
             }
-            pend[i] = msm_run<F>(c, h.d[dev] + offsets[k], d_sc, total(k), c.pin.template as<uint8_t>() + slot * (i / L), window_bits,
-                                 n1 ? h.d[dev] + off1[k] : nullptr, n1 ? npoints[k] : ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits);
             done[i] = c.new_event();
             HIP_TRY(hipEventRecord(done[i], c.stream));
         }
-        // the host finishes instance i while the GPU works on the later ones
+        // the host finishes job i while the GPU works on the later ones
         std::unique_ptr<msm_accum_t<F>> acc;
-        for (size_t i = 0; i < mine.size(); i++) {
+        for (size_t i = 0; i < jobs.size(); i++) {
             HIP_TRY(hipEventSynchronize(done[i]));
-            acc.reset(new msm_accum_t<F>());
-            msm_collect<F>(*acc, pend[i]);
-            acc->finish((uint8_t*)outs + out_bytes * mine[i]);
+            for (size_t q = 0; q < jobs[i].size(); q++) {
+                acc.reset(new msm_accum_t<F>());
+                if (jobs[i].size() == 1)
+                    msm_collect<F>(*acc, pend[i]);
+                else
+                    msm_collect_inst<F>(*acc, pend[i], (int)q);
+                acc->finish((uint8_t*)outs + out_bytes * jobs[i][q]);
+            }
         }
         for (int l = 0; l < L; l++) lg.lanes[l]->end_call();
     });

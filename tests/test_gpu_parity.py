@@ -285,6 +285,51 @@ def test_msm_batch_pipelined(golden):
     rb.close()
 
 
+@pytest.mark.parametrize("tables,window_bits", [(17, 15), (16, 0), (20, 13)])
+def test_msm_batch_fused_multi_instance(golden, tables, window_bits):
+    """Batches of proof-sized instances over windowed tables run FUSED (runtime.hip.h::msm_batch_run: one launch sequence per
+    group, instance id = top sort key).  Ragged sizes (0, 1, tile boundaries 8191 / 8192 / 8193, > 2^16), base offsets, host and
+    device scalars, Montgomery scalars, and an instance too big to fuse in the middle of the batch; every result against the
+    oracle's batched::msm of that instance alone."""
+    import torch
+
+    N = 70000
+    bases = _srs(golden, N)
+    bases[33]["infinity"] = 1
+    rb = RegisteredBases(bases, tables=tables, window_bits=window_bits)
+    sizes = [8192, 1, 0, 8191, 8193, 70000, 333, 65536, 40000, 2, 16384]
+    offs = [0, 5, 0, 100, 1000, 0, 60000, 17, 30000, 69998, 8192]
+    scal = [synthetic.random_fr_integers(k, 2300 + i) for i, k in enumerate(sizes)]
+    scal[0][:3] = util.ints_to_fr([0, 1, pyref.R_MOD - 1])
+    scal[3][:] = scal[3][0]          # all scalars equal: one bucket per table takes every point of the instance
+    want = [oracle.g1_to_affine(oracle.g1_msm(bases[o:o + k], s, oracle.MSM_BATCHED)) if k else None for k, o, s in zip(sizes, offs, scal)]
+
+    def check(got, label):
+        for i, k in enumerate(sizes):
+            a = oracle.g1_to_affine(got[i:i + 1])
+            if k == 0:
+                assert a["infinity"][0] == 1, (label, i)
+            else:
+                assert util.affine_equal(a, want[i]), (label, i, k)
+
+    check(rb.msm_batch(scal, offsets=offs), "host scalars")
+    d_sc = [torch.from_numpy(s.view(np.int64).copy()).cuda() if s.shape[0] else torch.zeros(4, dtype=torch.int64, device="cuda") for s in scal]
+    torch.cuda.synchronize()
+    check(rb.msm_batch(device_ptrs=[d.data_ptr() for d in d_sc], npoints=sizes, offsets=offs), "device scalars")
+    mont = [oracle.fr_op("from_bigint", s) if s.shape[0] else s for s in scal]
+    check(rb.msm_batch(mont, offsets=offs, montgomery=True), "montgomery scalars")
+    # the same instances one at a time through the single-MSM path
+    for i, (k, o) in enumerate(zip(sizes, offs)):
+        if k:
+            assert util.affine_equal(oracle.g1_to_affine(rb.msm(scal[i], offset=o)), want[i]), ("single", i)
+    # a group bigger than one fused launch takes (40 instances > MSM_FUSE_MAX_K)
+    many = [scal[6]] * 40
+    got = rb.msm_batch(many, offsets=[offs[6]] * 40)
+    for i in range(40):
+        assert util.affine_equal(oracle.g1_to_affine(got[i:i + 1]), want[6]), ("many", i)
+    rb.close()
+
+
 def _device_bases(n, start=1):
     import torch
 

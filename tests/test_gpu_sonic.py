@@ -119,16 +119,17 @@ def test_sonic_commit_and_batch_open_match_reference_formulas():
     for proof, (name, point, labels) in zip(proofs, [("alpha", z2, ["bounded", "hiding"]), ("beta", z1, ["hiding", "plain"])]):
         length = max(by_label[lb][0].coeffs.shape[0] for lb in labels)
         comb = np.zeros((length, 4), dtype=np.uint64)
-        comb_r = np.zeros((3, 4), dtype=np.uint64)
+        rlen = max(by_label[lb][1].blinding_polynomial.shape[0] for lb in labels) or 1
+        comb_r = np.zeros((rlen, 4), dtype=np.uint64)
         for lb in labels:
             c = chal.squeeze_short_nonnative_field_element()
             pc = np.zeros((length, 4), dtype=np.uint64)
             pc[: by_label[lb][0].coeffs.shape[0]] = by_label[lb][0].coeffs
             comb = oracle.fr_vec_op("axpy", comb, pc, np.tile(c, (length, 1)))
-            rb = np.zeros((3, 4), dtype=np.uint64)
+            rb = np.zeros((rlen, 4), dtype=np.uint64)
             bl = by_label[lb][1].blinding_polynomial
             rb[: bl.shape[0]] = bl
-            comb_r = oracle.fr_vec_op("axpy", comb_r, rb, np.tile(c, (3, 1)))
+            comb_r = oracle.fr_vec_op("axpy", comb_r, rb, np.tile(c, (rlen, 1)))
         chal.squeeze_short_nonnative_field_element()  # the unused `_randomizer`
         wq, _ = oracle.poly_divide(comb, _linear_divisor(point))
         want_w = oracle.g1_msm(powers[: wq.shape[0]], oracle.fr_op("to_bigint", wq))
