@@ -281,6 +281,10 @@ int snarkvm_hip_selftest_msm_plan(size_t n, int window_bits, int tables, int tab
  * memory images - the Horner chain that combines the bit-plane sums the device leaves (and the per-device partial results of
  * a split MSM, the reference's host `dadd`, snarkvm.cu:290-295).  Returns 0. */
 int snarkvm_hip_selftest_g1_finish(const void *planes_projective, const int32_t *pos, size_t n, void *out);
+/* The lazily reduced arithmetic of the accumulate kernel (csrc/ffl.hip.h) against the exact arithmetic, on the host: `iters`
+ * chained mixed additions (doublings, cancellations and restarts from infinity included) compared coordinate by coordinate,
+ * then the field routines at the edges of their operand ranges.  0 = identical; > 0: first differing step; < 0: field case. */
+int snarkvm_hip_selftest_fq_lazy(uint64_t seed, int iters);
 /* Same field operations executed by a GPU kernel (one thread per element). */
 RustError snarkvm_hip_devtest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
 

@@ -6,6 +6,7 @@
 // point-range split of one MSM over the GPUs with a host-side combine, error reporting as RustError.
 // Fr entry points: api_fr.hip; point encoding + setup-time group operations: api_serde.hip; G2: api_g2.hip.
 #include "runtime.hip.h"
+#include "ffl.hip.h"
 
 runtime_t g_rt;
 
@@ -107,6 +108,7 @@ static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points
                 }
                 convert_bases<fq_t>(c, src, ffi_affine_sz, npoints, h->d[dev]);
                 precompute_tables(c, h.get(), h->d[dev]);
+                bases_to_lazy_form(c, h->d[dev], (size_t)tables * npoints);  // last: the tables are derived from one another in the exact form
                 HIP_TRY(hipStreamSynchronize(c.stream));
             };
             std::vector<int> all;
@@ -597,6 +599,80 @@ int snarkvm_hip_selftest_g1_msm_naive(const void* points, size_t npoints, size_t
     j.x.to_mem_mont().pack(o);
     j.y.to_mem_mont().pack(o + 12);
     j.z.to_mem_mont().pack(o + 24);
+    return 0;
+}
+// The lazily reduced accumulate arithmetic (ffl.hip.h) against the exact one (ff.hip.h / ec.hip.h) on the host, no device needed:
+// a chain of `iters` mixed additions of +-k G (k from a SplitMix64 stream over a pool of 64 multiples of the generator, so that
+// P + P, P + (-P) and additions to infinity all occur), every coordinate of the accumulator compared after every step; also the
+// field routines on values at the edges of their documented ranges.  Returns 0, or the (1-based) step of the first mismatch.
+int snarkvm_hip_selftest_fq_lazy(uint64_t seed, int iters) {
+    uint32_t xw[12], yw[12];
+    memcpy(xw, G1_GEN_X, 48);
+    memcpy(yw, G1_GEN_Y, 48);
+    const g1_aff_t g{fq_t::unpack(xw).from_mem_mont(), fq_t::unpack(yw).from_mem_mont()};
+    // pool[k] = (k + 1) G, affine, exact internal form
+    std::vector<g1_aff_t> pool;
+    g1_xyzz_t run = g1_xyzz_t::inf();
+    for (int k = 0; k < 64; k++) {
+        run.add_affine(g);
+        const fq_t izzz = run.zzz.inverse();
+        const fq_t izz = izzz.sqr() * run.zz.sqr();
+        pool.push_back({run.x * izz, run.y * izzz});
+    }
+    const fq_t c406 = fq_t::from_table(FqLConv::C406), c348 = fq_t::from_table(FqLConv::C348);
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    g1_xyzz_t exact = g1_xyzz_t::inf();
+    xyzz_lazy_t lazy = xyzz_lazy_t::infinity();
+    int prev = -1;
+    bool prev_neg = false;
+    for (int it = 0; it < iters; it++) {
+        const uint64_t r = next();
+        int k = (int)(r % 64);
+        bool neg = ((r >> 8) & 1) != 0;
+        const int mode = (int)((r >> 16) % 16);
+        if (mode == 0 && prev >= 0) k = prev, neg = prev_neg;    // the same point again
+        if (mode == 1 && prev >= 0) k = prev, neg = !prev_neg;   // its negative
+        if (mode == 2) {                                         // restart from infinity: acc = P, then P again -> doubling
+            exact = g1_xyzz_t::inf();
+            lazy = xyzz_lazy_t::infinity();
+        }
+        prev = k;
+        prev_neg = neg;
+        const g1_aff_t p = pool[k];
+        exact.add_affine(p, neg);
+        const fql_t px = fql_t::from_limbs(p.x * c406), py = fql_t::from_limbs(p.y * c406);
+        if (!lazy.madd(px, py, neg)) {  // exceptional (or a false alarm of the low-limb filter): the exact arithmetic decides
+            g1_xyzz_t e = lazy.to_exact();
+            fq_t ex, ey;
+            for (int i = 0; i < 13; i++) ex.v[i] = (uint32_t)px.v[i], ey.v[i] = (uint32_t)py.v[i];
+            e.add_affine({ex * c348, ey * c348}, neg);
+            lazy = xyzz_lazy_t::from_exact(e);
+        }
+        const g1_xyzz_t got = lazy.to_exact();
+        if (got.is_inf() != exact.is_inf()) return it + 1;
+        if (!exact.is_inf() && (got.x != exact.x || got.y != exact.y || got.zz != exact.zz || got.zzz != exact.zzz)) return it + 1;
+    }
+    // field routines on operands at the edges of their ranges: a = -q .. values near +-q with extreme limbs
+    for (int t = 0; t < 200; t++) {
+        fq_t a, b;
+        for (int i = 0; i < 13; i++) a.v[i] = (uint32_t)(next() & LIMB_MASK), b.v[i] = (uint32_t)(next() & LIMB_MASK);
+        a.v[12] &= 0x00ffffffu;
+        b.v[12] &= 0x00ffffffu;
+        if (t & 1) for (int i = 0; i < 12; i++) a.v[i] = LIMB_MASK;  // all-ones limbs
+        if (t & 2) for (int i = 0; i < 12; i++) b.v[i] = (i & 1) ? LIMB_MASK : 0;
+        const fql_t la = fql_t::from_exact(a), lb = fql_t::from_exact(b);
+        if (fql_t::mul(la, lb).to_exact() != a * b) return -(4 * t + 1);
+        if (fql_t::sqr(la - lb).to_exact() != (a - b).sqr()) return -(4 * t + 2);
+        if (fql_t::diff_of_products(la - lb, lb - la, fql_t::from_exact(a * b).normalized(), la).to_exact() != fq_t::diff_of_products(a - b, b - a, a * b, a))
+            return -(4 * t + 3);
+        if (((la + lb) - (lb + lb)).normalized().to_exact() != (a - b)) return -(4 * t + 4);
+    }
     return 0;
 }
 // The host-side finish of an MSM (runtime.hip.h msm_accum_t) on its own, no device needed: out (144 B) = sum_i 2^pos[i] *

@@ -40,6 +40,7 @@ RustError snarkvm_hip_register_bases_serialized(snarkvm_hip_bases_t** handle, co
                 HIP_TRY(hipMalloc((void**)&h->d[dev], (size_t)tables * npoints * sizeof(g1_aff_mem_t)));
                 serde_throw_on_status(g1_deserialize_run(c, bytes, npoints, compressed, validate, h->d[dev], nullptr), "register_bases_serialized");
                 sv_precompute_tables(c, h.get(), h->d[dev]);
+                bases_to_lazy_form(c, h->d[dev], (size_t)tables * npoints);
                 HIP_TRY(hipStreamSynchronize(c.stream));
             });
         } catch (...) {

@@ -81,10 +81,12 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
                 p.c = 16;
                 while (part % p.c) p.c--;
             }
+            if (p.c < 2) p.c = part <= 16 ? part : 2;
         } else if (part <= 16) {
             p.c = n >= 4096 ? 16 : 8;
             if (p.c > part) p.c = part;
             while (part % p.c) p.c--;
+            if (p.c < 2) p.c = part;  // a prime part width (13 x 20 tables ...) has no smaller window: one window per table set
         } else {
             // wide tables: the divisor d of the part width (d <= 16, or the whole part) with the least estimated work:
             // J * (part / d) * n bucket additions + ~8 addition-equivalents of sort / fold overhead per bucket
@@ -242,8 +244,32 @@ static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32
 // ------------------------------------------------------------------------------------------
 // 0. base conversion: Rust `Affine` (x, y Montgomery R = 2^384, infinity flag; stride bytes) -> g1_aff_mem_t
 // ------------------------------------------------------------------------------------------
+// form406 (G1 only): the slot holds the canonical residues of x * 2^406, y * 2^406 - the operand form of the lazily reduced
+// accumulate arithmetic (ffl.hip.h) - instead of the exact internal form x * 2^377: the same single product, another constant.
 template <class F>
-__global__ void convert_bases_kernel(const uint8_t* in, size_t stride, size_t n, aff_mem_t<F>* out) {
+SV_HD F base_coord_from_raw(const uint32_t* w, int form406) {
+    return F::from_raw_words(w);
+}
+template <>
+SV_HD fq_t base_coord_from_raw<fq_t>(const uint32_t* w, int form406) {
+    static constexpr uint32_t C399[13] = {0x1fb3d5efu, 0x1759ffffu, 0x161ae2aeu, 0x06bd319fu, 0x15cd6eabu, 0x15c6dfc5u, 0x00a7763du,
+                                          0x1e5d80e1u, 0x10d7c95fu, 0x04add573u, 0x1c80b321u, 0x02e104bau, 0x10f92f11u};  // 2^399 mod q
+    return form406 ? fq_t::unpack(w) * fq_t::from_table(C399) : fq_t::from_raw_words(w);
+}
+// in-place: exact internal form -> form406 (the last step of a G1 registration, after the tables have been derived from one another)
+static __global__ void g1_bases_to_form406_kernel(g1_aff_mem_t* slots, size_t n) {
+    static constexpr uint32_t C406[13] = {0x19eaf730u, 0x171ffffeu, 0x0d714cf8u, 0x044e31d8u, 0x1eb6e262u, 0x0bfad163u, 0x00d46e9cu,
+                                          0x10b6ddbfu, 0x13b9cbddu, 0x075782afu, 0x03bd1d8au, 0x1557cab6u, 0x15742a14u};  // 2^406 mod q
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fq_t c = fq_t::from_table(C406);
+    g1_aff_t a = g1_load_aff(&slots[i]);
+    a.x = a.x * c;  // the point at infinity (0, 0) stays (0, 0)
+    a.y = a.y * c;
+    store_aff<fq_t>(&slots[i], a);
+}
+template <class F>
+__global__ void convert_bases_kernel(const uint8_t* in, size_t stride, size_t n, aff_mem_t<F>* out, int form406) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = (const uint32_t*)(in + i * stride);  // stride is a multiple of 8 (Rust layout)
@@ -259,8 +285,8 @@ __global__ void convert_bases_kernel(const uint8_t* in, size_t stride, size_t n,
     if (inf) {
         a = aff_t<F>::inf();
     } else {
-        a.x = F::from_raw_words(xw);
-        a.y = F::from_raw_words(yw);
+        a.x = base_coord_from_raw<F>(xw, form406);
+        a.y = base_coord_from_raw<F>(yw, form406);
     }
     store_aff<F>(&out[i], a);
 }

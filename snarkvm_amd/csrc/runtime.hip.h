@@ -543,6 +543,9 @@ struct msm_multi_t {
     size_t hn = 0;    // points of the registered vector: virtual index = table * hn + base index
 };
 
+static bool msm_lazy_enabled();
+template <class F>
+static constexpr bool msm_lazy_field();
 // Device side of one MSM on lane `c`: d_bases = converted device bases; d_scalars = device scalars (32 B each).  Everything
 // is enqueued on the lane's stream, ending with the copy of the bit-plane sums into `host_planes` (pinned, >=
 // msm_plane_bytes<F>(...)); the caller synchronises the stream and runs msm_collect / msm_accum_t::finish.
@@ -818,6 +821,19 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             // multi: an entry's virtual index is the slot of its base in the handle's table array (d_bases[table * hn + index])
             const uint32_t vn = mu ? (uint32_t)mu->hn : (uint32_t)n, vn0 = mu ? 0xffffffffu : (uint32_t)n0;
             const size_t vstride = mu ? mu->hn : table_stride;
+            if constexpr (msm_lazy_field<F>()) {
+                if (msm_lazy_enabled()) {
+                    if (single_round && prefetch_ok && prefetch_env)
+                        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                                           d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                           c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride);
+                    else
+                        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
+                                           d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                           c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride);
+                    goto accumulated;
+                }
+            }
             if (single_round && prefetch_ok && prefetch_env)
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
                                    d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
@@ -826,6 +842,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
                                    d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
                                    c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride, dbg_mask);
+        accumulated:;
         }
         phase_end();
     }
@@ -892,10 +909,27 @@ static void msm_run_sync(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_
     c.phase_host("msm_host_finish", host_now_ms() - t0);  // the Horner chain over the bit planes, on the calling thread
 }
 
+// G1 accumulation runs on the lazily reduced arithmetic of ffl.hip.h (SNARKVM_HIP_LAZY=0: the exact kernel, A/B switch).  Process
+// wide: every G1 base slot an MSM reads - registered tables and the staging of table-less calls - then holds form406.
+static bool msm_lazy_enabled() {
+    static const int env = getenv("SNARKVM_HIP_LAZY") ? atoi(getenv("SNARKVM_HIP_LAZY")) : 1;
+    return env != 0;
+}
 template <class F>
-static void convert_bases(lane_t& c, const uint8_t* d_in, size_t stride, size_t n, aff_mem_t<F>* d_out, hipStream_t st = nullptr) {
+static constexpr bool msm_lazy_field() {
+    return sizeof(F) == sizeof(fq_t);  // G1 only; the Fq2 instantiations keep the exact arithmetic
+}
+template <class F>
+static void convert_bases(lane_t& c, const uint8_t* d_in, size_t stride, size_t n, aff_mem_t<F>* d_out, hipStream_t st = nullptr, bool for_msm = false) {
     if (!n) return;
-    hipLaunchKernelGGL((convert_bases_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st ? st : c.stream, d_in, stride, n, d_out);
+    const int form406 = for_msm && msm_lazy_field<F>() && msm_lazy_enabled() ? 1 : 0;
+    hipLaunchKernelGGL((convert_bases_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st ? st : c.stream, d_in, stride, n, d_out, form406);
+    HIP_TRY(hipGetLastError());
+}
+// the last step of a G1 registration: every slot of every table, exact internal form -> form406
+static void bases_to_lazy_form(lane_t& c, g1_aff_mem_t* d, size_t slots) {
+    if (!slots || !msm_lazy_enabled()) return;
+    hipLaunchKernelGGL(g1_bases_to_form406_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c.stream, d, slots);
     HIP_TRY(hipGetLastError());
 }
 
@@ -1079,7 +1113,7 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
             lane_t& c = *lg.lanes[j % L];
             uint8_t* raw = c.bases_tmp.template as<uint8_t>() + aff_bytes;
             if (prof) c.phase_begin("msm_convert_bases");
-            convert_bases<F>(c, raw, stride, chunk_cnt(j), c.bases_tmp.template as<aff_mem_t<F>>());
+            convert_bases<F>(c, raw, stride, chunk_cnt(j), c.bases_tmp.template as<aff_mem_t<F>>(), nullptr, true);
             if (prof) c.phase_end();
             pend[j] = msm_run<F>(c, c.bases_tmp.template as<aff_mem_t<F>>(), c.scalars_tmp.template as<uint4>(), chunk_cnt(j), c.pin.template as<uint8_t>() + slot * (j / L),
                                  0, nullptr, ~(size_t)0, 0, 1, 0, prof, 0);

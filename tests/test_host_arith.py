@@ -187,3 +187,12 @@ def test_msm_host_finish_matches_oracle():
     # nothing but infinity -> Projective::zero()
     rc = _lib.lib().snarkvm_hip_selftest_g1_finish(_p(planes[inf]), _p(pos[inf].copy()), ctypes.c_size_t(2), _p(out))
     assert rc == 0 and oracle.g1_to_affine(out)["infinity"][0] == 1
+
+
+def test_lazy_accumulate_arithmetic_matches_exact():
+    """csrc/ffl.hip.h (signed 29-bit limbs, R = 2^406, no canonical form inside the accumulate loop) against the exact
+    arithmetic of ff.hip.h / ec.hip.h, compiled for the host: chains of mixed additions with doublings, cancellations and
+    restarts from infinity, every coordinate compared after every step; then the field routines at the edges of their ranges."""
+    L = _lib.lib()
+    for seed in (1, 2, 3, 0xDEADBEEF):
+        assert L.snarkvm_hip_selftest_fq_lazy(ctypes.c_uint64(seed), ctypes.c_int(5000)) == 0, seed

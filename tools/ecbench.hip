@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "../snarkvm_amd/csrc/msm.hip.h"
+#include "../snarkvm_amd/csrc/ffl.hip.h"
 
 using namespace sv;
 
@@ -54,6 +55,29 @@ __global__ void __launch_bounds__(256, MINW) k_point(uint32_t* out, int iters, i
     }
     uint32_t x = 0;
     for (int i = 0; i < 13; i++) x ^= acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+    out[tid] = x;
+}
+
+// the lazily reduced arithmetic of ffl.hip.h: op 0 madd (xyzz_lazy_t::madd), 1 mul, 2 sqr, 3 diff_of_products
+template <int MINW, int op>
+__global__ void __launch_bounds__(256, MINW) k_lazy(uint32_t* out, int iters, int) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const fql_t px = fql_t::from_limbs(seed_fq(tid * 3 + 1)), py = fql_t::from_limbs(seed_fq(tid * 7 + 5));
+    xyzz_lazy_t acc;
+    acc.x = fql_t::from_limbs(seed_fq(tid + 11));
+    acc.y = fql_t::from_limbs(seed_fq(tid + 13));
+    acc.zz = fql_t::from_limbs(seed_fq(tid + 17));
+    acc.zzz = fql_t::from_limbs(seed_fq(tid + 19));
+    acc.inf = false;
+    uint32_t bad = 0;
+    for (int it = 0; it < iters; it++) {
+        if (op == 0) bad += acc.madd(px, py, (it & 1) != 0) ? 0u : 1u;
+        else if (op == 1) acc.x = fql_t::mul(acc.x, py);
+        else if (op == 2) acc.x = fql_t::sqr(acc.x - px).normalized();
+        else acc.y = fql_t::diff_of_products(acc.zz - px, acc.zzz - py, acc.y, px);
+    }
+    uint32_t x = bad;
+    for (int i = 0; i < 13; i++) x ^= (uint32_t)(acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i]);
     out[tid] = x;
 }
 
@@ -199,6 +223,11 @@ int main() {
                              run(k_point<2, OP>, cus * 2 * 4, IT, OP, d_out, e0, e1), run(k_point<3, OP>, cus * 3 * 4, IT, OP, d_out, e0, e1), \
                              run(k_point<4, OP>, cus * 4 * 4, IT, OP, d_out, e0, e1));
     ROW_P(0, 400) ROW_P(1, 400) ROW_P(2, 400)
+    const char* lnames[4] = {"lazy G1 madd (ffl.hip.h)", "lazy Fq mul", "lazy Fq sqr (+sub, norm)", "lazy Fq diff_of_products"};
+#define ROW_L(OP, IT) printf("%-24s %10.3f %10.3f %10.3f %10.3f\n", lnames[OP], run(k_lazy<1, OP>, cus * 1 * 4, IT, OP, d_out, e0, e1), \
+                             run(k_lazy<2, OP>, cus * 2 * 4, IT, OP, d_out, e0, e1), run(k_lazy<3, OP>, cus * 3 * 4, IT, OP, d_out, e0, e1), \
+                             run(k_lazy<4, OP>, cus * 4 * 4, IT, OP, d_out, e0, e1));
+    ROW_L(0, 400) ROW_L(1, 2000) ROW_L(2, 2000) ROW_L(3, 2000)
     // single-wave latency of one dependent group operation (the tails of a small MSM): one block of 64 threads
 #define LAT(OP) { const int it = 200; hipLaunchKernelGGL((k_point<1, OP>), dim3(1), dim3(64), 0, 0, d_out, 4, OP); CHECK(hipEventRecord(e0)); \
         hipLaunchKernelGGL((k_point<1, OP>), dim3(1), dim3(64), 0, 0, d_out, it, OP); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); \
