@@ -5,6 +5,7 @@
 // pool of (device, stream) resource tokens handed to concurrent callers, staging of the caller's host buffers, the
 // point-range split of one MSM over the GPUs with a host-side combine, error reporting as RustError.
 // Fr entry points: api_fr.hip; point encoding + setup-time group operations: api_serde.hip; G2: api_g2.hip.
+#define SV_TU_G1
 #include "runtime.hip.h"
 #include "ffl.hip.h"
 
@@ -672,6 +673,13 @@ int snarkvm_hip_selftest_fq_lazy(uint64_t seed, int iters) {
         if (fql_t::diff_of_products(la - lb, lb - la, fql_t::from_exact(a * b).normalized(), la).to_exact() != fq_t::diff_of_products(a - b, b - a, a * b, a))
             return -(4 * t + 3);
         if (((la + lb) - (lb + lb)).normalized().to_exact() != (a - b)) return -(4 * t + 4);
+        // raw memory image (how partial sums leave the accumulate kernel): a wide signed value through store_raw / load_raw
+        alignas(16) uint32_t raw[12];
+        const fql_t wide = (la - lb - lb - lb).normalized();
+        wide.store_raw(raw);
+        const fql_t back = fql_t::load_raw(raw);
+        for (int i = 0; i < 13; i++)
+            if (back.v[i] != wide.v[i]) return -(100000 + t);
     }
     return 0;
 }

@@ -226,6 +226,46 @@ struct fql_t {
         return r;
     }
 
+    // ---- raw memory image of a normalised value: the two's-complement 384-bit integer sum v_i 2^(29 i) in 12 words (limbs 0 .. 11
+    // fill bits 0 .. 347, the signed top limb bits 348 .. 379, sign-extended to 384).  How the accumulate kernel leaves its partial
+    // sums: no arithmetic at the flush; g1_partials_to_exact_kernel converts them afterwards.
+    SV_HD void store_raw(void* p) const {
+        uint32_t w[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) {
+                const int lo_bit = 29 * i - 32 * j;  // position of limb i's bit 0 inside word j
+                if (lo_bit > -29 && lo_bit < 32) x |= (lo_bit >= 0) ? ((uint32_t)v[i] << lo_bit) : ((uint32_t)v[i] >> (-lo_bit));
+            }
+            w[j] = x;
+        }
+        w[10] |= (uint32_t)v[12] << 28;        // bit 348 = word 10, bit 28
+        w[11] = (uint32_t)(v[12] >> 4);        // arithmetic: the sign fills the top four bits
+        uint4* q = (uint4*)p;
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    }
+    SV_HD static fql_t load_raw(const void* p) {
+        uint32_t w[12];
+        const uint4* q = (const uint4*)p;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const uint4 t = q[i];
+            w[4 * i] = t.x, w[4 * i + 1] = t.y, w[4 * i + 2] = t.z, w[4 * i + 3] = t.w;
+        }
+        fql_t r;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) {
+            const int bit = 29 * i, wi = bit / 32, sh = bit % 32;
+            const uint32_t lo = w[wi], hi = (wi + 1 < 12) ? w[wi + 1] : 0u;
+            r.v[i] = (int32_t)(((sh == 0) ? lo : ((lo >> sh) | (hi << (32 - sh)))) & MASK);
+        }
+        r.v[N - 1] = (int32_t)((w[10] >> 28) | (w[11] << 4));
+        return r;
+    }
+
     // ---- leaving the lazy domain: the canonical ff.hip.h value (internal form x 2^377, < q) of a normalised lazy value within
     // (-2^10 q, 2^10 q).  One product by 2^377 brings it into (-1.002 q, 0.002 q); then at most two additions of q.
     SV_HD fq_t to_exact() const {
@@ -258,9 +298,39 @@ struct fql_t {
     }
 };
 
+// A base slot of a G1 MSM on this arithmetic: the 128 bytes of a g1_aff_mem_t reinterpreted as 26 limbs - x then y, canonical
+// residues of the coordinates times 2^406, one 29-bit limb per word: the gather needs no unpacking (78 instructions per addition
+// with the packed 2 x 12-word image) - and a flag word for the point at infinity (a 26-limb zero test otherwise).
+struct alignas(128) g1_lazy_slot_t {
+    uint32_t w[32];  // [0, 13): x limbs, [13, 26): y limbs, [26]: 1 = point at infinity, [27, 32): unused
+    SV_HD void coords(fql_t& px, fql_t& py) const {
+#pragma unroll
+        for (int i = 0; i < 13; i++) px.v[i] = (int32_t)w[i], py.v[i] = (int32_t)w[13 + i];
+        SV_OPAQUE_13(px.v);
+        SV_OPAQUE_13(py.v);
+    }
+    // x406, y406: canonical residues (exact-arithmetic values whose limbs are read as plain integers)
+    SV_HD static void store(g1_aff_mem_t* slot, const fq_t& x406, const fq_t& y406, bool inf) {
+        uint32_t* o = (uint32_t*)slot;
+        uint4* q = (uint4*)slot;
+        uint32_t t[28];
+#pragma unroll
+        for (int i = 0; i < 13; i++) t[i] = inf ? 0u : x406.v[i], t[13 + i] = inf ? 0u : y406.v[i];
+        t[26] = inf ? 1u : 0u;
+        t[27] = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        (void)o;
+    }
+};
+static_assert(sizeof(g1_lazy_slot_t) == sizeof(g1_aff_mem_t), "a lazy base slot overlays the exact one");
+
 // ------------------------------------------------------------------------------------------------------------------------
 // XYZZ accumulator on the lazy arithmetic.  Infinity is a flag (zz is never tested for zero inside the loop).
 // ------------------------------------------------------------------------------------------------------------------------
+struct alignas(16) g1_lazy_partial_t {  // raw partial sum of the lazy accumulate kernel: x, y, zz, zzz limbs (4 x 13 words)
+    int32_t w[52];
+};
 struct xyzz_lazy_t {
     fql_t x, y, zz, zzz;  // normalised; x within (-1.1 q, 3.1 q), y within (-0.01 q, 1.01 q), zz / zzz within (-1.01 q, 0.01 q)
     bool inf;
@@ -274,6 +344,36 @@ struct xyzz_lazy_t {
     SV_HD g1_xyzz_t to_exact() const {
         if (inf) return g1_xyzz_t::inf();
         return {x.to_exact(), y.to_exact(), zz.to_exact(), zzz.to_exact()};
+    }
+    // raw partial sum: the 52 limbs as they are (208 bytes, no packing - the flush runs in most iterations of a wave, see
+    // msm_accumulate_lazy_kernel); infinity = all zero (zz = 0 converts to the exact zz = 0)
+    SV_HD void store_raw(g1_lazy_partial_t* p) const {
+        uint4* q = (uint4*)p;
+        if (inf) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) q[i] = make_uint4(0, 0, 0, 0);
+            return;
+        }
+        int32_t t[52];
+#pragma unroll
+        for (int i = 0; i < 13; i++) t[i] = x.v[i], t[13 + i] = y.v[i], t[26 + i] = zz.v[i], t[39 + i] = zzz.v[i];
+#pragma unroll
+        for (int i = 0; i < 13; i++) q[i] = make_uint4((uint32_t)t[4 * i], (uint32_t)t[4 * i + 1], (uint32_t)t[4 * i + 2], (uint32_t)t[4 * i + 3]);
+    }
+    SV_HD static g1_xyzz_t exact_from_raw(const g1_lazy_partial_t* p) {
+        const uint4* q = (const uint4*)p;
+        int32_t t[52];
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const uint4 u = q[i];
+            t[4 * i] = (int32_t)u.x, t[4 * i + 1] = (int32_t)u.y, t[4 * i + 2] = (int32_t)u.z, t[4 * i + 3] = (int32_t)u.w;
+        }
+        fql_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int i = 0; i < 13; i++) c[k].v[i] = t[13 * k + i];
+        return {c[0].to_exact(), c[1].to_exact(), c[2].to_exact(), c[3].to_exact()};
     }
     SV_HD static xyzz_lazy_t from_exact(const g1_xyzz_t& p) {
         xyzz_lazy_t r;

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "ec.hip.h"
+#include "ffl.hip.h"
 
 namespace sv {
 
@@ -244,29 +245,39 @@ static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32
 // ------------------------------------------------------------------------------------------
 // 0. base conversion: Rust `Affine` (x, y Montgomery R = 2^384, infinity flag; stride bytes) -> g1_aff_mem_t
 // ------------------------------------------------------------------------------------------
-// form406 (G1 only): the slot holds the canonical residues of x * 2^406, y * 2^406 - the operand form of the lazily reduced
-// accumulate arithmetic (ffl.hip.h) - instead of the exact internal form x * 2^377: the same single product, another constant.
+// form406 (G1 only): the slot becomes a g1_lazy_slot_t (ffl.hip.h) - the unpacked canonical residues of x * 2^406, y * 2^406, the
+// operand form of the lazily reduced accumulate arithmetic - instead of the exact internal form x * 2^377: the same single
+// product per coordinate, another constant.
 template <class F>
-SV_HD F base_coord_from_raw(const uint32_t* w, int form406) {
-    return F::from_raw_words(w);
+SV_HD void store_base_slot(aff_mem_t<F>* slot, const uint32_t* xw, const uint32_t* yw, bool inf, int form406) {
+    aff_t<F> a = aff_t<F>::inf();
+    if (!inf) {
+        a.x = F::from_raw_words(xw);
+        a.y = F::from_raw_words(yw);
+    }
+    store_aff<F>(slot, a);
 }
 template <>
-SV_HD fq_t base_coord_from_raw<fq_t>(const uint32_t* w, int form406) {
-    static constexpr uint32_t C399[13] = {0x1fb3d5efu, 0x1759ffffu, 0x161ae2aeu, 0x06bd319fu, 0x15cd6eabu, 0x15c6dfc5u, 0x00a7763du,
-                                          0x1e5d80e1u, 0x10d7c95fu, 0x04add573u, 0x1c80b321u, 0x02e104bau, 0x10f92f11u};  // 2^399 mod q
-    return form406 ? fq_t::unpack(w) * fq_t::from_table(C399) : fq_t::from_raw_words(w);
+SV_HD void store_base_slot<fq_t>(aff_mem_t<fq_t>* slot, const uint32_t* xw, const uint32_t* yw, bool inf, int form406) {
+    if (form406) {
+        const fq_t c = fq_t::from_table(FqLConv::C399);  // memory form x 2^384 -> x 2^406
+        g1_lazy_slot_t::store(slot, fq_t::unpack(xw) * c, fq_t::unpack(yw) * c, inf);
+        return;
+    }
+    g1_aff_t a = g1_aff_t::inf();
+    if (!inf) {
+        a.x = fq_t::from_raw_words(xw);
+        a.y = fq_t::from_raw_words(yw);
+    }
+    store_aff<fq_t>(slot, a);
 }
-// in-place: exact internal form -> form406 (the last step of a G1 registration, after the tables have been derived from one another)
+// in-place: exact slot -> g1_lazy_slot_t (the last step of a G1 registration, after the tables have been derived from one another)
 static __global__ void g1_bases_to_form406_kernel(g1_aff_mem_t* slots, size_t n) {
-    static constexpr uint32_t C406[13] = {0x19eaf730u, 0x171ffffeu, 0x0d714cf8u, 0x044e31d8u, 0x1eb6e262u, 0x0bfad163u, 0x00d46e9cu,
-                                          0x10b6ddbfu, 0x13b9cbddu, 0x075782afu, 0x03bd1d8au, 0x1557cab6u, 0x15742a14u};  // 2^406 mod q
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const fq_t c = fq_t::from_table(C406);
-    g1_aff_t a = g1_load_aff(&slots[i]);
-    a.x = a.x * c;  // the point at infinity (0, 0) stays (0, 0)
-    a.y = a.y * c;
-    store_aff<fq_t>(&slots[i], a);
+    const fq_t c = fq_t::from_table(FqLConv::C406);
+    const g1_aff_t a = g1_load_aff(&slots[i]);
+    g1_lazy_slot_t::store(&slots[i], a.x * c, a.y * c, a.is_inf());
 }
 template <class F>
 __global__ void convert_bases_kernel(const uint8_t* in, size_t stride, size_t n, aff_mem_t<F>* out, int form406) {
@@ -281,14 +292,7 @@ __global__ void convert_bases_kernel(const uint8_t* in, size_t stride, size_t n,
         yw[k] = src[MW + k];
     }
     const uint32_t inf = src[2 * MW] & 0xffu;
-    aff_t<F> a;
-    if (inf) {
-        a = aff_t<F>::inf();
-    } else {
-        a.x = base_coord_from_raw<F>(xw, form406);
-        a.y = base_coord_from_raw<F>(yw, form406);
-    }
-    store_aff<F>(&out[i], a);
+    store_base_slot<F>(&out[i], xw, yw, inf != 0, form406);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -47,7 +47,10 @@ struct msm_radix_params_t {
     uint32_t TPW;          // level-1 tiles per window = J * tiles_per_row
     const msm_inst_t* inst = nullptr;  // multi: K + 1 entries (the last one is a sentinel with pstart = n); window = instance, W == 1
     uint32_t ninst = 0;
-    uint32_t hn = 0;       // multi: points of the registered vector (virtual index = table * hn + base index)
+    // An entry's virtual index is the SLOT of its base relative to one base pointer B (the accumulate kernel reads B[v], no
+    // arithmetic): digit row of table j, scalar i  ->  j * vstride + (i < vn0 ? vr0 + i : vr1 + (i - vn0)).  (vn0, vr0, vr1) come
+    // from the instance table in a multi-instance run.
+    uint32_t vstride = 0, vn0 = 0, vr0 = 0, vr1 = 0;
 };
 // One level-1 tile: digits [lo, hi) of one digit row feeding bucket window w; its counters live at cbase + bin * TPW + tw.
 struct l1_tile_t {
@@ -199,23 +202,21 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* 
         cursor[i] = start;
     }
     __syncthreads();
-    // virtual index of digit position i: single MSM: table * n + i; multi: the slot of the base in the handle's table array
-    // (table * hn + base index), two base ranges per instance
-    const bool multi = p.inst != nullptr;
-    msm_inst_t in;
-    if (multi) in = p.inst[tl.inst_idx];
-    const uint32_t voff = multi ? tl.j * p.hn : (uint32_t)((size_t)tl.j * p.n);
+    // virtual index of digit position i = the slot of its base (msm_radix_params_t)
+    uint32_t pstart = 0, vn0 = p.vn0, vr0 = p.vr0, vr1 = p.vr1;
+    if (p.inst) {
+        const msm_inst_t in = p.inst[tl.inst_idx];
+        pstart = in.pstart, vn0 = in.n0, vr0 = in.off0, vr1 = in.off1;
+    }
+    const uint32_t voff = tl.j * p.vstride;
     const uint32_t lmask = (1u << p.LB) - 1;
     auto place = [&](uint32_t u, size_t i) {
         uint32_t b, neg;
         if (digit_bucket(u, half, b, neg)) {
             const uint32_t bin = b >> p.LB;
             const uint32_t pos = atomicAdd(&cursor[bin], 1u);
-            uint32_t vi = (uint32_t)i;
-            if (multi) {
-                const uint32_t idx = vi - in.pstart;
-                vi = idx < in.n0 ? in.off0 + idx : in.off1 + (idx - in.n0);
-            }
+            const uint32_t idx = (uint32_t)i - pstart;
+            const uint32_t vi = idx < vn0 ? vr0 + idx : vr1 + (idx - vn0);
             sv_[pos] = (voff + vi) | neg;
             sl_[pos] = (RT)(b & lmask);
             sbin_[pos] = (uint8_t)bin;
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) radix_scatter1_fused_kernel(con
                     const uint32_t lk = (uint32_t)rl * B1 + (b >> p.LB);
                     const uint32_t pos = atomicAdd(&cursor[lk], 1u);
                     const uint32_t j = (uint32_t)r / (uint32_t)p.W;
-                    sv_[pos] = ((uint32_t)((size_t)j * p.n) + i) | neg;
+                    sv_[pos] = (j * p.vstride + (i < p.vn0 ? p.vr0 + i : p.vr1 + (i - p.vn0))) | neg;
                     sl_[pos] = (uint16_t)(b & lmask);
                     skey_[pos] = (uint16_t)lk;
                 }
@@ -732,12 +733,9 @@ static __global__ void msm_alloc_seg_kernel(const uint32_t* __restrict__ boff, u
 // before the addition of entry pos starts, so its ~2 us of HBM latency run under the ~9 us of arithmetic.  Big MSMs keep two
 // resident waves per SIMD instead (the extra 24 registers of the prefetched slot were measured: no gain there).
 template <class F, int MINW, bool PREFETCH>  // MINW: waves per SIMD asked of the register allocator (3 -> <= 168 VGPRs for G1)
-__global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff_mem_t<F>* __restrict__ bases,
-                                                                 const aff_mem_t<F>* __restrict__ bases1, uint32_t n0,
-                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
-                                                                 const uint32_t* __restrict__ start, xyzz_mem_t<F>* __restrict__ partial,
-                                                                 uint32_t nbt, uint32_t S, uint32_t n, size_t table_stride,
-                                                                 uint32_t debug_idx_mask) {
+__global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff_mem_t<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                                 const uint32_t* __restrict__ boff, const uint32_t* __restrict__ start,
+                                                                 xyzz_mem_t<F>* __restrict__ partial, uint32_t nbt, uint32_t S, uint32_t debug_idx_mask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = boff[nbt];
     const uint64_t lo64 = (uint64_t)t * S;
@@ -747,12 +745,8 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
     uint32_t k = find_bucket(boff, nbt, lo);  // the non-empty bucket that contains entry `lo`
     uint32_t kend = boff[k + 1];
     xyzz_t<F> acc = xyzz_t<F>::inf();
-    auto slot_of = [&](uint32_t e) -> const aff_mem_t<F>* {
-        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
-        const uint32_t tbl = v / n;
-        const uint32_t idx = (v - tbl * n) & debug_idx_mask;  // bases come in up to two segments (mask: timing experiments only)
-        return (idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride;
-    };
+    // entry = slot of the base relative to `bases` (31 bits) | sign << 31  (mask: timing experiments of profiling builds only)
+    auto slot_of = [&](uint32_t e) -> const aff_mem_t<F>* { return &bases[(e & 0x7fffffffu) & debug_idx_mask]; };
     uint32_t e_next = sorted[lo];
     aff_mem_t<F> raw_next;
     if (PREFETCH) raw_next = *slot_of(e_next);
@@ -782,16 +776,33 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
     store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);
 }
 
+// raw partial sums of msm_accumulate_lazy_kernel (52 signed limbs, congruent to coordinate * 2^406) -> the exact representation
+// the tail kernels read (canonical, internal form): four products per partial sum, every lane busy
+static __global__ void __launch_bounds__(256) g1_partials_to_exact_kernel(const g1_lazy_partial_t* __restrict__ raw, g1_xyzz_mem_t* __restrict__ partial,
+                                                                   const uint32_t* __restrict__ start, uint32_t nbt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= start[nbt]) return;  // start[nbt] = number of partial sums
+    g1_store_xyzz(&partial[i], xyzz_lazy_t::exact_from_raw(&raw[i]));
+}
+// the cold path of the lazy kernel, out of line: acc += +-(px, py) on the exact arithmetic (doubling, cancellation, or a false alarm
+// of the low-limb filter).  Keeping ~9 000 instructions and their constants out of the kernel body relieves its scalar registers.
+static __device__ __noinline__ void lazy_exceptional_add(xyzz_lazy_t* acc, const fql_t* px, const fql_t* py, bool neg) {
+    g1_xyzz_t ex = acc->to_exact();
+    const fq_t c348 = fq_t::from_table(FqLConv::C348);
+    fq_t bx, by;
+#pragma unroll
+    for (int i = 0; i < 13; i++) bx.v[i] = (uint32_t)px->v[i], by.v[i] = (uint32_t)py->v[i];
+    ex.add_affine({bx * c348, by * c348}, neg);
+    *acc = xyzz_lazy_t::from_exact(ex);
+}
 // ---- the same kernel on the lazily reduced arithmetic of ffl.hip.h (G1).  The base slots hold canonical residues of the
-// coordinates times 2^406 (runtime.hip.h::bases_to_lazy_form / convert_bases form406); the accumulator lives in signed limbs
-// without a canonical form and is converted back to the exact representation when a partial sum is flushed (4 products per
-// flush against ~9.4 per addition).  The addition law's exceptional cases (the filter of xyzz_lazy_t::madd) are resolved on
+// coordinates times 2^406 as unpacked limbs (g1_lazy_slot_t; runtime.hip.h::bases_to_lazy_form / convert_bases form406); the accumulator lives in signed limbs
+// without a canonical form; partial sums are flushed raw and converted to the exact representation by a dense pass afterwards.  The addition law's exceptional cases (the filter of xyzz_lazy_t::madd) are resolved on
 // the exact arithmetic: cold code.  Per addition: 3 046 multiply-adds + ~900 other instructions (exact kernel: 2 951 + 2 238).
 template <bool PREFETCH>
-__global__ void __launch_bounds__(256, 1) msm_accumulate_lazy_kernel(const g1_aff_mem_t* __restrict__ bases, const g1_aff_mem_t* __restrict__ bases1,
-                                                              uint32_t n0, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ boff,
-                                                              const uint32_t* __restrict__ start, g1_xyzz_mem_t* __restrict__ partial, uint32_t nbt,
-                                                              uint32_t S, uint32_t n, size_t table_stride) {
+__global__ void __launch_bounds__(256, 1) msm_accumulate_lazy_kernel(const g1_aff_mem_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                              const uint32_t* __restrict__ boff, const uint32_t* __restrict__ start,
+                                                              g1_lazy_partial_t* __restrict__ partial, uint32_t nbt, uint32_t S, uint32_t debug_idx_mask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = boff[nbt];
     const uint64_t lo64 = (uint64_t)t * S;
@@ -800,49 +811,57 @@ __global__ void __launch_bounds__(256, 1) msm_accumulate_lazy_kernel(const g1_af
     const uint32_t hi = (total - lo < S) ? total : lo + S;
     uint32_t k = find_bucket(boff, nbt, lo);  // the non-empty bucket that contains entry `lo`
     uint32_t kend = boff[k + 1];
+    // slot of this thread's partial sum inside bucket k: start[k] + (t - first thread of the bucket).  Only the thread's FIRST bucket
+    // can have started in an earlier thread; every later one starts inside this segment, i.e. its first thread is t (no division
+    // inside the loop)
+    uint32_t part_off = t - boff[k] / S;
     xyzz_lazy_t acc = xyzz_lazy_t::infinity();
-    auto slot_of = [&](uint32_t e) -> const g1_aff_mem_t* {
-        const uint32_t v = e & 0x7fffffffu;  // virtual index = table * n + scalar index
-        const uint32_t tbl = v / n;
-        const uint32_t idx = v - tbl * n;
-        return (idx < n0 ? &bases[idx] : &bases1[idx - n0]) + (size_t)tbl * table_stride;
-    };
-    uint32_t e_next = sorted[lo];
-    g1_aff_mem_t raw_next;
-    if (PREFETCH) raw_next = *slot_of(e_next);
+    auto slot_of = [&](uint32_t e) -> const g1_lazy_slot_t* { return (const g1_lazy_slot_t*)&bases[(e & 0x7fffffffu) & debug_idx_mask]; };
+    // Software pipeline of the gather.  PREFETCH (one wave per SIMD, nothing else hides latency): two stages - the INDEX of entry
+    // pos + 2 and the BASE of entry pos + 1 are requested before the addition of entry pos starts, so neither the index load nor
+    // the dependent base load (index -> address) is ever waited for with an idle SIMD.  Otherwise (two resident waves): the index
+    // one iteration ahead, the base at its use.
+    uint32_t e_cur = sorted[lo];
+    uint32_t e_n1 = lo + 1 < hi ? sorted[lo + 1] : 0u;
+    g1_lazy_slot_t raw_next;
+    if (PREFETCH) raw_next = *slot_of(e_cur);
     for (uint32_t pos = lo;; pos++) {
         const bool end = pos >= hi;
-        if (end || pos >= kend) {  // bucket k ends here: flush its partial sum (one site for both cases: the code is 4 products long)
-            g1_store_xyzz(&partial[start[k] + (t - boff[k] / S)], acc.to_exact());
+        if (end || pos >= kend) {
+            // bucket k ends here: flush its partial sum - RAW (signed limbs, no arithmetic): the lanes of a wave reach their bucket
+            // boundaries in different iterations, so whatever the flush costs, the wave pays it in most iterations (at 2^24: 1.7
+            // flushes per 64 additions per lane = some lane flushes in 81 % of the iterations); g1_partials_to_exact_kernel
+            // converts all partial sums in one dense pass afterwards
+            acc.store_raw(&partial[start[k] + part_off]);
             if (end) break;
-            acc = xyzz_lazy_t::infinity();
+            part_off = 0;
+            acc.inf = true;  // the coordinates of an empty accumulator are never read
             do {
                 k++;
                 kend = boff[k + 1];
             } while (pos >= kend);
         }
-        const uint32_t e = e_next;
-        g1_aff_mem_t raw;
+        const uint32_t e = e_cur;
+        g1_lazy_slot_t raw;
         if (PREFETCH) {
             raw = raw_next;
-            if (pos + 1 < hi) {
-                e_next = sorted[pos + 1];
-                raw_next = *slot_of(e_next);
-            }
+            if (pos + 1 < hi) raw_next = *slot_of(e_n1);  // e_n1 arrived during the previous addition
         } else {
             raw = *slot_of(e);
-            if (pos + 1 < hi) e_next = sorted[pos + 1];
         }
-        const fq_t bx = fq_t::load(&raw.x), by = fq_t::load(&raw.y);
-        if (bx.is_zero() && by.is_zero()) continue;  // the point at infinity
+        e_cur = e_n1;
+        if (pos + 2 < hi) e_n1 = sorted[pos + 2];
+        if (raw.w[26]) continue;  // the point at infinity
         const bool neg = (e >> 31) != 0;
-        const fql_t px = fql_t::from_limbs(bx), py = fql_t::from_limbs(by);
+        fql_t px, py;
+        raw.coords(px, py);
         if (!acc.madd(px, py, neg)) {
-            // acc == +-P (or a false alarm of the low-limb filter, 6 * 2^-29 per addition): doubling / cancellation on the exact arithmetic
-            g1_xyzz_t ex = acc.to_exact();
-            const fq_t c348 = fq_t::from_table(FqLConv::C348);
-            ex.add_affine({bx * c348, by * c348}, neg);
-            acc = xyzz_lazy_t::from_exact(ex);
+            // acc == +-P (or a false alarm of the low-limb filter, 6 * 2^-29 per addition): resolved out of line on the exact arithmetic.
+            // The callee gets COPIES: an accumulator whose address escaped would live in scratch memory for the whole loop.
+            xyzz_lazy_t tmp = acc;
+            const fql_t tx = px, ty = py;
+            lazy_exceptional_add(&tmp, &tx, &ty, neg);
+            acc = tmp;
         }
     }
 }

@@ -120,7 +120,7 @@ struct lane_t {
     int index = 0;
     hipStream_t stream = nullptr;
     // MSM workspace
-    dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, planes;
+    dev_buf scalars, digits, counts, offsets, scan_tmp, sorted, boff, cnt_a, cnt_b, start_a, start_b, part_a, part_b, part_raw, planes;
     dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
     dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
     dev_buf fold_sums;                                                        // two-axis bucket fold
@@ -310,6 +310,9 @@ static void tu_kernel_attributes(int logical) {
     if ((int)done.size() <= logical) done.resize(logical + 1, 0);
     if (done[logical]) return;
     HIP_TRY(hipFuncSetAttribute((const void*)scan_one_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCAN_ONE_MAX * 4)));
+#ifdef SV_TU_G1  // the unit that launches the G1 MSMs (api.hip): see msm_acc_lds()
+    HIP_TRY(hipFuncSetAttribute((const void*)msm_accumulate_lazy_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+#endif
 #ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 #endif
@@ -543,6 +546,13 @@ struct msm_multi_t {
     size_t hn = 0;    // points of the registered vector: virtual index = table * hn + base index
 };
 
+// Single-round accumulate grids are 256 workgroups of 4 waves for 256 CUs - one wave per SIMD when every CU gets exactly one
+// workgroup.  The registers would let a CU take two, and the dispatcher does hand some CUs two while others stay idle; asking for
+// more than half of a CU's 160 KB of LDS (unused) makes the second workgroup impossible.  SNARKVM_HIP_ACC_LDS overrides (0: off).
+static size_t msm_acc_lds() {
+    static const long env = getenv("SNARKVM_HIP_ACC_LDS") ? atol(getenv("SNARKVM_HIP_ACC_LDS")) : 96 * 1024;
+    return env < 0 ? 0 : (size_t)env;
+}
 static bool msm_lazy_enabled();
 template <class F>
 static constexpr bool msm_lazy_field();
@@ -573,6 +583,13 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         throw hip_failure{hipErrorInvalidValue, "msm: geometry not eligible for a fused multi-instance run", __LINE__};
     if ((size_t)pl.Wd * n >= ((size_t)1 << 32)) throw hip_failure{hipErrorInvalidValue, "msm: windows * npoints must be < 2^32", __LINE__};
     if ((size_t)pl.J * n >= ((size_t)1 << 31)) throw hip_failure{hipErrorInvalidValue, "msm: tables * npoints must be < 2^31", __LINE__};
+    const aff_mem_t<F>* vb1 = d_bases1 ? d_bases1 : d_bases;
+    const aff_mem_t<F>* vbase = mu ? d_bases : (vb1 < d_bases ? vb1 : d_bases);
+    if (!mu) {
+        const size_t top0 = (size_t)(d_bases - vbase) + n0, top1 = (size_t)(vb1 - vbase) + (n - n0);
+        if ((size_t)(pl.J - 1) * table_stride + (top0 > top1 ? top0 : top1) >= ((size_t)1 << 31))
+            throw hip_failure{hipErrorInvalidValue, "msm: base slots must be addressable in 31 bits (tables * registered points < 2^31)", __LINE__};
+    }
     hipStream_t st = c.stream;
     const size_t E_max = (size_t)pl.Wd * n;
     const uint32_t nwin = mu ? mu->K : (uint32_t)pl.W;  // bucket windows of the tail (multi: one per instance)
@@ -646,10 +663,16 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         rp.c = pl.c;
         rp.W = pl.W;
         rp.J = pl.J;
+        // virtual indices = slots relative to vbase (msm_radix_params_t): the lower of the two base ranges, or the handle's table array
         if (mu) {
             rp.inst = mu->d_inst;
             rp.ninst = mu->K;
-            rp.hn = (uint32_t)mu->hn;
+            rp.vstride = (uint32_t)mu->hn;
+        } else {
+            rp.vn0 = (uint32_t)n0;
+            rp.vr0 = (uint32_t)(d_bases - vbase);
+            rp.vr1 = (uint32_t)(vb1 - vbase);
+            rp.vstride = (uint32_t)table_stride;
         }
         const int LBL = K < 7 ? K : 7;  // key bits of the last level
         rp.LB = wide ? 14 : LBL;        // bits left below the level-1 key
@@ -817,31 +840,31 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             constexpr uint32_t dbg_mask = 0xffffffffu;
 #endif
             // (a 3-waves-per-SIMD build of this kernel - 168 VGPRs - and a software-pipelined gather were measured: no gain)
-            static const int prefetch_env = getenv("SNARKVM_HIP_PREFETCH") ? atoi(getenv("SNARKVM_HIP_PREFETCH")) : 1;
-            // multi: an entry's virtual index is the slot of its base in the handle's table array (d_bases[table * hn + index])
-            const uint32_t vn = mu ? (uint32_t)mu->hn : (uint32_t)n, vn0 = mu ? 0xffffffffu : (uint32_t)n0;
-            const size_t vstride = mu ? mu->hn : table_stride;
+            static const int prefetch_env = getenv("SNARKVM_HIP_PREFETCH") ? atoi(getenv("SNARKVM_HIP_PREFETCH")) : 2;  // 0: never, 1: single-round launches only, 2: always (lazy kernel: -2 .. 3 %)
             if constexpr (msm_lazy_field<F>()) {
                 if (msm_lazy_enabled()) {
-                    if (single_round && prefetch_ok && prefetch_env)
-                        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                                           d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                           c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride);
+                    // raw partial sums (208 B each) go to their own buffer; the dense conversion pass fills part_a for the tail
+                    const size_t tmax = nthreads + nbt + 1;  // every thread leaves >= 1 partial sum, one more per bucket boundary inside its segment
+                    c.part_raw.ensure(tmax * sizeof(g1_lazy_partial_t));
+                    if ((single_round && prefetch_ok && prefetch_env) || prefetch_env >= 2)
+                        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256),
+                                           single_round && prefetch_ok ? msm_acc_lds() : 0, st, vbase, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                           c.part_raw.as<g1_lazy_partial_t>(), nbt, pl.S, dbg_mask);
                     else
-                        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                                           d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                           c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride);
+                        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,
+                                           c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_raw.as<g1_lazy_partial_t>(), nbt, pl.S, dbg_mask);
+                    hipLaunchKernelGGL(g1_partials_to_exact_kernel, dim3((unsigned)((tmax + 255) / 256)), dim3(256), 0, st,
+                                       (const g1_lazy_partial_t*)c.part_raw.as<g1_lazy_partial_t>(), c.part_a.as<g1_xyzz_mem_t>(),
+                                       (const uint32_t*)c.start_a.as<uint32_t>(), nbt);
                     goto accumulated;
                 }
             }
             if (single_round && prefetch_ok && prefetch_env)
-                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                                   d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride, dbg_mask);
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,
+                                   c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, dbg_mask);
             else
-                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_bases,
-                                   d_bases1 ? d_bases1 : d_bases, vn0, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                   c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, vn, vstride, dbg_mask);
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,
+                                   c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_a.as<xyzz_mem_t<F>>(), nbt, pl.S, dbg_mask);
         accumulated:;
         }
         phase_end();
