@@ -814,23 +814,22 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                            (uint8_t*)nullptr, nseg, LBL, 0);
         phase_end();
         // A single-round MSM (<= 2^22 digit entries: at most 2^16 accumulate threads) leaves at most 2^16 + nbt partial sums
-        // whatever the scalars are, and the tail kernels walk them position by position (msm.hip.h 7a/7b): no reduce round
-        // and no host read-back in the middle of the pipeline.  Bigger MSMs size their reduce rounds by the largest bucket
-        // (4-byte read-back): a round shrinks millions of partial sums to at most TAIL_PARTIALS per bucket before the fold
-        // reads them twice.
-        uint32_t max_bucket = 0;
-        if (!single_round) {
-            HIP_TRY(hipMemcpyAsync(&max_bucket, d_max, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
+        // whatever the scalars are, and the tail kernels walk them position by position (msm.hip.h 7a/7b): no reduce round.
+        // Bigger MSMs run a FIXED number of reduce rounds (2: each shrinks a bucket's partial sums 8x) before the fold reads
+        // them twice - what uniform scalars need anyway (the top digit row of a 253-bit scalar fills only 2^(253 mod c) buckets,
+        // thousands of entries each) - and the flattened-list fold takes whatever is left of a heavier bucket (all scalars
+        // equal at 2^24: 2 048 partial sums in one bucket, 32 additions per lane of its row and column).  Nothing is read back:
+        // an MSM of any size is one uninterrupted enqueue (round 2 sized the rounds by the largest bucket: a 4-byte copy and
+        // a stream synchronisation between sort and accumulate).
         // ---- 5. accumulate
         phase_begin("msm_accumulate");
         {
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
             static const size_t env_tailp = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 0;
             const size_t tail_partials = env_tailp ? env_tailp : 4;
-            if (!single_round)
-                for (size_t m = max_bucket ? ((size_t)max_bucket - 1) / pl.S + 2 : 0; m > tail_partials; m = (m + pl.S2 - 1) / pl.S2) rounds++;
+            static const int env_rounds = getenv("SNARKVM_HIP_REDUCE_ROUNDS") ? atoi(getenv("SNARKVM_HIP_REDUCE_ROUNDS")) : 2;
+            (void)tail_partials;
+            if (!single_round) rounds = env_rounds < 0 ? 0 : (env_rounds > 8 ? 8 : env_rounds);
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
@@ -897,7 +896,8 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         // buckets are throughput-bound: one wave per output
         const unsigned fold_blocks = ((1u << fold_m) + (1u << fold_hb)) * (unsigned)nwin;
         const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
-        if (single_round || fold_threads == 256u)  // flattened lists: any distribution, and 256 lanes busy on 128 buckets
+        static const int flat_env = getenv("SNARKVM_HIP_FOLD_FLAT") ? atoi(getenv("SNARKVM_HIP_FOLD_FLAT")) : 1;  // A/B switch
+        if (single_round || fold_threads == 256u || flat_env)  // flattened lists: any distribution of the partial sums over the buckets
             hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, pin, start_in,
                                cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
         else

@@ -416,6 +416,31 @@ def test_msm_wide_windows_skewed_buckets(golden):
     rb.close()
 
 
+def test_msm_multi_round_skewed_no_readback():
+    """A multi-round MSM (> 2^22 digit entries) sizes nothing by a host read-back: two fixed reduce rounds, then the flattened-list
+    fold takes whatever is left.  All scalars equal / two values / 90 % tiny at 2^19 pairs over 12 x 22-bit tables: single
+    buckets with 2^19 entries; closed form over bases (i + 1) G."""
+    import torch
+
+    n = 1 << 19
+    buf = _device_bases(n, start=1)
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=12, window_bits=22)
+    del buf
+    uni = synthetic.random_fr_integers(n, 9191)
+    rng = np.random.default_rng(5)
+    tiny = np.zeros_like(uni)
+    tiny[:, 0] = rng.integers(0, 4, n, dtype=np.uint64)
+    keep = rng.random(n) < 0.1
+    tiny[keep] = uni[keep]
+    for name, sc in (("all equal", np.tile(uni[:1], (n, 1))), ("two values", uni[rng.integers(0, 2, n)]), ("90 % tiny", tiny), ("r - 1", np.tile(util.limbs(pyref.R_MOD - 1, 4), (n, 1)))):
+        d_sc = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        got = rb.msm(device_ptr=d_sc.data_ptr(), npoints=n, window_bits=22)
+        kk = util.weighted_sum_mod_r(sc, start=1)
+        assert util.affine_equal(oracle.g1_to_affine(got), oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), util.limbs(kk, 4)))), name
+    rb.close()
+
+
 def test_msm_2_24_wide_closed_form():
     """2^24 pairs over 12 tables of 22-bit windows (the bench configuration), closed form as above."""
     import torch
