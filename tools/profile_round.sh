@@ -25,7 +25,7 @@ P=$(find $OUT/proofs -name "*.db" | head -1)
 [ -n "$F" ] && python tools/rocprof_summary.py pmc $F > $OUT/${TAG}_rocprofv3_pmc_fetch.txt
 [ -n "$W" ] && python tools/rocprof_summary.py pmc $W > $OUT/${TAG}_rocprofv3_pmc_write.txt
 [ -n "$Q" ] && python tools/rocprof_summary.py pmc $Q > $OUT/${TAG}_rocprofv3_pmc_sq_counters.txt
-[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on 'bench.py $ARGS0' (MSM 2^24 over 12 base tables of 22-bit windows, fused scalar read; NTT 2^24), MI355X, round 2" > $OUT/${TAG}_pmc_traffic.json
+[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on 'bench.py $ARGS0' (MSM 2^24 over 12 base tables of 22-bit windows, fused scalar read; NTT 2^24), MI355X, round 3" > $OUT/${TAG}_pmc_traffic.json
 # keep the merge small: the sqlite files stay on the box
 find $OUT -name "*.db" -delete
 ls -la $OUT
