@@ -421,7 +421,7 @@ def main():
     # Only quoted for the configuration they were collected on; PMC collection cannot run inside this process.
     default_cfg = args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits
     pmc = (load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
-    ceil = load_profile_json("r02_alu_ceilings.json")
+    ceil = load_profile_json("r03_alu_ceilings.json") or load_profile_json("r02_alu_ceilings.json")
 
     def traffic(kernel_prefix, fetch_key, times=1):
         for name, k in pmc.items():
@@ -440,15 +440,15 @@ def main():
         alu = None
         if ceil and acc_ms:
             alu = {
-                "kernel": "msm_accumulate_seg_kernel",
+                "kernel": "msm_accumulate_lazy_kernel",
                 "madds_per_launch": madds,
                 "madds_per_s": madds / (acc_ms * 1e-3),
-                "madd_ceiling_per_s": ceil.get("g1_madd_per_s"),
-                "frac": madds / (acc_ms * 1e-3) / ceil["g1_madd_per_s"] if ceil.get("g1_madd_per_s") else None,
-                "mads_per_launch": madds * 2938.0,  # v_mad_u64_u32 per mixed addition: 6 M + 2 S + one two-product reduction over 13 limbs
+                "madd_ceiling_per_s": ceil.get("g1_lazy_madd_per_s") or ceil.get("g1_madd_per_s"),
+                "frac": madds / (acc_ms * 1e-3) / (ceil.get("g1_lazy_madd_per_s") or ceil["g1_madd_per_s"]) if ceil.get("g1_madd_per_s") else None,
+                "mads_per_launch": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)),
                 "peak_mads_per_s": ceil.get("v_mad_u64_u32_per_s"),
-                "mad_frac": madds * 2938.0 / (acc_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"] if ceil.get("v_mad_u64_u32_per_s") else None,
-                "source": "profiles/r02_alu_ceilings.json (tools/ecbench.hip, tools/microbench.hip: wall-clock, whole chip)",
+                "mad_frac": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)) / (acc_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"] if ceil.get("v_mad_u64_u32_per_s") else None,
+                "source": "profiles/r03_alu_ceilings.json (tools/ecbench.hip k_lazy at the kernel's occupancy, tools/microbench.hip: wall-clock, whole chip)",
             }
         alu_ntt = None
         if ceil and ntt_kernel_ms and ceil.get("v_mad_u64_u32_per_s"):
@@ -491,7 +491,7 @@ def main():
             # kernel is integer-ALU bound, so `frac` is small by nature - `alu_roofline` is the bound that applies.
             "roofline": {
                 "bound": "hbm",
-                "kernel": "msm_accumulate_seg_kernel",
+                "kernel": "msm_accumulate_lazy_kernel",
                 "achieved": alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else None,
                 "peak": 8000.0,
                 "unit": "GB/s",
@@ -512,6 +512,16 @@ def main():
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
                 "traffic": traffic("radix_hist1_fused_kernel", "fetch_bytes_x2") if "msm_scalar_read" in phase_ms else traffic("msm_digits_kernel", "fetch_bytes_x2"),
                 "algorithmic_bytes": 32.0 * n,
+                # the whole scalar-consuming phase: the level-1 scatter (radix_scatter1_fused_kernel + its counter scans) reads every
+                # scalar a second time and writes 72 B of (index | sign, remainder) entries per scalar; still priced on 32 n bytes
+                "whole_phase": ({
+                    "kernels": "radix_hist1_fused + fused_chunk_sums / scan / fused_tile_offsets + radix_scatter1_fused",
+                    "ms": dig_ms + phase_ms["msm_sort_level1"],
+                    "achieved": (32.0 * n) / ((dig_ms + phase_ms["msm_sort_level1"]) * 1e-3) / 1e9,
+                    "frac": (32.0 * n) / ((dig_ms + phase_ms["msm_sort_level1"]) * 1e-3) / 1e9 / 8000.0,
+                    "bytes_moved_model": (32.0 + 32.0 + 72.0 + 3.0) * n,
+                    "frac_on_bytes_moved": (139.0 * n) / ((dig_ms + phase_ms["msm_sort_level1"]) * 1e-3) / 1e9 / 8000.0,
+                } if dig_ms and "msm_scalar_read" in phase_ms and phase_ms.get("msm_sort_level1") else None),
             },
             "roofline_ntt": {
                 "bound": "hbm",

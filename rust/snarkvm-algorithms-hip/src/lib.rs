@@ -271,6 +271,10 @@ pub mod resident {
         /// (off0[k], n0[k], off1[k], n1[k], coeffs[k]).
         pub fn commit_batch<Fr, Projective: Clone>(&self, ranges: &[(usize, usize, usize, usize)], coeffs: &[&[Fr]], montgomery: bool, zero: &Projective) -> Result<Vec<Projective>, Error> {
             assert_eq!(ranges.len(), coeffs.len());
+            for (r, c) in ranges.iter().zip(coeffs.iter()) {
+                // the same bounds `commit` asserts, per instance: a short slice would become an out-of-bounds host read
+                assert!(c.len() >= r.1 + r.3 && r.0 + r.1 <= self.len && r.2 + r.3 <= self.len);
+            }
             let off0: Vec<usize> = ranges.iter().map(|r| r.0).collect();
             let n0: Vec<usize> = ranges.iter().map(|r| r.1).collect();
             let off1: Vec<usize> = ranges.iter().map(|r| r.2).collect();

@@ -502,10 +502,17 @@ struct fq2_t {
         return x4 + x;
     }
     // fp2.rs:404-410: c0 = a0 b0 + nr a1 b1, c1 = a0 b1 + a1 b0   (nr = -5)
+    // Schoolbook with one Montgomery reduction per component (two-product columns on the signed accumulator of
+    // Fp::diff_of_products): 4 x 169 product multiply-adds + 2 x 169 reduction ones = the 1 014 of Karatsuba's three full
+    // products, without Karatsuba's five canonical additions / subtractions and with 18 fewer live limbs (no v0, v1, s).
     SV_HD fq2_t operator*(const fq2_t& b) const {
+#if defined(SV_FQ2_KARATSUBA)
         fq_t v0 = c0 * b.c0, v1 = c1 * b.c1;
         fq_t s = (c0 + c1) * (b.c0 + b.c1);  // Karatsuba cross term
         return {v0 - mul5(v1), s - v0 - v1};
+#else
+        return {fq_t::diff_of_products(c0, b.c0, mul5(c1), b.c1), fq_t::diff_of_products(c0, b.c1, c1.neg(), b.c0)};
+#endif
     }
     // fp2.rs:149-165 (same value)
     SV_HD fq2_t sqr() const {

@@ -744,6 +744,10 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
     const uint32_t hi = (total - lo < S) ? total : lo + S;
     uint32_t k = find_bucket(boff, nbt, lo);  // the non-empty bucket that contains entry `lo`
     uint32_t kend = boff[k + 1];
+    // bucket bookkeeping one bucket ahead (see msm_accumulate_lazy_kernel): no dependent loads at the flush
+    uint32_t kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+    uint32_t start_k = start[k];
+    uint32_t part_off = t - boff[k] / S;  // only the thread's first bucket can have started in an earlier thread
     xyzz_t<F> acc = xyzz_t<F>::inf();
     // entry = slot of the base relative to `bases` (31 bits) | sign << 31  (mask: timing experiments of profiling builds only)
     auto slot_of = [&](uint32_t e) -> const aff_mem_t<F>* { return &bases[(e & 0x7fffffffu) & debug_idx_mask]; };
@@ -752,12 +756,17 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
     if (PREFETCH) raw_next = *slot_of(e_next);
     for (uint32_t pos = lo; pos < hi; pos++) {
         if (pos >= kend) {  // bucket k ends inside this segment: flush and move to the bucket of `pos`
-            store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);
+            store_xyzz<F>(&partial[start_k + part_off], acc);
             acc = xyzz_t<F>::inf();
-            do {
+            part_off = 0;
+            k++;
+            kend = kend2;
+            while (pos >= kend) {
                 k++;
                 kend = boff[k + 1];
-            } while (pos >= kend);
+            }
+            kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+            start_k = start[k];
         }
         const uint32_t e = e_next;
         aff_mem_t<F> raw;
@@ -773,7 +782,7 @@ __global__ void __launch_bounds__(256, MINW) msm_accumulate_seg_kernel(const aff
         }
         acc.add_affine(load_aff<F>(&raw), (e >> 31) != 0);
     }
-    store_xyzz<F>(&partial[start[k] + (t - boff[k] / S)], acc);
+    store_xyzz<F>(&partial[start_k + part_off], acc);
 }
 
 // raw partial sums of msm_accumulate_lazy_kernel (52 signed limbs, congruent to coordinate * 2^406) -> the exact representation
@@ -811,6 +820,13 @@ __global__ void __launch_bounds__(256, 1) msm_accumulate_lazy_kernel(const g1_af
     const uint32_t hi = (total - lo < S) ? total : lo + S;
     uint32_t k = find_bucket(boff, nbt, lo);  // the non-empty bucket that contains entry `lo`
     uint32_t kend = boff[k + 1];
+    // The bucket bookkeeping runs one bucket ahead: the end of the NEXT bucket (boff[k + 2]) and the partial-sum slot of the
+    // CURRENT one (start[k]) are requested when a lane enters bucket k, so the flush at the bucket's end - reached by some lane
+    // of a wave in most iterations - finds both in registers instead of waiting for two dependent loads from 8 MB arrays
+    // (boff / start: one entry per bucket) while the wave's arithmetic stands still.  boff has nbt + 1 entries: the index is
+    // clamped (a clamped value is only ever compared after the segment's last entry).
+    uint32_t kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+    uint32_t start_k = start[k];
     // slot of this thread's partial sum inside bucket k: start[k] + (t - first thread of the bucket).  Only the thread's FIRST bucket
     // can have started in an earlier thread; every later one starts inside this segment, i.e. its first thread is t (no division
     // inside the loop)
@@ -832,14 +848,18 @@ __global__ void __launch_bounds__(256, 1) msm_accumulate_lazy_kernel(const g1_af
             // boundaries in different iterations, so whatever the flush costs, the wave pays it in most iterations (at 2^24: 1.7
             // flushes per 64 additions per lane = some lane flushes in 81 % of the iterations); g1_partials_to_exact_kernel
             // converts all partial sums in one dense pass afterwards
-            acc.store_raw(&partial[start[k] + part_off]);
+            acc.store_raw(&partial[start_k + part_off]);
             if (end) break;
             part_off = 0;
             acc.inf = true;  // the coordinates of an empty accumulator are never read
-            do {
+            k++;
+            kend = kend2;
+            while (pos >= kend) {  // empty buckets in between (rare: the sort leaves none for uniform scalars)
                 k++;
                 kend = boff[k + 1];
-            } while (pos >= kend);
+            }
+            kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+            start_k = start[k];
         }
         const uint32_t e = e_cur;
         g1_lazy_slot_t raw;

@@ -396,9 +396,18 @@ static inline ntt_plan_t ntt_make_plan(int lg) {
 }
 // tile width (log2) of a pass of radix 2^a whose tile dimension offers `avail` bits: [2^a x 2^lgT] elements of 36 bytes must
 // fit the 96 KiB the pass kernel may use
-static inline int ntt_tile_lg(int a, int avail) {
+// Small transforms (the 2^14 - 2^18 domains of a proof) would fill only 8 ... 128 of the chip's 256 CUs with [2^a x 8] tiles, and a
+// thread's work does not depend on the tile width (one radix-4 group per stage round): such passes take narrower tiles until
+// the launch has NTT_MIN_TILES workgroups (SNARKVM_HIP_NTT_MIN_TILES; the data is L2 resident at these sizes, so the shorter
+// coalesced runs of a narrow tile cost nothing).
+static inline int ntt_min_tiles() {
+    static const int v = getenv("SNARKVM_HIP_NTT_MIN_TILES") ? atoi(getenv("SNARKVM_HIP_NTT_MIN_TILES")) : 256;
+    return v;
+}
+static inline int ntt_tile_lg(int a, int avail, int lg_n) {
     int lgT = avail < 3 ? avail : 3;
     while (lgT > 0 && a + lgT > 11) lgT--;
+    while (lgT > 0 && ((size_t)1 << (lg_n - a - lgT)) < (size_t)ntt_min_tiles()) lgT--;
     return lgT;
 }
 
@@ -542,7 +551,7 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
         p.reduce_only = 0;
         if (!p.last) {
             p.s = lg - consumed - p.a;
-            p.lgT = ntt_tile_lg(p.a, p.s);
+            p.lgT = ntt_tile_lg(p.a, p.s, lg);
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
             const bool prelast = (k == pl.npass - 2);
             bool f = false;
@@ -552,7 +561,7 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
             p.reduce_only = folded ? 1 : 0;
             p.a1 = (pl.npass >= 2) ? pl.a[0] : 0;
             p.lg_mid = (pl.npass == 3) ? pl.a[1] : 0;
-            p.lgT = ntt_tile_lg(p.a, p.a1);
+            p.lgT = ntt_tile_lg(p.a, p.a1, lg);
         }
         if (pl.npass == 1) {
             p.in = data;

@@ -15,6 +15,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python ben
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python bench.py $ARGS0 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python bench.py $ARGS0 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU -d $OUT/sq -o s -- python bench.py $ARGS0 > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/sq2 -o t -- python bench.py $ARGS0 > $OUT/pmc_sq2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/proofs -o p -- python bench.py --workload proofs64 --proof-workers 8 > $OUT/proofs64_under_rocprof.log 2>&1
 find $OUT -name "*.db" | head
 S=$(find $OUT/stats -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1); Q=$(find $OUT/sq -name "*.db" | head -1)
@@ -25,6 +26,8 @@ P=$(find $OUT/proofs -name "*.db" | head -1)
 [ -n "$F" ] && python tools/rocprof_summary.py pmc $F > $OUT/${TAG}_rocprofv3_pmc_fetch.txt
 [ -n "$W" ] && python tools/rocprof_summary.py pmc $W > $OUT/${TAG}_rocprofv3_pmc_write.txt
 [ -n "$Q" ] && python tools/rocprof_summary.py pmc $Q > $OUT/${TAG}_rocprofv3_pmc_sq_counters.txt
+Q2=$(find $OUT/sq2 -name "*.db" | head -1)
+[ -n "$Q2" ] && python tools/rocprof_summary.py pmc $Q2 > $OUT/${TAG}_rocprofv3_pmc_sq_stall_counters.txt
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on 'bench.py $ARGS0' (MSM 2^24 over 12 base tables of 22-bit windows, fused scalar read; NTT 2^24), MI355X, round 3" > $OUT/${TAG}_pmc_traffic.json
 # keep the merge small: the sqlite files stay on the box
 find $OUT -name "*.db" -delete

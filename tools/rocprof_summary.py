@@ -65,12 +65,13 @@ def pmc(path):
     agg = {}
     for r in rows:
         key = (r[ix["kernel_name"]].split("(")[0].replace("sv::", ""), r[ix["counter_name"]])
-        a = agg.setdefault(key, [0, 0.0])
+        a = agg.setdefault(key, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += float(r[ix["value"]])
-    out = [f"{'kernel':60s} {'counter':14s} {'dispatches':>10s} {'sum':>16s} {'per_dispatch':>16s}"]
-    for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        out.append(f"{k:60s} {c:14s} {n:10d} {s:16.1f} {s / n:16.1f}")
+        a[2] = max(a[2], float(r[ix["value"]]))
+    out = [f"{'kernel':60s} {'counter':20s} {'dispatches':>10s} {'sum':>16s} {'per_dispatch':>16s} {'largest dispatch':>18s}"]
+    for (k, c), (n, s, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"{k:60s} {c:20s} {n:10d} {s:16.1f} {s / n:16.1f} {mx:18.1f}")
     return "\n".join(out)
 
 
