@@ -229,13 +229,22 @@ def main():
     def ntt_dev(t, lg, direction):
         _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(t.data_ptr()), ctypes.c_uint32(lg), 0, direction, 0))
 
-    def time_ntt(t, lg, steps):
-        ntt_dev(t, lg, 0)
-        ntt_dev(t, lg, 1)
+    def time_ntt(t, lg, steps, batched=True):
+        """`steps` transforms (forward / inverse alternating, so the vector ends as it began).  batched: ONE
+        snarkvm_hip_ntt_device_batch call - one enqueue, one synchronisation, like the MSM's pipelined batch (a prover round
+        issues its independent transforms this way); otherwise one synchronous snarkvm_hip_ntt_device call per transform."""
+        ptrs = (ctypes.c_void_p * steps)(*([t.data_ptr()] * steps))
+        dirs = (ctypes.c_int * steps)(*[i & 1 for i in range(steps)])
+        # untimed warm-up: the same number of transforms (the host-side preparation before this leg leaves the GPU idle for
+        # seconds; the first ~20 ms of work after an idle period run at a lower clock: 2.35 instead of 2.16 ms per 2^24 transform)
+        _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(steps), ctypes.c_uint32(lg), 0, dirs, None))
         barrier()
         t0 = time.perf_counter()
-        for i in range(steps):
-            ntt_dev(t, lg, i & 1)
+        if batched:
+            _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(steps), ctypes.c_uint32(lg), 0, dirs, None))
+        else:
+            for i in range(steps):
+                ntt_dev(t, lg, i & 1)
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
@@ -243,6 +252,7 @@ def main():
         args.ntt_steps += 1  # forward / inverse pairs: the vector is back to the input afterwards
     ntt_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps)
     ntt_elems_per_s = world * nn * args.ntt_steps / ntt_dt
+    ntt_sync_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps, batched=False)
     L.snarkvm_hip_set_profiling(1)
     ntt_dev(d_x, args.lg_ntt, 0)
     ntt_kernel_ms = L.snarkvm_hip_get_phase_ms(0)
@@ -300,7 +310,8 @@ def main():
         if args.lg_ntt >= 20:
             nt = 20
             d20 = time_ntt(d_x, 20, nt)
-            extra["ntt_2p20"] = {"value": (1 << 20) * nt / d20, "unit": "elements/s", "ms_per_transform": d20 / nt * 1e3}
+            d20s = time_ntt(d_x, 20, nt, batched=False)
+            extra["ntt_2p20"] = {"value": (1 << 20) * nt / d20, "unit": "elements/s", "ms_per_transform": d20 / nt * 1e3, "ms_per_transform_sync_calls": d20s / nt * 1e3}
         # -- the reference's own FFI symbols over host buffers (PCIe-inclusive; never `value`)
         ffi = {}
         host_bases = bases_dev.cpu().numpy().view(G1_AFFINE)
@@ -420,7 +431,7 @@ def main():
     # runs; gfx950 x2 FETCH correction), and the wall-clock arithmetic ceilings of tools/ecbench.hip / tools/microbench.hip.
     # Only quoted for the configuration they were collected on; PMC collection cannot run inside this process.
     default_cfg = args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits
-    pmc = (load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
+    pmc = (load_profile_json("r03_pmc_traffic.json") or load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
     ceil = load_profile_json("r03_alu_ceilings.json") or load_profile_json("r02_alu_ceilings.json")
 
     def traffic(kernel_prefix, fetch_key, times=1):
@@ -484,6 +495,8 @@ def main():
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
             "ntt_ms_per_transform": ntt_dt / args.ntt_steps * 1e3,
+            "ntt_sync_call": {"value": world * nn * args.ntt_steps / ntt_sync_dt, "unit": "elements/s", "ms_per_transform": ntt_sync_dt / args.ntt_steps * 1e3,
+                              "what": "one synchronous snarkvm_hip_ntt_device call per transform (ntt_value: the same transforms as one snarkvm_hip_ntt_device_batch call)"},
             "ntt_kernel_ms": ntt_kernel_ms,
             "ntt_vs_cpu_baseline": (ntt_elems_per_s / cpu["ntt_value"]) if cpu else None,
             "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
@@ -496,7 +509,7 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": (alg_bytes / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
-                "traffic": traffic("msm_accumulate_seg_kernel", "fetch_bytes_raw"),
+                "traffic": traffic("msm_accumulate_lazy_kernel", "fetch_bytes_raw") or traffic("msm_accumulate_seg_kernel", "fetch_bytes_raw"),
                 "algorithmic_bytes": alg_bytes,
                 "traffic_model": {"bytes": n * 100.0 * W, "what": "one gathered 96-B base + one 4-B sorted index per (pair, digit row)"},
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see alu_roofline; roofline_scalar_read is the HBM-bound phase",

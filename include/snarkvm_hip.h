@@ -97,6 +97,12 @@ int snarkvm_hip_num_devices(void);
 /* Same as snarkvm_ntt but `d_inout` is device memory (the call runs on the device that owns it). */
 RustError snarkvm_hip_ntt_device(void *d_inout, uint32_t lg_domain_size, int ntt_order, int ntt_direction,
                                  int ntt_type);
+/* `count` independent in-place transforms of 2^lg_domain_size elements over device vectors on one device: one enqueue, ONE
+ * synchronisation (the iNTTs of a prover round, e.g. z_a, z_b, z_c: algorithms/src/snark/varuna/ahp/prover/round_functions/
+ * second.rs:104-113).  ntt_directions / ntt_types: one value per vector, or NULL for all forward / all standard.  A vector
+ * listed twice is transformed twice, in list order. */
+RustError snarkvm_hip_ntt_device_batch(void *const *d_inouts, size_t count, uint32_t lg_domain_size, int ntt_order,
+                                       const int *ntt_directions, const int *ntt_types);
 
 /* Register a base vector once (SRS powers are static per proving key; the reference re-uploads
  * 104 B/point on every call, snarkvm.cu:262-275).  `points` is a Rust `[G1Affine]` with the given

@@ -845,9 +845,14 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                     // raw partial sums (208 B each) go to their own buffer; the dense conversion pass fills part_a for the tail
                     const size_t tmax = nthreads + nbt + 1;  // every thread leaves >= 1 partial sum, one more per bucket boundary inside its segment
                     c.part_raw.ensure(tmax * sizeof(g1_lazy_partial_t));
+                    // One workgroup per CU (a dynamic LDS request no second workgroup fits beside) = one accumulate wave per SIMD with half
+                    // of the register file and ~64 KB of LDS left free: single-round grids always; multi-round grids when
+                    // SNARKVM_HIP_ACC_ONE_WG is set - the sort and tail kernels of the NEXT instance of a pipelined batch (another
+                    // lane's stream) then find room beside the accumulate waves instead of waiting for gaps between its rounds.
+                    static const int one_wg_env = getenv("SNARKVM_HIP_ACC_ONE_WG") ? atoi(getenv("SNARKVM_HIP_ACC_ONE_WG")) : 0;
                     if ((single_round && prefetch_ok && prefetch_env) || prefetch_env >= 2)
                         hipLaunchKernelGGL((msm_accumulate_lazy_kernel<true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256),
-                                           single_round && prefetch_ok ? msm_acc_lds() : 0, st, vbase, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
+                                           (single_round && prefetch_ok) || one_wg_env ? msm_acc_lds() : 0, st, vbase, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
                                            c.part_raw.as<g1_lazy_partial_t>(), nbt, pl.S, dbg_mask);
                     else
                         hipLaunchKernelGGL((msm_accumulate_lazy_kernel<false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,

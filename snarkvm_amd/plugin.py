@@ -29,6 +29,18 @@ def NTT(domain_size, inout, ntt_order, ntt_direction, ntt_type):
     _lib.check(err)
 
 
+def NTT_device_batch(lg, device_ptrs, directions=None, types=None, ntt_order=0):
+    """Extension (no reference counterpart): `len(device_ptrs)` independent in-place transforms of 2^lg elements over device
+    vectors, one enqueue and one synchronisation (`snarkvm_hip_ntt_device_batch`).  directions / types: per vector or None."""
+    k = len(device_ptrs)
+    if k == 0:
+        return
+    ptrs = (ctypes.c_void_p * k)(*[int(p) for p in device_ptrs])
+    dirs = (ctypes.c_int * k)(*[int(d) for d in directions]) if directions is not None else None
+    tys = (ctypes.c_int * k)(*[int(t) for t in types]) if types is not None else None
+    _lib.check(_lib.lib().snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(k), ctypes.c_uint32(lg), ctypes.c_int(ntt_order), dirs, tys))
+
+
 def polymul(domain, polynomials, evaluations, zero=None):
     """lib.rs:100-145.  Returns the product as a (domain, 4) array (full domain length; the reference trims
     trailing zeros afterwards in DensePolynomial::from_coefficients_vec, multiplier.rs:93)."""

@@ -123,6 +123,12 @@ def replay(ws, salt=0, collect=None):
     def ntt(v, lg, direction, kind=0):
         timed("ntt", lambda: _lib.check(L.snarkvm_hip_ntt_device(_p(v), ctypes.c_uint32(lg), 0, direction, kind)))
 
+    def ntt_batch(vs, lg, directions):  # independent transforms of one round: one enqueue, one synchronisation
+        k = len(vs)
+        ptrs = (ctypes.c_void_p * k)(*[v.data_ptr() for v in vs])
+        dirs = (ctypes.c_int * k)(*directions)
+        timed("ntt", lambda: _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(k), ctypes.c_uint32(lg), 0, dirs, None)))
+
     def load(v, n, shift):  # a fresh "polynomial" of n coefficients (device copy on torch's stream: not part of the hot path)
         s = 4 * (shift + salt)
         with torch.cuda.device(ws.device):
@@ -132,8 +138,7 @@ def replay(ws, salt=0, collect=None):
             torch.cuda.current_stream().synchronize()
 
     def product(x, y, lg):  # PolyMultiplier::multiply of two coefficient vectors on the 2^lg domain, result in x
-        ntt(x, lg, 0)
-        ntt(y, lg, 0)
+        ntt_batch((x, y), lg, (0, 0))
         timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_mul_device(_p(x), _p(x), _p(y), ctypes.c_size_t(1 << lg))))
         ntt(x, lg, 1)
 
@@ -153,7 +158,8 @@ def replay(ws, salt=0, collect=None):
 
     load(a, nR, 1); ntt(a, sh.lg_r, 1); load(b, nR, 2); ntt(b, sh.lg_r, 0); commit_round([(a, nR - 2, 2)])         # round 1
     for i, v in enumerate((a, b, c)):                                                                             # round 2
-        load(v, nR, 10 + i); ntt(v, sh.lg_r, 1)
+        load(v, nR, 10 + i)
+    ntt_batch((a, b, c), sh.lg_r, (1, 1, 1))  # z_a, z_b, z_c (second.rs:104-113)
     with torch.cuda.device(ws.device):
         d.copy_(c)
         torch.cuda.current_stream().synchronize()

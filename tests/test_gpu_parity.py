@@ -66,6 +66,33 @@ def test_ntt_all_orders(lg):
             assert np.array_equal(got, oracle.ntt(x, order, d, oracle.STANDARD)), (lg, order, d)
 
 
+@pytest.mark.parametrize("lg", [0, 5, 12, 16, 18])
+def test_ntt_device_batch_vs_oracle(lg):
+    """snarkvm_hip_ntt_device_batch: several device vectors, mixed directions and types, one enqueue and one synchronisation -
+    every vector equals the oracle's transform; a vector listed twice is transformed twice in list order (round trip)."""
+    import torch
+
+    n = 1 << lg
+    xs = [_fr_vec(n, 7000 + 10 * lg + i) for i in range(5)]
+    dev = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in xs]
+    torch.cuda.synchronize()
+    dirs = [NTTDirection.Forward, NTTDirection.Inverse, NTTDirection.Forward, NTTDirection.Inverse, NTTDirection.Forward]
+    tys = [NTTType.Standard, NTTType.Standard, NTTType.Coset, NTTType.Coset, NTTType.Standard]
+    plugin.NTT_device_batch(lg, [t.data_ptr() for t in dev], dirs, tys)
+    for i in range(5):
+        got = dev[i].cpu().numpy().view(np.uint64).reshape(-1, 4)
+        assert np.array_equal(got, oracle.ntt(xs[i], oracle.ORDER_NN, dirs[i], tys[i])), (lg, i)
+    # the same vector forward then inverse in one batch: back to the forward input
+    before = dev[0].cpu().numpy().copy()
+    plugin.NTT_device_batch(lg, [dev[0].data_ptr(), dev[0].data_ptr()], [NTTDirection.Inverse, NTTDirection.Forward], None)
+    assert np.array_equal(dev[0].cpu().numpy(), before)
+    plugin.NTT_device_batch(lg, [])  # empty batch: nothing to do
+    # defaults (NULL directions / types) = forward, standard
+    plugin.NTT_device_batch(lg, [dev[1].data_ptr()])
+    want = oracle.ntt(oracle.ntt(xs[1], oracle.ORDER_NN, NTTDirection.Inverse, NTTType.Standard), oracle.ORDER_NN, NTTDirection.Forward, NTTType.Standard)
+    assert np.array_equal(dev[1].cpu().numpy().view(np.uint64).reshape(-1, 4), want)
+
+
 @pytest.mark.parametrize("lg", [20, 21, 22, 23])
 def test_ntt_large_vs_oracle(lg):
     """BASELINE configs[2] (domain sizes 2^18 - 2^24): every size of the range that the lg 0..19 sweep above and the 2^24 test
@@ -893,6 +920,10 @@ def test_extension_abi_rejects_bad_arguments(golden):
     err(L.snarkvm_hip_g1_group_ntt(P(out), ctypes.c_uint32(25), 0))                                            # lg > 24
     err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(27), 0, 0, 0))                       # lg > 26: caller falls back
     err(L.snarkvm_hip_ntt_device(ctypes.c_void_p(0x1000), ctypes.c_uint32(4), 7, 0, 0))                        # bad enum
+    one = (ctypes.c_void_p * 1)(0x1000)
+    err(L.snarkvm_hip_ntt_device_batch(one, ctypes.c_size_t(1), ctypes.c_uint32(27), 0, None, None))          # lg > 26
+    err(L.snarkvm_hip_ntt_device_batch(None, ctypes.c_size_t(1), ctypes.c_uint32(4), 0, None, None))           # null list
+    err(L.snarkvm_hip_ntt_device_batch(one, ctypes.c_size_t(1), ctypes.c_uint32(4), 0, None, None))            # not a device pointer of a device in use
     err(L.snarkvm_hip_g1_serialize(P(x), P(bases), ctypes.c_size_t(1), ctypes.c_size_t(96), 0))                # stride < 104
 
 
