@@ -193,3 +193,55 @@ def test_chunk_ring_single_device():
     script = RING_SCRIPT % (util.ROOT, os.path.join(util.ROOT, "tests", "golden", "beta_h_g2.bin"))
     r = subprocess.run([sys.executable, "-u", "-c", script], capture_output=True, text=True, env=env, timeout=1200, cwd=util.ROOT)
     assert "RING_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The A/B switches DESIGN.md quotes measurements for select other kernels / launch shapes for the same mathematics: every one of
+# them must return bit-identical results.  One subprocess per setting (the switches are read once per process).
+AB_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import cpu as oracle
+from snarkvm_amd import msm, plugin, synthetic
+from snarkvm_amd.layout import NTTDirection, NTTInputOutputOrder, NTTType
+from tests import util
+
+G = util.g1_generator_affine()
+def closed(s, start=1):
+    return oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(s, start=start), 4)))
+# NTT at proof sizes, all four transforms (the tile rule, SNARKVM_HIP_NTT_MIN_TILES)
+for lg in (12, 14, 15, 16, 17):
+    x = oracle.fr_op("from_bigint", synthetic.random_fr_integers(1 << lg, 4100 + lg))
+    for d in (NTTDirection.Forward, NTTDirection.Inverse):
+        for t in (NTTType.Standard, NTTType.Coset):
+            y = x.copy()
+            plugin.NTT(1 << lg, y, NTTInputOutputOrder.NN, d, t)
+            assert np.array_equal(y, oracle.ntt(x, oracle.ORDER_NN, d, t)), ("ntt", lg, d, t)
+# MSM: a single-round size, a multi-round size over wide windows, a fused batch of proof-sized instances
+n = (1 << 19) + 77
+bases = oracle.g1_gen_bases(G, 1, n)
+sc = synthetic.random_fr_integers(n, 4242)
+for tables, bits, m in ((16, 16, 70000), (13, 20, n)):
+    rb = msm.RegisteredBases(bases[:m], tables=tables, window_bits=bits)
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc[:m])), closed(sc[:m])), ("msm", tables, bits)
+    rb.close()
+rb = msm.RegisteredBases(bases[:1 << 17], tables=17, window_bits=15)
+sizes = [65536, 131072, 40000, 1, 99999]
+offs = [0, 0, 1000, 5, 31000]
+res = rb.msm_batch([sc[:k] for k in sizes], offsets=offs)
+for i, (k, o) in enumerate(zip(sizes, offs)):
+    assert util.affine_equal(oracle.g1_to_affine(res[i:i + 1]), closed(sc[:k], start=o + 1)), ("batch", i)
+rb.close()
+assert util.affine_equal(oracle.g1_to_affine(plugin.msm(bases[:300000], sc[:300000])), closed(sc[:300000])), "ffi"
+print("AB_OK")
+'''
+
+
+@pytest.mark.parametrize("env", [
+    {"SNARKVM_HIP_NTT_MIN_TILES": "1"}, {"SNARKVM_HIP_NTT_MIN_TILES": "1024"}, {"SNARKVM_HIP_LAZY": "0"}, {"SNARKVM_HIP_PREFETCH": "0"},
+    {"SNARKVM_HIP_ACC_ONE_WG": "1", "SNARKVM_HIP_ACC_LDS": "83968"}, {"SNARKVM_HIP_FUSE_BATCH": "0"}, {"SNARKVM_HIP_FUSED": "0"},
+    {"SNARKVM_HIP_S": "96"}, {"SNARKVM_HIP_REDUCE_ROUNDS": "0"}], ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
+def test_ab_switches_are_bit_exact(env):
+    r = subprocess.run([sys.executable, "-c", AB_SCRIPT % util.ROOT], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900, cwd=util.ROOT)
+    assert r.returncode == 0 and "AB_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
