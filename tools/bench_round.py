@@ -83,6 +83,13 @@ def main():
             fn()
         dt = (time.perf_counter() - t0) / reps
         res[name] = {"ms": dt * 1e3, "pairs_per_s": sum(sizes) / dt}
+    # HIP-event phases of one fused all14 call (events on the launch stream of the lane that ran the group)
+    L.snarkvm_hip_set_profiling(1)
+    all14()
+    res["all14_phase_ms"] = {L.snarkvm_hip_get_phase_name(i).decode(): round(L.snarkvm_hip_get_phase_ms(i), 4) for i in range(L.snarkvm_hip_get_phase_count())}
+    rb.msm_batch(device_ptrs=ptrs[:1], npoints=sizes[:1])
+    res["one_instance_batch_phase_ms"] = {L.snarkvm_hip_get_phase_name(i).decode(): round(L.snarkvm_hip_get_phase_ms(i), 4) for i in range(L.snarkvm_hip_get_phase_count())}
+    L.snarkvm_hip_set_profiling(0)
     print(json.dumps(res))
     rb.close()
 
