@@ -87,6 +87,11 @@ struct xyzz_t {
         r.zzz = w * zzz;
         return r;
     }
+    // The doublings inside the addition laws (P + P: one pair in 2^377 for random operands) are COLD code: out of line, they stop
+    // costing every addition site its ~3 500 (G1) / ~15 000 (G2) instructions of inlined doubling - the tail kernels hold a dozen
+    // addition sites each.  The callee works on copies (an object whose address escapes would live in scratch for the caller).
+    static SV_COLD void cold_dbl_affine(xyzz_t* out, const aff_t<F>* p) { *out = dbl_affine(*p); }
+    static SV_COLD void cold_dbl(xyzz_t* out, const xyzz_t* a) { *out = a->dbl(); }
     // this += p  (madd-2008-s); `negate` adds -p instead (signed-digit buckets)
     SV_HD void add_affine(const aff_t<F>& p_in, bool negate = false) {
         if (p_in.is_inf()) return;
@@ -101,10 +106,14 @@ struct xyzz_t {
         F pp_ = u2 - x;  // P
         F r = s2 - y;    // R
         if (pp_.is_zero()) {
-            if (r.is_zero())
-                *this = dbl_affine(p);
-            else
+            if (r.is_zero()) {
+                const aff_t<F> pc = p;
+                xyzz_t d;
+                cold_dbl_affine(&d, &pc);
+                *this = d;
+            } else {
                 *this = inf();
+            }
             return;
         }
         F pp = pp_.sqr();
@@ -130,10 +139,14 @@ struct xyzz_t {
         F pp_ = u2 - u1;
         F r = s2 - s1;
         if (pp_.is_zero()) {
-            if (r.is_zero())
-                *this = dbl();
-            else
+            if (r.is_zero()) {
+                const xyzz_t self = *this;
+                xyzz_t d;
+                cold_dbl(&d, &self);
+                *this = d;
+            } else {
                 *this = inf();
+            }
             return;
         }
         F pp = pp_.sqr();

@@ -28,6 +28,11 @@
 #include <stdint.h>
 
 #define SV_HD __host__ __device__ __forceinline__
+#if defined(SV_COLD_INLINE)  // A/B switch of profiling builds: the round-2 code shape (everything inlined)
+#define SV_COLD __host__ __device__ __forceinline__
+#else
+#define SV_COLD __host__ __device__ __noinline__  // exceptional paths: kept out of the hot code
+#endif
 
 namespace sv {
 

@@ -455,6 +455,16 @@ __device__ __forceinline__ xyzz_t<F> select_point(bool c, const xyzz_t<F>& a, co
 // Operands move between the lanes as DPP quad permutations.  Infinity operands are a final select; P = +-Q (U1 == U2) in any
 // quad sends the whole wave through the plain formula (wave-uniform branch; every lane of a quad takes the same path).
 template <class F>
+#if defined(SV_COLD_INLINE)
+static __device__ __forceinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {
+    acc->add(*o);
+}
+#else
+static __device__ __noinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {  // the cold fallback of quad_add, out of line
+    acc->add(*o);
+}
+#endif
+template <class F>
 __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
     const uint32_t r = threadIdx.x & 3;
     const bool inf1 = acc.is_inf(), inf2 = o.is_inf();
@@ -465,7 +475,10 @@ __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
     const F d = select_field((r & 1) != 0, m1, t) - select_field((r & 1) != 0, t, m1);  // P | P | R | R
     const bool same_x = !inf1 && !inf2 && r < 2 && d.is_zero();
     if (__ballot(same_x) != 0) {
-        acc.add(o);
+        xyzz_t<F> a2 = acc;
+        const xyzz_t<F> o2 = o;
+        quad_add_plain<F>(&a2, &o2);
+        acc = a2;
         return;
     }
     a = select_field((r & 1) == 0, d, select_field(r == 1, acc.zz, acc.zzz));
