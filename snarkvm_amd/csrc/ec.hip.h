@@ -87,9 +87,9 @@ struct xyzz_t {
         r.zzz = w * zzz;
         return r;
     }
-    // The doublings inside the addition laws (P + P: one pair in 2^377 for random operands) are COLD code: out of line, they stop
-    // costing every addition site its ~3 500 (G1) / ~15 000 (G2) instructions of inlined doubling - the tail kernels hold a dozen
-    // addition sites each.  The callee works on copies (an object whose address escapes would live in scratch for the caller).
+    // The doublings inside the addition laws (P + P: one pair in 2^377 for random operands) are cold code behind SV_COLD (ff.hip.h):
+    // inlined in the product build, out of line in development builds (-DSV_COLD_OOL).  The callee works on copies (an object
+    // whose address escapes would live in scratch for the caller).
     static SV_COLD void cold_dbl_affine(xyzz_t* out, const aff_t<F>* p) { *out = dbl_affine(*p); }
     static SV_COLD void cold_dbl(xyzz_t* out, const xyzz_t* a) { *out = a->dbl(); }
     // this += p  (madd-2008-s); `negate` adds -p instead (signed-digit buckets)

@@ -28,10 +28,14 @@
 #include <stdint.h>
 
 #define SV_HD __host__ __device__ __forceinline__
-#if defined(SV_COLD_INLINE)  // A/B switch of profiling builds: the round-2 code shape (everything inlined)
-#define SV_COLD __host__ __device__ __forceinline__
+// Exceptional paths (the doubling inside the addition laws, quad_add's plain fallback).  Out of line (-DSV_COLD_OOL, development
+// builds: `python -m snarkvm_amd.build --ool`) every addition site loses its inlined doubling and the full build takes 4.4 minutes
+// instead of 14; measured on one box against the inlined shape, though, the tail kernels of a 2^16 MSM run 10 % slower (0.184 vs
+// 0.167 ms: scratch for the callee's operand copies) and the G2 accumulate 5 % - so the product build inlines them.
+#if defined(SV_COLD_OOL)
+#define SV_COLD __host__ __device__ __noinline__
 #else
-#define SV_COLD __host__ __device__ __noinline__  // exceptional paths: kept out of the hot code
+#define SV_COLD __host__ __device__ __forceinline__
 #endif
 
 namespace sv {

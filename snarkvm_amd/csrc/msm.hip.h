@@ -455,7 +455,7 @@ __device__ __forceinline__ xyzz_t<F> select_point(bool c, const xyzz_t<F>& a, co
 // Operands move between the lanes as DPP quad permutations.  Infinity operands are a final select; P = +-Q (U1 == U2) in any
 // quad sends the whole wave through the plain formula (wave-uniform branch; every lane of a quad takes the same path).
 template <class F>
-#if defined(SV_COLD_INLINE)
+#if !defined(SV_COLD_OOL)
 static __device__ __forceinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {
     acc->add(*o);
 }
