@@ -36,7 +36,8 @@ def main():
     buf = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     _lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(n)))
-    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=17, window_bits=15)
+    tables, bits = int(os.environ.get("BENCH_ROUND_TABLES", "17")), int(os.environ.get("BENCH_ROUND_BITS", "15"))  # A/B of the geometry
+    rb = RegisteredBases(device_ptr=buf.data_ptr(), npoints=n, tables=tables, window_bits=0 if bits == 16 and tables == 16 else bits)
     host = [synthetic.random_fr_integers(k, 7700 + i) for i, k in enumerate(sizes)]
     dev = [torch.from_numpy(h.view(np.int64)).cuda() for h in host]
     torch.cuda.synchronize()
@@ -69,7 +70,7 @@ def main():
     def single():
         return np.concatenate([rb.msm(device_ptr=p, npoints=k) for p, k in zip(ptrs, sizes)])
 
-    res = {"fuse_batch": os.environ.get("SNARKVM_HIP_FUSE_BATCH", "1"), "pairs": sum(sizes), "instances": len(sizes)}
+    res = {"fuse_batch": os.environ.get("SNARKVM_HIP_FUSE_BATCH", "1"), "tables_x_bits": f"{tables} x {bits}", "pairs": sum(sizes), "instances": len(sizes)}
     for name, fn in (("all14", all14), ("rounds", by_rounds), ("single", single)):
         got = to_affine(fn())
         for i in range(len(sizes)):
