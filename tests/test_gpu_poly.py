@@ -40,7 +40,7 @@ def test_vec_ops(n):
     assert np.array_equal(poly.vec_op("rsub_scalar", a, scalar=s), oracle.fr_op("neg", oracle.fr_vec_op("sub_scalar", a, s)))
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 64, 1023, 1024, 1025, 32 * 32 * 32 + 5, 100003, 1 << 18])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 8, 9, 31, 32, 33, 64, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 32 * 32 * 32 + 5, 100003, 1 << 18, 2048 * 2048 + 5])  # 2 048 per workgroup, 8 per thread: one, two and three levels
 def test_divide_by_linear_and_evaluate(n):
     """polynomial / (X - z) (kzg10/mod.rs:213-236) and DensePolynomial::evaluate (dense.rs:98-114)."""
     a = _rnd(n, 10 + n)
