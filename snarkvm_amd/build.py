@@ -31,10 +31,10 @@ OBJDIR = os.environ.get("SNARKVM_HIP_OBJDIR", "/tmp/snarkvm_hip_obj")  # objects
 
 
 def build(force=False, verbose=False, fast=False, only=None, ool=False):
-    """fast=True (development only) compiles without the G2 / Fq2 instantiations.  ool=True (development only): exceptional paths
-    out of line (-DSV_COLD_OOL): the full build in 4.4 minutes instead of 14, kernels a few percent slower (ff.hip.h).  only=[...] (development only): recompile just
+    """fast=True (development only) compiles without the G2 / Fq2 instantiations.  ool=True (A/B switch): every exceptional
+    path out of line (-DSV_COLD_OOL): kernels a few percent slower, see ff.hip.h.  only=[...] (development only): recompile just
     the listed translation units and link them with the objects kept from the last build, whatever their age - for experiments
-    on a kernel that one unit instantiates (the Fq2 unit alone takes 14 minutes); the driver's build() always compiles everything."""
+    on a kernel that one unit instantiates (each unit takes 2 - 5 minutes); the driver's build() always compiles everything."""
     if not force and not only and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)

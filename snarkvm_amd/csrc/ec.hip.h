@@ -87,11 +87,17 @@ struct xyzz_t {
         r.zzz = w * zzz;
         return r;
     }
-    // The doublings inside the addition laws (P + P: one pair in 2^377 for random operands) are cold code behind SV_COLD (ff.hip.h):
-    // inlined in the product build, out of line in development builds (-DSV_COLD_OOL).  The callee works on copies (an object
-    // whose address escapes would live in scratch for the caller).
+    // The doubling inside the general addition (P + P: one pair in 2^377 for random operands) is cold code.  For Fq2 it is kept out
+    // of line: the tail kernels hold a dozen addition sites each, and ~15 000 instructions of inlined doubling per site made the
+    // Fq2 unit 14 of the build's 14 minutes (two 365 000-instruction kernels); measured on one box the out-of-line form costs
+    // the G2 tail nothing (0.92 vs 0.915 ms at 2^16).  The mixed addition of the accumulate loop keeps its doubling inlined
+    // (out of line: -5 % there), and so does everything over Fq (out of line: the 2^16 tail 0.184 vs 0.167 ms) unless the
+    // A/B switch -DSV_COLD_OOL asks otherwise (`python -m snarkvm_amd.build --ool`).
+    // The callee works on copies (an object whose address escapes would live in scratch for the caller).
+    static constexpr bool COLD_DBL_OOL = sizeof(F) > 64;
     static SV_COLD void cold_dbl_affine(xyzz_t* out, const aff_t<F>* p) { *out = dbl_affine(*p); }
     static SV_COLD void cold_dbl(xyzz_t* out, const xyzz_t* a) { *out = a->dbl(); }
+    static __host__ __device__ __noinline__ void cold_dbl_ool(xyzz_t* out, const xyzz_t* a) { *out = a->dbl(); }
     // this += p  (madd-2008-s); `negate` adds -p instead (signed-digit buckets)
     SV_HD void add_affine(const aff_t<F>& p_in, bool negate = false) {
         if (p_in.is_inf()) return;
@@ -142,7 +148,10 @@ struct xyzz_t {
             if (r.is_zero()) {
                 const xyzz_t self = *this;
                 xyzz_t d;
-                cold_dbl(&d, &self);
+                if constexpr (COLD_DBL_OOL)
+                    cold_dbl_ool(&d, &self);
+                else
+                    cold_dbl(&d, &self);
                 *this = d;
             } else {
                 *this = inf();

@@ -28,10 +28,11 @@
 #include <stdint.h>
 
 #define SV_HD __host__ __device__ __forceinline__
-// Exceptional paths (the doubling inside the addition laws, quad_add's plain fallback).  Out of line (-DSV_COLD_OOL, development
-// builds: `python -m snarkvm_amd.build --ool`) every addition site loses its inlined doubling and the full build takes 4.4 minutes
-// instead of 14; measured on one box against the inlined shape, though, the tail kernels of a 2^16 MSM run 10 % slower (0.184 vs
-// 0.167 ms: scratch for the callee's operand copies) and the G2 accumulate 5 % - so the product build inlines them.
+// Exceptional paths (the doubling inside the addition laws, quad_add's plain fallback).  -DSV_COLD_OOL (`python -m snarkvm_amd.build
+// --ool`, an A/B switch) puts ALL of them out of line; measured on one box against the inlined shape the tail kernels of a 2^16 G1 MSM
+// then run 10 % slower (0.184 vs 0.167 ms: scratch for the callee's operand copies) and the G2 accumulate 5 % - so the product
+// build inlines them, with one exception that costs nothing measurable and cut the build from 14 to 4.6 minutes: the general
+// addition over Fq2 (ec.hip.h COLD_DBL_OOL, msm.hip.h quad_add_plain).
 #if defined(SV_COLD_OOL)
 #define SV_COLD __host__ __device__ __noinline__
 #else

@@ -454,16 +454,22 @@ __device__ __forceinline__ xyzz_t<F> select_point(bool c, const xyzz_t<F>& a, co
 //   round 4   ZZZ3 = ZZZ1 ZZZ2 PPP | -  | R (Q - X3)   | S1 PPP            with X3 = R^2 - PPP - 2 Q
 // Operands move between the lanes as DPP quad permutations.  Infinity operands are a final select; P = +-Q (U1 == U2) in any
 // quad sends the whole wave through the plain formula (wave-uniform branch; every lane of a quad takes the same path).
+// the cold fallback of quad_add (equal x coordinates somewhere in the wave): inlined for Fq, out of line for Fq2 (see ec.hip.h)
 template <class F>
-#if !defined(SV_COLD_OOL)
-static __device__ __forceinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {
+static __device__ __noinline__ void quad_add_plain_ool(xyzz_t<F>* acc, const xyzz_t<F>* o) {
     acc->add(*o);
 }
+template <class F>
+__device__ __forceinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {
+#if defined(SV_COLD_OOL)
+    quad_add_plain_ool<F>(acc, o);
 #else
-static __device__ __noinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {  // the cold fallback of quad_add, out of line
-    acc->add(*o);
-}
+    if constexpr (sizeof(F) > 64)
+        quad_add_plain_ool<F>(acc, o);
+    else
+        acc->add(*o);
 #endif
+}
 template <class F>
 __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
     const uint32_t r = threadIdx.x & 3;
