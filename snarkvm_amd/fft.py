@@ -79,6 +79,26 @@ class PolyMultiplier:
         return res[: (nz[-1] + 1 if nz.size else 0)]
 
 
+    def element_wise_arithmetic_4_over_domain(self, domain, labels, f):
+        """multiplier.rs:136-178: the four labelled inputs on `domain` - polynomials through a forward transform (resized to the
+        domain), evaluation vectors resized - combined element by element by `f(a, b, c, d)` and interpolated back; returns the
+        trimmed coefficient vector.  `f` receives and returns (|domain|, 4) arrays (e.g. built from `snarkvm_amd.poly.vec_op`,
+        which runs on the device).  The reference evaluates in bit-reversed order (out-of-order FFT, `derange` of the
+        evaluation vectors, out-of-order iFFT); an element-wise `f` commutes with that permutation, so the natural-order
+        transforms give the same polynomial.  Like the reference it insists on exactly four inputs (`assert_eq!(p.len(), 4)`)."""
+        vecs = {}
+        for label, pol in self.polynomials:
+            vecs[label] = domain.fft(pol)  # `_resized`: zero-pad or truncate to the domain (multiplier.rs:155)
+        for label, ev in self.evaluations:
+            vecs[label] = domain._resized(ev)  # multiplier.rs:163
+        if len(vecs) != 4:
+            raise AssertionError("element_wise_arithmetic_4_over_domain needs exactly four distinctly labelled inputs")
+        result = np.ascontiguousarray(f(*[vecs[l] for l in labels]), dtype=np.uint64).reshape(-1, 4)
+        coeffs = domain.ifft(result)
+        nz = np.nonzero(coeffs.any(axis=1))[0]
+        return coeffs[: (nz[-1] + 1 if nz.size else 0)]
+
+
 class Evaluations:
     """fft/evaluations.rs:28-74: evaluations of a polynomial over a domain (thin wrappers over the transforms)."""
 

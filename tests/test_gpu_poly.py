@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import cpu as oracle
-from snarkvm_amd import _lib, kzg10, poly, synthetic
+from snarkvm_amd import _lib, fft, kzg10, poly, synthetic
 from tests import util
 from tests.test_gpu_parity import _srs
 
@@ -291,3 +291,33 @@ def test_evaluate_over_domain_incl_long_polynomials(n, lg):
         pad[: trimmed.shape[0]] = trimmed
         want = oracle.ntt(pad)
     assert np.array_equal(got, want)
+
+
+def test_element_wise_arithmetic_4_over_domain():
+    """`PolyMultiplier::element_wise_arithmetic_4_over_domain` (multiplier.rs:136-178): two polynomials and two evaluation vectors
+    on a 2^10 domain combined by f = a * b - c + d on the device, against the same composition of the oracle's transforms."""
+    lg = 10
+    n = 1 << lg
+    dom = fft.EvaluationDomain.new(n)
+    pa, pb = _rnd(300, 501), _rnd(n, 502)  # a short and a full-length polynomial
+    ec, ed = _rnd(n, 503), _rnd(700, 504)  # a full and a short (zero-padded) evaluation vector
+    m = fft.PolyMultiplier()
+    m.add_polynomial(pa, "a")
+    m.add_polynomial(pb, "b")
+    m.add_evaluation(ec, "c")
+    m.add_evaluation(ed, "d")
+    got = m.element_wise_arithmetic_4_over_domain(dom, ["a", "b", "c", "d"], lambda a, b, c, d: poly.vec_op("add", poly.vec_op("mul_sub", a, b, c), d))
+
+    def pad(v):
+        out = np.zeros((n, 4), dtype=np.uint64)
+        out[: v.shape[0]] = v
+        return out
+
+    ea, eb = oracle.ntt(pad(pa)), oracle.ntt(pad(pb))
+    comb = oracle.fr_op("add", oracle.fr_op("sub", oracle.fr_op("mul", ea, eb), ec), pad(ed))
+    want = poly.trim(oracle.ntt(comb, oracle.ORDER_NN, oracle.INVERSE, oracle.STANDARD))
+    assert np.array_equal(got, want)
+    with pytest.raises(AssertionError):
+        m2 = fft.PolyMultiplier()
+        m2.add_polynomial(pa, "a")
+        m2.element_wise_arithmetic_4_over_domain(dom, ["a", "a", "a", "a"], lambda a, b, c, d: a)
