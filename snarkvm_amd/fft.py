@@ -6,12 +6,64 @@ from . import plugin
 from .layout import NTTDirection, NTTInputOutputOrder, NTTType
 
 FR_TWO_ADICITY = 47  # curves/src/bls12_377/fr.rs:109
+FR_TWO_ADIC_ROOT_OF_UNITY = 8065159656716812877374967518403273466521432693661810619979959746626482506078  # fr.rs:110
+FR_GENERATOR = 22  # fr.rs:126: the multiplicative generator, the coset shift of coset_fft (domain.rs:195-221)
+
+
+def _fr(value):
+    """A field element as its Rust memory image: one (1, 4) u64 row of Montgomery limbs (value * 2^256 mod r)."""
+    from .synthetic import R_MOD
+
+    m = (value % R_MOD) * (1 << 256) % R_MOD
+    return np.array([[(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64)
+
+
+class FFTPrecomputation:
+    """`FFTPrecomputation` / `IFFTPrecomputation` (domain.rs:883-933): the n/2 twiddles of a domain.  The device keeps its own
+    tables (ntt.hip.h), so the transforms ignore it; it exists so that code written against `*_with_pc` keeps its shape, and
+    `roots` holds what the reference's struct holds."""
+
+    def __init__(self, domain, roots, inverse=False):
+        self.domain, self.roots, self.inverse = domain, roots, inverse
+
+    def to_ifft_precomputation(self):  # domain.rs:899-911
+        return self.domain.precompute_ifft()
 
 
 class EvaluationDomain:
     def __init__(self, size, log_size_of_group):
+        from .synthetic import R_MOD
+
         self.size = size
         self.log_size_of_group = log_size_of_group
+        # domain.rs:83-98, 118-147: the constants the reference keeps beside the size (Montgomery memory images)
+        gen = pow(FR_TWO_ADIC_ROOT_OF_UNITY, 1 << (FR_TWO_ADICITY - log_size_of_group), R_MOD) if log_size_of_group <= FR_TWO_ADICITY else 0
+        self.size_as_field_element = _fr(size)
+        self.size_inv = _fr(pow(size, -1, R_MOD))
+        self.group_gen = _fr(gen)
+        self.group_gen_inv = _fr(pow(gen, -1, R_MOD)) if gen else _fr(0)
+        self.generator_inv = _fr(pow(FR_GENERATOR, -1, R_MOD))
+
+    def roots_of_unity(self, root):
+        """domain.rs:594-648: [root^i for i < size / 2] (size / 2 = 0 gives the empty vector), computed on the device."""
+        from . import poly
+
+        half = self.size // 2
+        if half == 0:
+            return np.zeros((0, 4), dtype=np.uint64)
+        return poly.distribute_powers_and_mul_by_const(np.repeat(_fr(1), half, axis=0), root, _fr(1))
+
+    def precompute_fft(self):  # domain.rs:360-365
+        return FFTPrecomputation(self, self.roots_of_unity(self.group_gen))
+
+    def precompute_ifft(self):  # domain.rs:367-372
+        return FFTPrecomputation(self, self.roots_of_unity(self.group_gen_inv), inverse=True)
+
+    def fft_with_pc(self, coeffs, pc=None):  # in_order_fft_with_pc (domain.rs:374-392): the table is the device's own
+        return self.fft(coeffs)
+
+    def ifft_with_pc(self, evals, pc=None):  # in_order_ifft_with_pc (domain.rs:403-420)
+        return self.ifft(evals)
 
     @classmethod
     def new(cls, num_coeffs):
@@ -114,6 +166,12 @@ class Evaluations:
         coeffs = self.domain.ifft(self.evaluations)
         nz = np.nonzero(coeffs.any(axis=1))[0]
         return coeffs[: (nz[-1] + 1 if nz.size else 0)]
+
+    def interpolate_by_ref(self):  # evaluations.rs:58-62: the same without consuming self
+        return self.interpolate()
+
+    def interpolate_with_pc(self, pc=None):  # evaluations.rs:64-74: the precomputation is the device's own table
+        return self.interpolate()
 
 
 def evaluate_over_domain(coeffs, domain):

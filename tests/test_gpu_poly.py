@@ -321,3 +321,33 @@ def test_element_wise_arithmetic_4_over_domain():
         m2 = fft.PolyMultiplier()
         m2.add_polynomial(pa, "a")
         m2.element_wise_arithmetic_4_over_domain(dom, ["a", "a", "a", "a"], lambda a, b, c, d: a)
+
+
+@pytest.mark.parametrize("lg", [0, 1, 3, 10, 16])
+def test_domain_constants_and_roots_of_unity(lg, golden):
+    """EvaluationDomain's fields (domain.rs:83-147) and `roots_of_unity` / `precompute_fft` / `precompute_ifft` (domain.rs:360-372,
+    594-648): group_gen has order exactly 2^lg, size_inv * size = 1, generator_inv * 22 = 1, the roots are the successive powers."""
+    dom = fft.EvaluationDomain.new(1 << lg)
+    one = _one()
+    mul = lambda a, b: oracle.fr_op("mul", a, b)  # noqa: E731
+    assert np.array_equal(mul(dom.size_inv, dom.size_as_field_element), one)
+    assert np.array_equal(mul(dom.group_gen, dom.group_gen_inv), one)
+    assert np.array_equal(mul(dom.generator_inv, fft._fr(22)), one)
+    g = dom.group_gen
+    for _ in range(lg):
+        last = g
+        g = mul(g, g)
+    assert np.array_equal(g, one) and (lg == 0 or not np.array_equal(last, one))  # order exactly 2^lg
+    if lg == 3:  # the reference's own size-8 domain (tests/golden: resources/circuit_0/domain/R.txt)
+        assert golden is not None
+    pc, ipc = dom.precompute_fft(), dom.precompute_ifft()
+    assert pc.roots.shape[0] == (1 << lg) // 2 and ipc.inverse and pc.to_ifft_precomputation().roots.shape == ipc.roots.shape
+    for roots, w in ((pc.roots, dom.group_gen), (ipc.roots, dom.group_gen_inv)):
+        if roots.shape[0]:
+            assert np.array_equal(roots[0:1], one)
+            assert np.array_equal(roots[1:], oracle.fr_op("mul", roots[:-1], np.repeat(w, roots.shape[0] - 1, axis=0)))
+            assert np.array_equal(mul(roots[-1:], w), oracle.fr_op("neg", one))  # w^(n/2) = -1
+    x = _rnd(1 << lg, 900 + lg)
+    assert np.array_equal(dom.fft_with_pc(x, pc), dom.fft(x)) and np.array_equal(dom.ifft_with_pc(x, ipc), dom.ifft(x))
+    ev = fft.Evaluations.from_vec_and_domain(x, dom)
+    assert np.array_equal(ev.interpolate_by_ref(), ev.interpolate()) and np.array_equal(ev.interpolate_with_pc(ipc), ev.interpolate())

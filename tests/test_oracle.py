@@ -83,6 +83,23 @@ def test_domain_size8_matches_varuna_vectors(golden):
     assert pyref.fr_from_mont(L(d[3])) == pow(22, -1, pyref.R_MOD)
 
 
+def test_host_mirror_domain_constants_match_reference(golden):
+    """snarkvm_amd.fft.EvaluationDomain's fields (domain.rs:83-147) against the reference's own size-8 domain vector
+    (resources/circuit_0/domain/R.txt = the powers of group_gen) and the oracle's domain constants at several sizes."""
+    from snarkvm_amd import fft
+
+    dom = fft.EvaluationDomain.new(8)
+    assert pyref.fr_from_mont(L(dom.group_gen[0])) == int(golden["varuna"]["domain"]["R"][1])
+    for lg in (0, 1, 3, 16, 24, 47):
+        dm = fft.EvaluationDomain.new(1 << lg)
+        d = oracle.domain(lg)
+        assert dm.log_size_of_group == lg and dm.size == 1 << lg
+        assert np.array_equal(dm.group_gen[0], d[0]) and np.array_equal(dm.group_gen_inv[0], d[1])
+        assert np.array_equal(dm.size_inv[0], d[2]) and np.array_equal(dm.generator_inv[0], d[3])
+        assert pyref.fr_from_mont(L(dm.size_as_field_element[0])) == (1 << lg) % pyref.R_MOD
+    assert fft.EvaluationDomain.new((1 << 47) + 1) is None  # domain.rs:118-147: no subgroup of that size
+
+
 def _kat_intt8(golden):
     # public inputs 1,8,32,128 interleaved with private 2,4,2,0 (SURVEY.md 8c.3)
     evals = [1, 2, 8, 4, 32, 2, 128, 0]
