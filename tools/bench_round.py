@@ -71,7 +71,10 @@ def main():
         return np.concatenate([rb.msm(device_ptr=p, npoints=k) for p, k in zip(ptrs, sizes)])
 
     res = {"fuse_batch": os.environ.get("SNARKVM_HIP_FUSE_BATCH", "1"), "tables_x_bits": f"{tables} x {bits}", "pairs": sum(sizes), "instances": len(sizes)}
+    modes = os.environ.get("BENCH_ROUND_MODES", "all14,rounds,single").split(",")  # e.g. all14 alone under rocprofv3
     for name, fn in (("all14", all14), ("rounds", by_rounds), ("single", single)):
+        if name not in modes:
+            continue
         got = to_affine(fn())
         for i in range(len(sizes)):
             if got[i:i + 1].tobytes() != want[i]:
