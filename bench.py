@@ -12,9 +12,10 @@ SURVEY.md 8(d) (algorithmic bytes n * 128 + 144 for the whole MSM, 32 n for the 
 `alu_roofline` against the wall-clock-calibrated arithmetic ceilings of tools/ecbench.hip, and a `cpu_baseline` (the C++
 restatement of the reference's rayon path, oracle/, timed on this box's host cores on a bounded sample).
 
-`--workload proofs64`: BASELINE.json configs[4] - 64 Varuna-proof-shaped call lists (13 G1 commitments / openings of
-2^16-2^17, ~45 NTTs, the polynomial passes, one 2^16 G2 MSM each; snarkvm_amd/proofs.py) replayed by concurrent caller
-threads, 64 / N proofs per rank; `value` = proofs/s over all ranks (strong scaling), with pairs/s beside it.
+`--workload proofs64`: BASELINE.json configs[4] - 64 Varuna-proof-shaped call lists (14 G1 commitments / openings of
+2^16-2^17, ~45 NTTs, the polynomial passes, one 2^16 G2 MSM each; snarkvm_amd/proofs.py), 64 / N proofs per rank, replayed in
+lock step (`value`, proofs/s over all ranks, strong scaling) and by concurrent caller threads (`concurrent_callers`); one whole
+proof is checked against the CPU oracle.
 """
 import argparse
 import ctypes
@@ -82,7 +83,8 @@ def main():
     ap.add_argument("--cpu-lg-msm", type=int, default=24, help="CPU baseline sample: 2^k pairs of the same workload (24 = the full configuration, ~10 s on 64 threads)")
     ap.add_argument("--cpu-lg-ntt", type=int, default=24)
     ap.add_argument("--proofs", type=int, default=64)
-    ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64)")
+    ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64, callers mode)")
+    ap.add_argument("--proof-group", type=int, default=32, help="proofs replayed in lock step per group (proofs64, lockstep mode)")
     args = ap.parse_args()
 
     import torch
@@ -557,8 +559,14 @@ def main():
 
 
 def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
-    """BASELINE.json configs[4]: a batch of Varuna-proof-shaped call lists, sharded over the ranks (64 / N proofs each) and, inside
-    a rank, replayed by concurrent caller threads."""
+    """BASELINE.json configs[4]: a batch of Varuna-proof-shaped call lists, sharded over the ranks (64 / N proofs each).  Inside a
+    rank two ways of issuing them are timed, one after the other, on the same proofs:
+      lockstep   `VarunaSNARK::prove_batch` is a batch by construction (varuna.rs:336): round k of all proofs of a group is ONE
+                 fused MSM call, the transforms of a step ONE batched NTT call per size (snarkvm_amd/proofs.py::LockstepBatch);
+      callers    --proof-workers concurrent caller threads, one proof each at a time - the reference's rayon fan-out; their
+                 proof-sized MSMs meet in the library's coalescer.
+    `value` is the lock-step rate.  Every result of both modes is compared (after affine normalisation) and, on rank 0, all 15
+    results of one proof are checked against the CPU oracle's restatement of the same data flow (oracle/proof_replay.py)."""
     import torch
     import torch.distributed as dist
 
@@ -566,43 +574,86 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
 
     shape = proofs.ProofShape()
     keys = proofs.ProverKeys(shape)
-    batch = proofs.ProofBatch(keys, workers=args.proof_workers, devices=[dev_index])
     mine = list(range(rank, args.proofs, world))
-    # warm-up: one proof per worker (allocations, twiddle tables), and the serial reference results of two proofs
-    batch.run(list(range(len(batch.workspaces))))
-    serial = proofs.ProofBatch(keys, workers=1, devices=[dev_index])
-    probe = sorted({mine[0], mine[-1]}) if mine else []
-    _, want = serial.run(probe, collect=True)
+    checks = {}
+    # ---- lock step
+    lock = proofs.LockstepBatch(keys, group=min(args.proof_group, max(1, len(mine))), devices=[dev_index])
+    lock.run(mine[: lock.group])  # warm-up: allocations, twiddle tables
     barrier()
     t0 = time.perf_counter()
-    _, got = batch.run(mine, collect=True)
+    _, got_lock = lock.run(mine, collect=True)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
-    for p, w in zip(probe, want):
-        if proofs.normalize_results(got[mine.index(p)]) != proofs.normalize_results(w):
-            raise SystemExit(f"bench.py: proof {p} replayed concurrently differs from its serial replay")
-    t = {k: sum(ws.times[k] for ws in batch.workspaces) for k in batch.workspaces[0].times}
+    dt_lock = max_over_ranks(time.perf_counter() - t0)
+    t_lock = dict(lock.workspaces[0].times)
+    del lock
+    torch.cuda.empty_cache()
+    # ---- concurrent callers
+    batch = proofs.ProofBatch(keys, workers=args.proof_workers, devices=[dev_index])
+    batch.run(list(range(len(batch.workspaces))))  # warm-up: one proof per worker
+    for ws in batch.workspaces:
+        ws.times = {k: 0.0 for k in ws.times}
+    barrier()
+    t0 = time.perf_counter()
+    _, got_thr = batch.run(mine, collect=True)
+    barrier()
+    dt_thr = max_over_ranks(time.perf_counter() - t0)
+    t_thr = {k: sum(ws.times[k] for ws in batch.workspaces) for k in batch.workspaces[0].times}
+    # ---- checks (outside the timed regions)
+    norm_lock = [proofs.normalize_results(r) for r in got_lock]
+    norm_thr = [proofs.normalize_results(r) for r in got_thr]
+    for i, p in enumerate(mine):
+        if norm_lock[i] != norm_thr[i]:
+            raise SystemExit(f"bench.py: proof {p}: the lock-step replay and the concurrent-caller replay differ")
+    checks["lockstep_vs_callers"] = f"all {len(mine)} proofs of this rank: 14 commitments + the G2 result identical in both modes"
+    if rank == 0 and mine and not args.no_cpu_baseline:
+        from oracle import cpu as oracle
+        from oracle import proof_replay
+
+        oracle.set_threads(min(os.cpu_count() or 1, 64))
+        p = mine[-1]
+        t0 = time.perf_counter()
+        want = proof_replay.expected_results(keys.pool_host, keys.g1_host, keys.g2_host, keys.point, shape.lg_r, shape.lg_k, shape.lg_g2, shape.nmax, p)
+        oracle_s = time.perf_counter() - t0
+        got = got_lock[mine.index(p)]
+        from snarkvm_amd import kzg10
+        from snarkvm_amd.layout import G1_PROJECTIVE, G2_PROJECTIVE
+        for j in range(14):
+            ga = kzg10.to_affine(np.frombuffer(got[j], dtype=G1_PROJECTIVE))
+            wa = want[j]
+            if not (np.array_equal(ga["x"], wa["x"]) and np.array_equal(ga["y"], wa["y"]) and np.array_equal(ga["infinity"], wa["infinity"])):
+                raise SystemExit(f"bench.py: proof {p}, commitment {j}: the device result differs from the CPU oracle")
+        if want[14] is not None:
+            g2a = oracle.g2_to_affine(np.frombuffer(got[14], dtype=G2_PROJECTIVE))
+            if g2a.tobytes() != want[14].tobytes():
+                raise SystemExit(f"bench.py: proof {p}: the G2 MSM result differs from the CPU oracle")
+        checks["one_proof_vs_oracle"] = (f"proof {p}: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py (fft_in_place, pointwise passes, "
+                                         f"divide_with_q_and_r, batched::msm, standard::msm restatements; {oracle_s:.1f} s on the host)")
     if rank == 0:
         print(json.dumps({
             "metric": "Varuna-proof-shaped hot-path replays per second (BASELINE.json configs[4]: batch of 64, G1 + G2)",
-            "value": args.proofs / dt,
+            "value": args.proofs / dt_lock,
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.proofs,
-            "warmup": len(batch.workspaces),
-            "ms_per_step": dt / args.proofs * 1e3,
+            "warmup": min(args.proof_group, len(mine)),
+            "ms_per_step": dt_lock / args.proofs * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": DTYPE,
             "data": "synthetic",
-            "config": {"workload": "64 x (13 G1 commitments / openings of 2^16-2^17 pairs in 6 batched rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM); "
-                                   "device-resident random data, transfer_private domain sizes",
-                       "proofs": args.proofs, "caller_threads_per_rank": len(batch.workspaces), "proofs_per_rank": len(mine)},
-            "g1_pairs_per_s": args.proofs * shape.pairs() / dt,
-            "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt,
-            "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t.items()},
-            "checks": {"concurrent_vs_serial": f"proofs {probe}: all 14 commitments + the G2 result identical to a serial replay"},
+            "config": {"workload": "64 x (14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM); "
+                                   "device-resident random data, transfer_private domain sizes; lock-step batch (prove_batch shape)",
+                       "proofs": args.proofs, "lockstep_group": min(args.proof_group, max(1, len(mine))), "proofs_per_rank": len(mine)},
+            "g1_pairs_per_s": args.proofs * shape.pairs() / dt_lock,
+            "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt_lock,
+            "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_lock.items()},
+            "concurrent_callers": {"value": args.proofs / dt_thr, "unit": "proofs/s", "ms_per_proof": dt_thr / args.proofs * 1e3,
+                                   "caller_threads_per_rank": len(batch.workspaces), "g1_pairs_per_s": args.proofs * shape.pairs() / dt_thr,
+                                   "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_thr.items()},
+                                   "what": "one proof per caller thread at a time (the reference's rayon fan-out); proof-sized MSMs of concurrent callers fused by the in-library coalescer"},
+            "rank_ms_per_step": dt_lock / max(1, len(mine)) * 1e3,
+            "checks": checks,
         }))
     keys.close()
     if world > 1:

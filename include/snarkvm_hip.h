@@ -100,9 +100,20 @@ RustError snarkvm_hip_ntt_device(void *d_inout, uint32_t lg_domain_size, int ntt
 /* `count` independent in-place transforms of 2^lg_domain_size elements over device vectors on one device: one enqueue, ONE
  * synchronisation (the iNTTs of a prover round, e.g. z_a, z_b, z_c: algorithms/src/snark/varuna/ahp/prover/round_functions/
  * second.rs:104-113).  ntt_directions / ntt_types: one value per vector, or NULL for all forward / all standard.  A vector
- * listed twice is transformed twice, in list order. */
+ * listed twice is transformed twice, in list order.  Consecutive distinct vectors with the same direction and type share ONE
+ * kernel launch per pass (up to 48 vectors). */
 RustError snarkvm_hip_ntt_device_batch(void *const *d_inouts, size_t count, uint32_t lg_domain_size, int ntt_order,
                                        const int *ntt_directions, const int *ntt_types);
+
+/* Deferred synchronisation for device-resident operands.  Between snarkvm_hip_scope_begin (d_any: any device pointer on the GPU
+ * to use, or NULL for any GPU) and snarkvm_hip_scope_end, calls of THIS thread whose operands and results live in device memory
+ * - snarkvm_hip_ntt_device, _ntt_device_batch, _fr_mul_device, _fr_convert_device and the snarkvm_hip_fr_* vector kernels with
+ * on_device = 1 - are enqueued on one stream, in call order, and return without waiting; snarkvm_hip_scope_end waits once.  The
+ * 32-byte host `remainder` of snarkvm_hip_fr_divide_by_linear is delivered by scope_end.  Every other call (MSMs, host buffers, a
+ * pointer on another GPU) first waits for the scope's queued work, so results are the same as without a scope.  Scopes do not
+ * nest; a scope must be ended by the thread that began it. */
+RustError snarkvm_hip_scope_begin(const void *d_any);
+RustError snarkvm_hip_scope_end(void);
 
 /* Register a base vector once (SRS powers are static per proving key; the reference re-uploads
  * 104 B/point on every call, snarkvm.cu:262-275).  `points` is a Rust `[G1Affine]` with the given

@@ -3,9 +3,12 @@
 hipcc cross-compiles without a GPU; the .so is kept in-tree (git-ignored) so that it travels to the
 GPU box with the repository snapshot.
 """
+import hashlib
+import json
 import os
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -20,6 +23,10 @@ def _inputs():
     return files
 
 
+def _headers():
+    return [f for f in _inputs() if f.endswith(".h")]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -27,35 +34,70 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in _inputs())
 
 
-OBJDIR = os.environ.get("SNARKVM_HIP_OBJDIR", "/tmp/snarkvm_hip_obj")  # objects stay out of the tree (they would travel to the GPU box)
+def _objdir(flags):
+    """Objects stay out of the tree (they would travel to the GPU box).  One private directory per (checkout, flag set): two
+    checkouts, or a --fast / --ool build beside the product build, never see each other's objects.  SNARKVM_HIP_OBJDIR overrides."""
+    env = os.environ.get("SNARKVM_HIP_OBJDIR")
+    if env:
+        return env
+    key = hashlib.sha256((os.path.realpath(HERE) + "\0" + " ".join(flags)).encode()).hexdigest()[:16]
+    base = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(tempfile.gettempdir(), f"snarkvm_hip_{os.getuid()}"), "obj")
+    return os.path.join(base, key)
+
+
+def _stamp(obj):
+    return obj + ".json"
+
+
+def _kept_object_is_current(obj, src, flags):
+    """A kept object may be linked only if it was compiled with the same flags, from this source, after every header's last change."""
+    try:
+        with open(_stamp(obj)) as f:
+            st = json.load(f)
+    except (OSError, ValueError):
+        return False
+    if st.get("flags") != flags or st.get("src") != os.path.realpath(src):
+        return False
+    t = os.path.getmtime(obj)
+    return all(os.path.getmtime(h) <= t for h in _headers() + [src])
 
 
 def build(force=False, verbose=False, fast=False, only=None, ool=False):
     """fast=True (development only) compiles without the G2 / Fq2 instantiations.  ool=True (A/B switch): every exceptional
     path out of line (-DSV_COLD_OOL): kernels a few percent slower, see ff.hip.h.  only=[...] (development only): recompile just
-    the listed translation units and link them with the objects kept from the last build, whatever their age - for experiments
-    on a kernel that one unit instantiates (each unit takes 2 - 5 minutes); the driver's build() always compiles everything."""
+    the listed translation units and link them with the objects kept from the last build of THIS checkout with THESE flags -
+    refused when a kept object is older than any header (a mixed library must never reach the GPU box); the driver's build()
+    always compiles everything."""
     if not force and not only and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DSV_NO_G2"] if fast else []) + (["-DSV_COLD_OOL"] if ool else [])
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"] + (["-DSV_NO_G2"] if fast else []) + (["-DSV_COLD_OOL"] if ool else [])
+    objdir = _objdir(flags)
+    os.makedirs(objdir, mode=0o700, exist_ok=True)
+    if os.path.islink(objdir) or os.stat(objdir).st_uid != os.getuid():
+        raise PermissionError(f"{objdir}: object directory is a symlink or belongs to another user")
     objs, procs = [], []
     for src in SOURCES:
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         if only and src not in only:
-            if not os.path.exists(obj):
-                raise FileNotFoundError(f"{obj}: no kept object for {src}; run a full build first")
+            if not os.path.exists(obj) or not _kept_object_is_current(obj, path, flags):
+                raise RuntimeError(f"{src}: the kept object is missing, was built with other flags, or is older than a header it includes - "
+                                   f"add it to the list or run a full build")
             continue
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if os.path.exists(_stamp(obj)):
+            os.remove(_stamp(obj))
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
+        procs.append((cmd, obj, path, subprocess.Popen(cmd)))
+    for cmd, obj, path, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+        with open(_stamp(obj), "w") as f:
+            json.dump({"flags": flags, "src": os.path.realpath(path)}, f)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(link))

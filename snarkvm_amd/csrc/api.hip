@@ -76,6 +76,49 @@ RustError snarkvm_hip_synchronize(void) {
     API_CATCH
 }
 
+// ---- deferred-synchronisation scope ---------------------------------------------------------------------
+// One lane stays bound to the calling thread between _begin and _end; the thread's calls on device-resident operands
+// (snarkvm_hip_ntt_device[_batch], snarkvm_hip_fr_* with on_device = 1) are enqueued on that lane's stream and return at once,
+// small host results (the remainder of fr_divide_by_linear) are delivered by _end.  How a prover that keeps its polynomials in HBM
+// issues a whole round - or the same round of many proofs in lock step - without a stream synchronisation per call (~40 us each
+// on this stack: 45 transforms per proof).  Calls that leave the scope's lane (MSMs, host buffers) wait for the scope first.
+RustError snarkvm_hip_scope_begin(const void* d_any) {
+    API_TRY
+    thread_scope_t& sc = tl_scope();
+    if (sc.lane) throw hip_failure{hipErrorInvalidValue, "scope_begin: the calling thread already has an open scope", __LINE__};
+    lane_guard lg;
+    lg.acquire(device_for(d_any, d_any ? 1 : 0), 1);
+    lane_t* l = lg.lanes[0];
+    sc.prev_device = lg.prev_device;
+    lg.lanes.clear();       // ownership of the lane (and of the device selection) moves to the scope
+    lg.prev_device = -1;
+    l->begin_call();
+    l->in_scope = true;
+    sc.lane = l;
+    API_CATCH
+}
+RustError snarkvm_hip_scope_end(void) {
+    thread_scope_t& sc = tl_scope();
+    lane_t* l = sc.lane;
+    if (!l) return ok();
+    RustError r = ok();
+    try {
+        l->flush_scope();
+    } catch (const hip_failure& f) {
+        r = from_failure(f);
+    } catch (...) {
+        r = fail(1, "snarkvm_hip: scope_end failed");
+    }
+    l->in_scope = false;
+    l->deferred.clear();
+    l->deferred_bytes = 0;
+    sc.lane = nullptr;
+    l->dev->give(l);
+    if (sc.prev_device >= 0) (void)hipSetDevice(sc.prev_device);
+    sc.prev_device = -1;
+    return r;
+}
+
 // ---- registered bases ---------------------------------------------------------------------------------
 // tables 1 .. J-1 of one replica: table j = 2^table_bits * table j-1
 static void precompute_tables(lane_t& c, snarkvm_hip_bases* h, g1_aff_mem_t* d) { precompute_tables_run<fq_t>(c, d, h->n, h->tables, h->table_bits); }
@@ -257,13 +300,27 @@ static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, s
     });
     acc->finish(out);
 }
+// one proof-sized MSM of one caller: a ticket on the handle's coalescer (runtime.hip.h::msm_coalesced) - concurrent callers are fused
+static void msm_single_coalesced(void* out, const snarkvm_hip_bases* h, size_t off0, size_t n0, size_t off1, size_t n1, const void* scalars,
+                                 int scalars_on_device, int scalars_montgomery, int window_bits) {
+    if (scalars_on_device && g_rt.device_of(scalars) < 0)
+        throw hip_failure{hipErrorInvalidValue, "device pointer does not belong to a device in use (snarkvm_hip_set_devices)", __LINE__};
+    msm_ticket_t t;
+    t.req.off0 = off0, t.req.n0 = n0, t.req.off1 = n1 ? off1 : 0, t.req.n1 = n1, t.req.scalars = scalars, t.req.out = out;
+    t.on_device = scalars_on_device ? 1 : 0;
+    t.montgomery = scalars_montgomery ? 1 : 0;
+    t.window_bits = window_bits;
+    msm_coalesced<fq_t>(*h, &t, 1);
+}
 RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, size_t offset, size_t npoints, const void* scalars,
                                      int scalars_on_device, int window_bits) {
     API_TRY
     if (!h || offset + npoints > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered: range exceeds the registered bases", __LINE__};
     check_window_bits(window_bits, "msm_registered");
     if (!out || (npoints && !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered: null argument", __LINE__};
-    if (!scalars_on_device) {
+    if (msm_coalescible(*h, npoints, window_bits)) {
+        msm_single_coalesced(out, h, offset, npoints, 0, 0, scalars, scalars_on_device, 0, window_bits);
+    } else if (!scalars_on_device) {
         msm_registered_host_scalars(out, h, offset, npoints, 0, 0, scalars, 0, window_bits);
     } else {
         lane_guard lg(device_for(scalars, npoints ? 1 : 0));
@@ -282,7 +339,9 @@ RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h,
     check_window_bits(window_bits, "msm_registered_ex");
     const size_t n = n0 + n1;
     if (!out || (n && !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: null argument", __LINE__};
-    if (!scalars_on_device) {
+    if (msm_coalescible(*h, n, window_bits)) {
+        msm_single_coalesced(out, h, off0, n0, off1, n1, scalars, scalars_on_device, scalars_montgomery, window_bits);
+    } else if (!scalars_on_device) {
         msm_registered_host_scalars(out, h, off0, n0, off1, n1, scalars, scalars_montgomery, window_bits);
     } else {
         lane_guard lg(device_for(scalars, n ? 1 : 0));
@@ -305,7 +364,8 @@ RustError snarkvm_hip_msm_registered_batch(void* outs, const snarkvm_hip_bases_t
     if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null handle", __LINE__};
     check_window_bits(window_bits, "msm_registered_batch");
     if (count && (!outs || !offsets || !npoints || !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null argument", __LINE__};
-    msm_batch_run<fq_t>(outs, *h, count, offsets, npoints, scalars, scalars_on_device, scalars_montgomery, window_bits);
+    std::vector<msm_req_t> req = msm_requests<fq_t>(outs, count, offsets, npoints, nullptr, nullptr, scalars);
+    msm_batch_dispatch<fq_t>(*h, req, scalars_on_device, scalars_montgomery, window_bits);
     API_CATCH
 }
 
@@ -318,7 +378,8 @@ RustError snarkvm_hip_msm_registered_batch_ex(void* outs, const snarkvm_hip_base
     if (!h) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch_ex: null handle", __LINE__};
     check_window_bits(window_bits, "msm_registered_batch_ex");
     if (count && (!outs || !off0 || !n0 || !off1 || !n1 || !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch_ex: null argument", __LINE__};
-    msm_batch_run<fq_t>(outs, *h, count, off0, n0, scalars, scalars_on_device, scalars_montgomery, window_bits, off1, n1);
+    std::vector<msm_req_t> req = msm_requests<fq_t>(outs, count, off0, n0, off1, n1, scalars);
+    msm_batch_dispatch<fq_t>(*h, req, scalars_on_device, scalars_montgomery, window_bits);
     API_CATCH
 }
 
@@ -450,7 +511,9 @@ RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void*
         std::shared_ptr<snarkvm_hip_bases> h;
         size_t offset = 0;
         if (base_cache_tables() && npoints > 1024 && ffi_affine_sz >= 104 && !(ffi_affine_sz & 7)) h = base_cache_lookup(points, npoints, ffi_affine_sz, offset);
-        if (h)
+        if (h && msm_coalescible(*h, npoints, 0))
+            msm_single_coalesced(out, h.get(), offset, npoints, 0, 0, scalars, 0, 0, 0);
+        else if (h)
             msm_registered_host_scalars(out, h.get(), offset, npoints, 0, 0, scalars, 0, 0);
         else
             msm_host_chunked<fq_t>(out, points, npoints, scalars, ffi_affine_sz);

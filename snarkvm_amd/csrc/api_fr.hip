@@ -39,7 +39,7 @@ RustError snarkvm_hip_ntt_device(void* d_inout, uint32_t lg, int order, int dir,
     ntt_run(c.ntt_ctx(), (fr_mem_t*)d_inout, c.ntt_scratch.as<fr_mem_t>(), (int)lg, order, dir, type);
     c.phase_end();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c.stream));
+    c.sync_or_defer();
     API_END
 }
 // `count` independent in-place transforms of 2^lg elements each over device vectors (the iNTTs of a prover round: second.rs:104-113
@@ -54,15 +54,44 @@ RustError snarkvm_hip_ntt_device_batch(void* const* d_inouts, size_t count, uint
     for (size_t k = 0; k < count; k++) {
         check_ntt_args(lg, order, dirs ? dirs[k] : 0, types ? types[k] : 0);
         if (!d_inouts[k]) throw hip_failure{hipErrorInvalidValue, "ntt_device_batch: null vector", __LINE__};
-        (void)device_for(d_inouts[k], 1);  // throws for a pointer no selected device owns (all vectors: one physical device)
+        // every vector must live on the lane's GPU: the kernels of this call run there
+        const int dk = device_for(d_inouts[k], 1);
+        if (g_rt.devs[dk]->physical != c.dev->physical) throw hip_failure{hipErrorInvalidValue, "ntt_device_batch: the vectors live on different devices", __LINE__};
     }
-    c.ntt_scratch.ensure(sizeof(fr_mem_t) << lg);
     c.phase_begin("ntt_kernels");
-    for (size_t k = 0; k < count; k++)
-        ntt_run(c.ntt_ctx(), (fr_mem_t*)d_inouts[k], c.ntt_scratch.as<fr_mem_t>(), (int)lg, order, dirs ? dirs[k] : 0, types ? types[k] : 0);
+    // Runs of consecutive list entries with the same (direction, type) and no vector twice travel as ONE launch per pass
+    // (blockIdx.y = vector; tuning ntt_batch=0: one launch sequence per vector).  List order is preserved between runs, so a
+    // vector listed twice is still transformed twice, in order.
+    const bool can_batch = tuning().ntt_batch && order == NTT_NN && lg > 8;
+    std::vector<std::pair<size_t, size_t>> runs;
+    size_t max_run = 1;
+    for (size_t k = 0; k < count;) {
+        const int dir = dirs ? dirs[k] : 0, type = types ? types[k] : 0;
+        size_t e = k + 1;
+        if (can_batch) {
+            while (e < count && e - k < (size_t)NTT_BATCH_MAX && (dirs ? dirs[e] : 0) == dir && (types ? types[e] : 0) == type) {
+                bool dup = false;
+                for (size_t q = k; q < e && !dup; q++) dup = d_inouts[q] == d_inouts[e];
+                if (dup) break;
+                e++;
+            }
+        }
+        runs.emplace_back(k, e);
+        max_run = e - k > max_run ? e - k : max_run;
+        k = e;
+    }
+    c.ntt_scratch.ensure((sizeof(fr_mem_t) << lg) * max_run);
+    for (const auto& r : runs) {
+        const size_t k = r.first, nv = r.second - r.first;
+        const int dir = dirs ? dirs[k] : 0, type = types ? types[k] : 0;
+        if (nv > 1)
+            ntt_run_nn(c.ntt_ctx(), nullptr, c.ntt_scratch.as<fr_mem_t>(), (int)lg, dir, type, (fr_mem_t* const*)(d_inouts + k), (unsigned)nv);
+        else
+            ntt_run(c.ntt_ctx(), (fr_mem_t*)d_inouts[k], c.ntt_scratch.as<fr_mem_t>(), (int)lg, order, dir, type);
+    }
     c.phase_end();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c.stream));
+    c.sync_or_defer();
     API_END
 }
 
@@ -148,7 +177,7 @@ RustError snarkvm_hip_fr_mul_device(void* d_out, const void* d_a, const void* d_
         const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(blocks), dim3(256), 0, c.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_a, (const fr_mem_t*)d_b, n, 1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        c.sync_or_defer();
     }
     API_END
 }
@@ -158,7 +187,7 @@ RustError snarkvm_hip_fr_convert_device(void* d_out, const void* d_in, size_t n,
         const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(blocks), dim3(256), 0, c.stream, (fr_mem_t*)d_out, (const fr_mem_t*)d_in, n, to_bigint);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        c.sync_or_defer();
     }
     API_END
 }
@@ -188,6 +217,13 @@ static fr_mem_t* fr_stage_out(lane_t& c, int slot, void* p, size_t n, int on_dev
 static void fr_finish_out(lane_t& c, fr_mem_t* d, void* p, size_t n, int on_device) {
     if (!on_device && p && n) HIP_TRY(hipMemcpyAsync(p, d, sizeof(fr_mem_t) * n, hipMemcpyDeviceToHost, c.stream));
 }
+// end of a vector call: device-resident operands may leave the wait to the calling thread's scope (runtime.hip.h), host operands never
+static void fr_call_done(lane_t& c, int on_device) {
+    if (on_device)
+        c.sync_or_defer();
+    else
+        HIP_TRY(hipStreamSynchronize(c.stream));
+}
 
 RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b, const void* c3, const void* scalar, size_t n, int on_device) {
     API_BEGIN_DEV(device_for(a, (on_device && n) ? 1 : 0))
@@ -207,7 +243,7 @@ RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b,
         hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, c.stream, op, dout, da, db, dc, s, n);
         HIP_TRY(hipGetLastError());
         fr_finish_out(c, dout, out, n, on_device);
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        fr_call_done(c, on_device);
     }
     API_END
 }
@@ -275,8 +311,8 @@ RustError snarkvm_hip_fr_divide_by_linear(void* quotient, void* remainder, const
         fr_mem_t* drem = c.poly[2].as<fr_mem_t>();
         fr_suffix_horner(c, din, n, z, dq, 1, drem);
         if (dq) fr_finish_out(c, dq, quotient, n - 1, on_device);
-        if (remainder) HIP_TRY(hipMemcpyAsync(remainder, drem, sizeof(fr_mem_t), hipMemcpyDeviceToHost, c.stream));
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (remainder) c.host_result(remainder, drem, sizeof(fr_mem_t));  // inside a scope: delivered by snarkvm_hip_scope_end
+        fr_call_done(c, on_device);
     }
     API_END
 }
@@ -296,7 +332,7 @@ RustError snarkvm_hip_fr_batch_inversion_and_mul(void* inout, size_t n, const vo
         fr_mem_t* dv = fr_stage_in(c, 0, inout, n, on_device);
         fr_batch_inverse_run(c, dv, n, fr_mem_from_host(coeff));
         fr_finish_out(c, dv, inout, n, on_device);
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        fr_call_done(c, on_device);
     }
     API_END
 }
@@ -314,7 +350,7 @@ RustError snarkvm_hip_fr_distribute_powers(void* inout, size_t n, const void* g,
         fr_mem_t* dv = fr_stage_in(c, 0, inout, n, on_device);
         fr_distribute_powers_run(c, dv, n, fr_mem_from_host(g), fr_mem_from_host(cmul));
         fr_finish_out(c, dv, inout, n, on_device);
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        fr_call_done(c, on_device);
     }
     API_END
 }
@@ -352,7 +388,7 @@ RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const voi
     }
     HIP_TRY(hipGetLastError());
     fr_finish_out(c, du, out, n, on_device);
-    HIP_TRY(hipStreamSynchronize(c.stream));
+    fr_call_done(c, on_device);
     API_END
 }
 
@@ -371,7 +407,7 @@ RustError snarkvm_hip_fr_divide_by_vanishing(void* quotient, void* remainder, co
         HIP_TRY(hipGetLastError());
         if (qlen) fr_finish_out(c, dq, quotient, qlen, on_device);
         fr_finish_out(c, dr, remainder, rlen, on_device);
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        fr_call_done(c, on_device);
     }
     API_END
 }
@@ -385,7 +421,7 @@ RustError snarkvm_hip_fr_mul_by_vanishing(void* out, const void* poly, size_t le
         hipLaunchKernelGGL(fr_mul_vanishing_kernel, dim3((unsigned)((olen + 255) / 256)), dim3(256), 0, c.stream, din, len, domain_size, dout);
         HIP_TRY(hipGetLastError());
         fr_finish_out(c, dout, out, olen, on_device);
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        fr_call_done(c, on_device);
     }
     API_END
 }

@@ -69,8 +69,28 @@ void snarkvm_hip_free_bases_g2(snarkvm_hip_bases_g2_t* h) {
     h->free_all();
     delete h;
 }
+#ifndef SV_NO_G2
+// a proof-sized G2 MSM of one caller: concurrent callers over the same handle are fused (runtime.hip.h::msm_coalesced)
+static RustError msm_g2_single_coalesced(void* out, const snarkvm_hip_bases_g2_t* h, size_t offset, size_t npoints, const void* scalars, int scalars_on_device,
+                                         int window_bits) {
+    API_TRY
+    if (scalars_on_device && g_rt.device_of(scalars) < 0)
+        throw hip_failure{hipErrorInvalidValue, "device pointer does not belong to a device in use (snarkvm_hip_set_devices)", __LINE__};
+    msm_ticket_t t;
+    t.req.off0 = offset, t.req.n0 = npoints, t.req.scalars = scalars, t.req.out = out;
+    t.on_device = scalars_on_device ? 1 : 0;
+    t.window_bits = window_bits;
+    msm_coalesced<fq2_t>(*h, &t, 1);
+    API_CATCH
+}
+#endif
 RustError snarkvm_hip_msm_g2_registered(void* out, const snarkvm_hip_bases_g2_t* h, size_t offset, size_t npoints, const void* scalars,
                                         int scalars_on_device, int window_bits) {
+#ifndef SV_NO_G2
+    if (h && out && scalars && offset + npoints <= h->n && (!window_bits || (window_bits >= 2 && window_bits <= MSM_C_MAX)) && g_rt.configured &&
+        msm_coalescible(*h, npoints, window_bits))
+        return msm_g2_single_coalesced(out, h, offset, npoints, scalars, scalars_on_device, window_bits);
+#endif
     API_BEGIN_DEV(device_for(scalars, (scalars_on_device && npoints) ? 1 : 0))
 #ifdef SV_NO_G2
     throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
@@ -100,7 +120,8 @@ RustError snarkvm_hip_msm_g2_registered_batch(void* outs, const snarkvm_hip_base
     if (!h) throw hip_failure{hipErrorInvalidValue, "msm_g2_registered_batch: null handle", __LINE__};
     if (window_bits && (window_bits < 2 || window_bits > MSM_C_MAX)) throw hip_failure{hipErrorInvalidValue, "msm_g2_registered_batch: window_bits must be 0 or 2..23", __LINE__};
     if (count && (!outs || !offsets || !npoints || !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_g2_registered_batch: null argument", __LINE__};
-    msm_batch_run<fq2_t>(outs, *h, count, offsets, npoints, scalars, scalars_on_device, 0, window_bits);
+    std::vector<msm_req_t> req = msm_requests<fq2_t>(outs, count, offsets, npoints, nullptr, nullptr, scalars);
+    msm_batch_dispatch<fq2_t>(*h, req, scalars_on_device, 0, window_bits);
 #endif
     API_CATCH
 }

@@ -25,6 +25,7 @@
 
 #include "ec.hip.h"
 #include "ffl.hip.h"
+#include "tuning.hip.h"
 
 namespace sv {
 
@@ -113,10 +114,7 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
     p.chunk &= ~7u;  // multiple of 8: 16-byte digit loads
     if (p.chunk > n) p.chunk = (uint32_t)(n ? n : 1);
     p.nchunks = (uint32_t)((n + p.chunk - 1) / p.chunk);
-    // tuning knobs (environment overrides are for experiments only)
-    static const int env_S = getenv("SNARKVM_HIP_S") ? atoi(getenv("SNARKVM_HIP_S")) : 0;
-    static const int env_S2 = getenv("SNARKVM_HIP_S2") ? atoi(getenv("SNARKVM_HIP_S2")) : 0;
-    static const int env_L = getenv("SNARKVM_HIP_L") ? atoi(getenv("SNARKVM_HIP_L")) : 0;
+    const int env_S = tuning().seg, env_S2 = tuning().seg2, env_L = tuning().fold_l;  // experiment overrides (tuning.hip.h), 0 = planner
     // points per accumulate thread.  Long segments amortise the partial-sum flushes (every thread leaves one partial sum per
     // bucket it touches and the tail pays two general additions for each), but the grid should be whole rounds of one wave
     // per SIMD (2^16 threads: one resident wave already keeps the multiplier ~95 % busy, tools/ecbench.hip): a grid of 1 088
@@ -228,7 +226,7 @@ static __global__ void __launch_bounds__(1024) scan_one_block_kernel(const uint3
 // out may alias in
 static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp) {
     if (n == 0) return;
-    static const int one_launch = getenv("SNARKVM_HIP_SCAN1") ? atoi(getenv("SNARKVM_HIP_SCAN1")) : 1;  // A/B switch
+    const int one_launch = tuning().scan1;  // A/B switch
     if (one_launch && n > (size_t)SCAN_TILE && n <= (size_t)SCAN_ONE_MAX) {
         const uint32_t per = (uint32_t)((n + SCAN_ONE_THREADS - 1) / SCAN_ONE_THREADS) | 1u;
         hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(SCAN_ONE_THREADS), (size_t)n * 4, st, in, out, (uint32_t)n, per);

@@ -21,9 +21,11 @@
 // 29-bit-limb arithmetic needs no conversion on this (linear) path.
 #pragma once
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "ff.hip.h"
+#include "tuning.hip.h"
 
 namespace sv {
 
@@ -193,8 +195,25 @@ __device__ __forceinline__ void dif_group(fr_t* x, int s, int a, int lo, const n
     }
 }
 
-static __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tables_t tb) {
+// Batched launches (snarkvm_hip_ntt_device_batch: the independent transforms of a prover round, or of many proofs in lock step):
+// blockIdx.y selects the vector.  Vector y lives at v[y]; its private scratch copy at scratch + (y << lg_n).  The pointers travel
+// as kernel arguments (no device-side table to keep alive while calls are in flight); more than NTT_BATCH_MAX vectors = several launches.
+static constexpr int NTT_BATCH_MAX = 48;
+struct ntt_batch_t {
+    fr_mem_t* v[NTT_BATCH_MAX];
+    fr_mem_t* scratch;
+    int in_scratch, out_scratch;
+};
+struct ntt_no_batch_t {};
+template <bool BATCH>
+__global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tables_t tb, typename std::conditional<BATCH, ntt_batch_t, ntt_no_batch_t>::type bt) {
     extern __shared__ uint32_t lds32[];
+    if constexpr (BATCH) {
+        fr_mem_t* vec = bt.v[blockIdx.y];
+        fr_mem_t* scr = bt.scratch + ((size_t)blockIdx.y << p.lg_n);
+        p.in = bt.in_scratch ? scr : vec;
+        p.out = bt.out_scratch ? scr : vec;
+    }
     const int R = 1 << p.a, T = 1 << p.lgT, E = R << p.lgT;
     ntt_lds_t L;
     L.data = lds32;
@@ -398,16 +417,15 @@ static inline ntt_plan_t ntt_make_plan(int lg) {
 // fit the 96 KiB the pass kernel may use
 // Small transforms (the 2^14 - 2^18 domains of a proof) would fill only 8 ... 128 of the chip's 256 CUs with [2^a x 8] tiles, and a
 // thread's work does not depend on the tile width (one radix-4 group per stage round): such passes take narrower tiles until
-// the launch has NTT_MIN_TILES workgroups (SNARKVM_HIP_NTT_MIN_TILES; the data is L2 resident at these sizes, so the shorter
+// the launch has ntt_min_tiles workgroups (tuning.hip.h; the data is L2 resident at these sizes, so the shorter
 // coalesced runs of a narrow tile cost nothing).
 static inline int ntt_min_tiles() {
-    static const int v = getenv("SNARKVM_HIP_NTT_MIN_TILES") ? atoi(getenv("SNARKVM_HIP_NTT_MIN_TILES")) : 256;
-    return v;
+    return tuning().ntt_min_tiles;
 }
-static inline int ntt_tile_lg(int a, int avail, int lg_n) {
+static inline int ntt_tile_lg(int a, int avail, int lg_n, size_t nvec = 1) {
     int lgT = avail < 3 ? avail : 3;
     while (lgT > 0 && a + lgT > 11) lgT--;
-    while (lgT > 0 && ((size_t)1 << (lg_n - a - lgT)) < (size_t)ntt_min_tiles()) lgT--;
+    while (lgT > 0 && (((size_t)1 << (lg_n - a - lgT)) * nvec) < (size_t)ntt_min_tiles()) lgT--;  // a batched launch covers the chip with wide tiles sooner
     return lgT;
 }
 
@@ -418,7 +436,7 @@ static inline int ntt_tile_lg(int a, int avail, int lg_n) {
 // order the pass stores its outputs (coalesced 32-byte reads next to the 32-byte stores): 2^(a+s) entries - 512 MiB for the
 // first pass of a 2^24 transform, 2 MiB for its second pass.  The tables live in a per-device cache bounded by
 // SNARKVM_HIP_NTT_TW_MB (default 1536 MiB): least recently used tables that no running call holds are evicted; when nothing
-// can be evicted (or SNARKVM_HIP_NTT_FULL_TW=0) the pass composes its twiddles on the fly.
+// can be evicted (or tuning ntt_full_tw=0) the pass composes its twiddles on the fly.
 struct ntt_tw_entry {
     fr_mem_t* p = nullptr;
     size_t bytes = 0;
@@ -471,9 +489,9 @@ static inline void ntt_tw_release_entries(ntt_tw_cache_t& cache, std::vector<voi
 // prelast_lg != 0: this is the pass before the last one of a 2^prelast_lg transform -> the folded variant
 static inline const fr_mem_t* ntt_get_full_tw(const ntt_ctx_t& cx, int a, int s, int tw_shift, int dir, int prelast_lg = 0, bool* folded = nullptr) {
     if (folded) *folded = false;
-    static const int enabled = getenv("SNARKVM_HIP_NTT_FULL_TW") ? atoi(getenv("SNARKVM_HIP_NTT_FULL_TW")) : 1;
+    const int enabled = tuning().ntt_full_tw;
     if (!enabled || !cx.cache || a + s > NTT_LG_MAX || a > NTT_MAX_RADIX_LG) return nullptr;
-    static const int fold_enabled = getenv("SNARKVM_HIP_NTT_FOLD") ? atoi(getenv("SNARKVM_HIP_NTT_FOLD")) : 1;
+    const int fold_enabled = tuning().ntt_fold;
     static const size_t cap = (getenv("SNARKVM_HIP_NTT_TW_MB") ? (size_t)atoll(getenv("SNARKVM_HIP_NTT_TW_MB")) : 1536) << 20;
     if (prelast_lg && !fold_enabled) prelast_lg = 0;
     ntt_tw_cache_t& cache = *cx.cache;
@@ -512,7 +530,7 @@ static inline const fr_mem_t* ntt_get_full_tw(const ntt_ctx_t& cx, int a, int s,
     return slot.p;
 }
 
-static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb) {
+static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const ntt_tables_t& tb, const ntt_batch_t* bt = nullptr, unsigned nvec = 1) {
     const size_t E = (size_t)1 << (p.a + p.lgT);
     const size_t ntiles = ((size_t)1 << p.lg_n) / E;
     {
@@ -520,13 +538,19 @@ static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const nt
         if (threads < 64) threads = 64;
         if (threads > 512) threads = 512;
         const size_t shmem = (9 * E + 9 * ((size_t)1 << (p.a ? p.a - 1 : 0))) * sizeof(uint32_t);  // a [2^8 x 8] tile + its twiddles: 78 KB, two workgroups per CU
-        hipLaunchKernelGGL(ntt_pass_kernel_v2, dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb);
+        if (bt)
+            hipLaunchKernelGGL((ntt_pass_kernel_v2<true>), dim3((unsigned)ntiles, nvec), dim3(threads), shmem, st, p, tb, *bt);
+        else
+            hipLaunchKernelGGL((ntt_pass_kernel_v2<false>), dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb, ntt_no_batch_t{});
     }
 }
 
 // NN-order transform of 2^lg elements held in `data`; `scratch` is a second buffer of the same size.
 // The result is left in `data`.
-static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scratch, int lg, int dir, int type) {
+// `vecs` != nullptr: the same transform of `nvec` (<= NTT_BATCH_MAX) distinct vectors in one launch per pass (needs >= 2 passes, i.e.
+// lg > 8; `scratch` then holds nvec * 2^lg elements); `data` is ignored.
+static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scratch, int lg, int dir, int type, fr_mem_t* const* vecs = nullptr,
+                              unsigned nvec = 1) {
     hipStream_t st = cx.st;
     const ntt_tables_t& tb = *cx.tb;
     if (lg == 0) {
@@ -534,6 +558,11 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
         return;
     }
     const ntt_plan_t pl = ntt_make_plan(lg);
+    ntt_batch_t bt;
+    if (vecs) {
+        for (unsigned i = 0; i < nvec; i++) bt.v[i] = vecs[i];
+        bt.scratch = scratch;
+    }
     const int scale_post = (dir == NTT_INVERSE) ? (type == NTT_COSET ? 2 : 1) : 0;
     const int coset_pre = (dir == NTT_FORWARD && type == NTT_COSET) ? 1 : 0;
     int consumed = 0;
@@ -551,7 +580,7 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
         p.reduce_only = 0;
         if (!p.last) {
             p.s = lg - consumed - p.a;
-            p.lgT = ntt_tile_lg(p.a, p.s, lg);
+            p.lgT = ntt_tile_lg(p.a, p.s, lg, nvec);
             p.tw_shift = NTT_LG_MAX - (p.a + p.s);
             const bool prelast = (k == pl.npass - 2);
             bool f = false;
@@ -561,7 +590,7 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
             p.reduce_only = folded ? 1 : 0;
             p.a1 = (pl.npass >= 2) ? pl.a[0] : 0;
             p.lg_mid = (pl.npass == 3) ? pl.a[1] : 0;
-            p.lgT = ntt_tile_lg(p.a, p.a1, lg);
+            p.lgT = ntt_tile_lg(p.a, p.a1, lg, nvec);
         }
         if (pl.npass == 1) {
             p.in = data;
@@ -576,7 +605,13 @@ static inline void ntt_run_nn(const ntt_ctx_t& cx, fr_mem_t* data, fr_mem_t* scr
             p.in = scratch;
             p.out = data;
         }
-        ntt_launch_pass(st, p, tb);
+        if (vecs) {
+            bt.in_scratch = (p.in == scratch);
+            bt.out_scratch = (p.out == scratch);
+            ntt_launch_pass(st, p, tb, &bt, nvec);
+        } else {
+            ntt_launch_pass(st, p, tb);
+        }
         consumed += p.a;
     }
     if (pl.npass == 1)

@@ -14,7 +14,10 @@
 #include <time.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -134,6 +137,14 @@ struct lane_t {
     hipStream_t alt = nullptr;  // second stream of the lane: copies of operand k + 1 while operand k is transformed (polynomial.cuh:136-242)
     hipEvent_t ev[4] = {};
     std::vector<void*> tw_leases;  // twiddle tables this call pinned in the device's cache
+    // deferred-synchronisation scope (snarkvm_hip_scope_begin): the owning thread's device-resident calls are only enqueued
+    bool in_scope = false;
+    struct deferred_out_t {
+        void* dst;
+        size_t off, bytes;
+    };
+    std::vector<deferred_out_t> deferred;  // host results parked in pin2 until the scope ends
+    size_t deferred_bytes = 0;
     // profiling
     std::vector<phase_rec> phases;
     std::vector<hipEvent_t> event_pool;
@@ -153,6 +164,26 @@ struct lane_t {
     inline void phase_end();
     inline void phase_host(const char* name, double ms);
     inline void end_call();
+    // the end of a call whose results all live in device memory: wait, unless the calling thread deferred that to its scope's end
+    void sync_or_defer() {
+        if (!in_scope) HIP_TRY(hipStreamSynchronize(stream));
+    }
+    // a small host result (<= a few KB) of a call that may run inside a scope: copied now and waited for, or parked in pinned
+    // memory and delivered by snarkvm_hip_scope_end
+    void host_result(void* dst, const void* d_src, size_t bytes) {
+        if (!in_scope) {
+            HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
+            return;
+        }
+        if (deferred_bytes + bytes > pin2.cap) {
+            if (!deferred.empty()) flush_scope();  // staging full: deliver what is parked, then start over
+            pin2.ensure(deferred_bytes + bytes > (size_t)1 << 16 ? deferred_bytes + bytes : (size_t)1 << 16);
+        }
+        HIP_TRY(hipMemcpyAsync(pin2.as<uint8_t>() + deferred_bytes, d_src, bytes, hipMemcpyDeviceToHost, stream));
+        deferred.push_back({dst, deferred_bytes, bytes});
+        deferred_bytes += (bytes + 15) & ~(size_t)15;
+    }
+    inline void flush_scope();
 };
 
 struct device_t {
@@ -314,21 +345,46 @@ static void tu_kernel_attributes(int logical) {
     HIP_TRY(hipFuncSetAttribute((const void*)msm_accumulate_lazy_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 #endif
 #ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
-    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 #endif
     done[logical] = 1;
 }
 
 // RAII ownership of lanes.  Selecting a lane makes its device current on the calling thread (the HIP current device is per
 // host thread - rayon workers!) and restores the previous one on release.
+// Deferred-synchronisation scope of the calling thread (snarkvm_hip_scope_begin / _end): one lane stays bound to the thread; its
+// device-resident calls borrow that lane and return after the enqueue.  Anything that takes OTHER lanes (MSMs, host-buffer calls,
+// another device) first waits for the scope's stream - what it reads may have been produced inside the scope.
+struct thread_scope_t {
+    lane_t* lane = nullptr;
+    int prev_device = -1;
+};
+static thread_scope_t& tl_scope() {
+    static thread_local thread_scope_t s;
+    return s;
+}
+static void scope_flush() {
+    if (lane_t* l = tl_scope().lane) l->flush_scope();
+}
 struct lane_guard {
     std::vector<lane_t*> lanes;
     int prev_device = -1;
+    bool borrowed = false;
     lane_guard() {}
     lane_guard(const lane_guard&) = delete;
     // one lane on logical device `dev`, or on the least busy device when dev < 0
-    explicit lane_guard(int dev) { acquire(dev, 1); }
+    explicit lane_guard(int dev) {
+        lane_t* sl = tl_scope().lane;
+        if (sl && (dev < 0 || (dev < (int)g_rt.devs.size() && g_rt.devs[dev]->physical == sl->dev->physical))) {  // inside the thread's scope: its lane, its device is already current
+            borrowed = true;
+            lanes.push_back(sl);
+            return;
+        }
+        acquire(dev, 1);
+    }
     void acquire(int dev, int want) {
+        scope_flush();
         g_rt.configure();
         if (prev_device < 0 && hipGetDevice(&prev_device) != hipSuccess) prev_device = 0;
         const int nd = (int)g_rt.devs.size();
@@ -367,6 +423,7 @@ struct lane_guard {
     }
     lane_t& c() { return *lanes[0]; }
     ~lane_guard() {
+        if (borrowed) return;
         for (lane_t* l : lanes) l->dev->give(l);
         if (prev_device >= 0) (void)hipSetDevice(prev_device);
     }
@@ -392,7 +449,15 @@ inline void lane_t::phase_host(const char* name, double ms) {  // a phase that r
     phases.push_back(phase_rec{name, nullptr, nullptr, ms});
 }
 static void ntt_tw_release(device_t* dev, std::vector<void*>& leases) { ntt_tw_release_entries(dev->tw, leases); }
+inline void lane_t::flush_scope() {  // wait for everything the scope has enqueued, deliver parked host results, return the twiddle leases
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (const deferred_out_t& d : deferred) memcpy(d.dst, pin2.as<uint8_t>() + d.off, d.bytes);
+    deferred.clear();
+    deferred_bytes = 0;
+    if (!tw_leases.empty()) ntt_tw_release(dev, tw_leases);
+}
 inline void lane_t::end_call() {
+    if (in_scope) return;  // nothing is waited for; leases are held until the scope ends
     if (!tw_leases.empty()) {
         HIP_TRY(hipStreamSynchronize(stream));
         ntt_tw_release(dev, tw_leases);
@@ -436,12 +501,18 @@ static void for_each_device(const std::vector<int>& devices, Fn fn) {
 }
 
 // registered base vectors: one replica per logical device (every device holds its own copy of the static SRS)
+struct msm_ticket_t;
 template <class F>
 struct bases_handle_t {
     std::vector<aff_mem_t<F>*> d;  // [logical device]: tables * n entries: table j at d + j * n holds 2^(table_bits * j) * P_i
     size_t n = 0;
     int tables = 1;
     int table_bits = 256;  // table j = 2^(table_bits * j) * P
+    // tickets of concurrent callers waiting to be fused (msm_coalesced)
+    mutable std::mutex co_mu;
+    mutable std::condition_variable co_cv;
+    mutable std::deque<msm_ticket_t*> co_q;
+    mutable int co_leaders = 0;
     void free_all() {
         int prev = 0;
         (void)hipGetDevice(&prev);
@@ -544,13 +615,14 @@ struct msm_multi_t {
     uint32_t K = 0;
     size_t npad = 0;  // padded positions of all instances (multiple of SORT_TILE)
     size_t hn = 0;    // points of the registered vector: virtual index = table * hn + base index
+    size_t plane_capacity = 0;  // planes the caller's staging area holds (checked before the copy is enqueued)
 };
 
 // Single-round accumulate grids are 256 workgroups of 4 waves for 256 CUs - one wave per SIMD when every CU gets exactly one
 // workgroup.  The registers would let a CU take two, and the dispatcher does hand some CUs two while others stay idle; asking for
-// more than half of a CU's 160 KB of LDS (unused) makes the second workgroup impossible.  SNARKVM_HIP_ACC_LDS overrides (0: off).
+// more than half of a CU's 160 KB of LDS (unused) makes the second workgroup impossible.  tuning acc_lds overrides (0: off).
 static size_t msm_acc_lds() {
-    static const long env = getenv("SNARKVM_HIP_ACC_LDS") ? atol(getenv("SNARKVM_HIP_ACC_LDS")) : 96 * 1024;
+    const long env = tuning().acc_lds;
     return env < 0 ? 0 : (size_t)env;
 }
 static bool msm_lazy_enabled();
@@ -624,11 +696,12 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     pd.ninst = mu ? (int)mu->K : 0;
     if ((!mu && pd.nplanes > MSM_MAX_POS) || pl.c * (pl.W - 1) + (fold ? fold_m : 0) + nbits > MSM_MAX_POS)
         throw hip_failure{hipErrorInvalidValue, "msm: window geometry exceeds the tail's bit-position range", __LINE__};
+    if (mu && (size_t)pd.nplanes > mu->plane_capacity) throw hip_failure{hipErrorInvalidValue, "msm: plane staging of the fused group too small", __LINE__};
     c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
 
     // 1. scalar read.  Wide windows: fused with the level-1 partition below (the digits never exist in memory); otherwise the
     // stand-alone digit kernel writes the [rows][n] digit matrix.
-    static const int fused_env = getenv("SNARKVM_HIP_FUSED") ? atoi(getenv("SNARKVM_HIP_FUSED")) : 1;
+    const int fused_env = tuning().fused;
     const bool fused = !mu && wide && fused_env && pl.c <= 22 && pl.Wd <= FUSED_MAX_ROWS;  // level-1 key of <= 7 bits: FUSED_G * 2^HB <= FUSED_THREADS
     msm_digit_params_t dp;
     memcpy(dp.bias, pl.bias, sizeof dp.bias);
@@ -825,10 +898,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         phase_begin("msm_accumulate");
         {
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
-            static const size_t env_tailp = getenv("SNARKVM_HIP_TAILP") ? (size_t)atoi(getenv("SNARKVM_HIP_TAILP")) : 0;
-            const size_t tail_partials = env_tailp ? env_tailp : 4;
-            static const int env_rounds = getenv("SNARKVM_HIP_REDUCE_ROUNDS") ? atoi(getenv("SNARKVM_HIP_REDUCE_ROUNDS")) : 2;
-            (void)tail_partials;
+            const int env_rounds = tuning().reduce_rounds;
             if (!single_round) rounds = env_rounds < 0 ? 0 : (env_rounds > 8 ? 8 : env_rounds);
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
@@ -839,7 +909,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             constexpr uint32_t dbg_mask = 0xffffffffu;
 #endif
             // (a 3-waves-per-SIMD build of this kernel - 168 VGPRs - and a software-pipelined gather were measured: no gain)
-            static const int prefetch_env = getenv("SNARKVM_HIP_PREFETCH") ? atoi(getenv("SNARKVM_HIP_PREFETCH")) : 2;  // 0: never, 1: single-round launches only, 2: always (lazy kernel: -2 .. 3 %)
+            const int prefetch_env = tuning().prefetch;  // 0: never, 1: single-round launches only, 2: always (lazy kernel: -2 .. 3 %)
             if constexpr (msm_lazy_field<F>()) {
                 if (msm_lazy_enabled()) {
                     // raw partial sums (208 B each) go to their own buffer; the dense conversion pass fills part_a for the tail
@@ -847,9 +917,9 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                     c.part_raw.ensure(tmax * sizeof(g1_lazy_partial_t));
                     // One workgroup per CU (a dynamic LDS request no second workgroup fits beside) = one accumulate wave per SIMD with half
                     // of the register file and ~64 KB of LDS left free: single-round grids always; multi-round grids when
-                    // SNARKVM_HIP_ACC_ONE_WG is set - the sort and tail kernels of the NEXT instance of a pipelined batch (another
+                    // tuning acc_one_wg is set - the sort and tail kernels of the NEXT instance of a pipelined batch (another
                     // lane's stream) then find room beside the accumulate waves instead of waiting for gaps between its rounds.
-                    static const int one_wg_env = getenv("SNARKVM_HIP_ACC_ONE_WG") ? atoi(getenv("SNARKVM_HIP_ACC_ONE_WG")) : 0;
+                    const int one_wg_env = tuning().acc_one_wg;
                     if ((single_round && prefetch_ok && prefetch_env) || prefetch_env >= 2)
                         hipLaunchKernelGGL((msm_accumulate_lazy_kernel<true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256),
                                            (single_round && prefetch_ok) || one_wg_env ? msm_acc_lds() : 0, st, vbase, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
@@ -901,7 +971,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         // buckets are throughput-bound: one wave per output
         const unsigned fold_blocks = ((1u << fold_m) + (1u << fold_hb)) * (unsigned)nwin;
         const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
-        static const int flat_env = getenv("SNARKVM_HIP_FOLD_FLAT") ? atoi(getenv("SNARKVM_HIP_FOLD_FLAT")) : 1;  // A/B switch
+        const int flat_env = tuning().fold_flat;  // A/B switch
         if (single_round || fold_threads == 256u || flat_env)  // flattened lists: any distribution of the partial sums over the buckets
             hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, pin, start_in,
                                cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
@@ -937,11 +1007,10 @@ static void msm_run_sync(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_
     c.phase_host("msm_host_finish", host_now_ms() - t0);  // the Horner chain over the bit planes, on the calling thread
 }
 
-// G1 accumulation runs on the lazily reduced arithmetic of ffl.hip.h (SNARKVM_HIP_LAZY=0: the exact kernel, A/B switch).  Process
+// G1 accumulation runs on the lazily reduced arithmetic of ffl.hip.h (tuning lazy=0: the exact kernel, A/B switch).  Process
 // wide: every G1 base slot an MSM reads - registered tables and the staging of table-less calls - then holds form406.
 static bool msm_lazy_enabled() {
-    static const int env = getenv("SNARKVM_HIP_LAZY") ? atoi(getenv("SNARKVM_HIP_LAZY")) : 1;
-    return env != 0;
+    return tuning().lazy != 0;
 }
 template <class F>
 static constexpr bool msm_lazy_field() {
@@ -983,19 +1052,19 @@ static void precompute_tables_run(lane_t& c, aff_mem_t<F>* d, size_t n, int tabl
 // lanes a batch cycles through per device: more lanes hide more of the latency-bound tail of small MSMs, fewer keep the
 // workspace footprint of big ones down (a 2^24 lane holds ~4 GB)
 static int batch_lanes(size_t npoints) {
-    static const int env = getenv("SNARKVM_HIP_LANES") ? atoi(getenv("SNARKVM_HIP_LANES")) : 0;
+    const int env = tuning().lanes;
     int l = env > 0 ? env : (npoints >= ((size_t)1 << 20) ? 3 : device_t::LANES);  // measured: 8 lanes +7 % below 2^20, no gain above
     return l < 1 ? 1 : (l > device_t::LANES ? device_t::LANES : l);
 }
 static constexpr size_t MSM_SPLIT_MIN = (size_t)1 << 18;  // pairs per device below which a point-range split costs more than it saves
 static size_t msm_chunk_pairs() {  // pairs per upload / compute chunk of an MSM whose bases arrive from the host
-    static const int lg = getenv("SNARKVM_HIP_MSM_CHUNK_LG") ? atoi(getenv("SNARKVM_HIP_MSM_CHUNK_LG")) : 21;
+    const int lg = tuning().msm_chunk_lg;
     return (size_t)1 << (lg < 16 ? 16 : (lg > 30 ? 30 : lg));
 }
-// pairs per scalar chunk of a host-scalar MSM over registered bases (SNARKVM_HIP_SCALAR_CHUNK_LG, default 2^22: the tail of
+// pairs per scalar chunk of a host-scalar MSM over registered bases (tuning scalar_chunk_lg, default 2^22: the tail of
 // a chunk costs < 1 ms, its upload 2.4 ms)
 static size_t msm_scalar_chunk_pairs() {
-    static const int lg = getenv("SNARKVM_HIP_SCALAR_CHUNK_LG") ? atoi(getenv("SNARKVM_HIP_SCALAR_CHUNK_LG")) : 22;
+    const int lg = tuning().scalar_chunk_lg;
     return (size_t)1 << (lg < 18 ? 18 : lg > 30 ? 30 : lg);
 }
 
@@ -1171,7 +1240,7 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
 }
 
 // A batch of independent MSMs over one registered base vector, fanned out over devices x lanes (see
-// snarkvm_hip_msm_registered_batch).  outs: count Jacobian memory images.
+// snarkvm_hip_msm_registered_batch).  Every request names its own 144 / 288-byte output (Jacobian memory image).
 //
 // Instances of up to 2^18 pairs over windowed tables (one bucket window per table set: the geometries registered for proof-sized
 // commitments, 17 x 15 / 16 x 16 bit) are FUSED: the instances a device received travel as groups through ONE launch sequence
@@ -1181,28 +1250,70 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
 // for the tail (the accumulate grid is sized for the group, not per instance) and ~25 launches are shared by the group.
 static constexpr size_t MSM_FUSE_MAX_PAIRS = (size_t)1 << 18;   // per instance
 static constexpr size_t MSM_FUSE_MAX_ENTRIES = (size_t)1 << 26;  // digit entries (tables x padded pairs) per fused group
-static constexpr size_t MSM_FUSE_MAX_K = 32;
-static constexpr size_t MSM_FUSE_PLANES = 20;                    // >= 2 * (fold_m + 1) planes per instance for windows of <= 16 bits
 static bool msm_fuse_enabled() {
-    static const int env = getenv("SNARKVM_HIP_FUSE_BATCH") ? atoi(getenv("SNARKVM_HIP_FUSE_BATCH")) : 1;  // A/B switch
-    return env != 0;
+    return tuning().fuse_batch != 0;  // A/B switch
+}
+static size_t msm_fuse_max_k() {
+    const int k = tuning().fuse_max_k;
+    return (size_t)(k < 2 ? 2 : (k > 256 ? 256 : k));
+}
+// one MSM of a batch: bases [off0, off0 + n0) followed by [off1, off1 + n1) (KZG10's hiding range; n1 = 0: none) against n0 + n1
+// consecutive scalars; `out`: where its Jacobian memory image goes
+struct msm_req_t {
+    size_t off0 = 0, n0 = 0, off1 = 0, n1 = 0;
+    const void* scalars = nullptr;
+    void* out = nullptr;
+};
+// fn(i) for i < n on up to `max_threads` host threads (the calling thread is one of them).  Used for the Horner finishes of a fused
+// group: 25 - 35 us each on one core, 64 of them per group.
+template <class Fn>
+static void host_parallel_for(size_t n, int max_threads, Fn fn) {
+    size_t T = n / 4;
+    if (T > (size_t)max_threads) T = (size_t)max_threads;
+    if (T <= 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::exception_ptr> errs(T);
+    auto work = [&](size_t t) {
+        try {
+            for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
+        } catch (...) {
+            errs[t] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
+}
+// the handle's geometry admits fused multi-instance groups: one bucket window of 12 .. 16 bits per table set, slots addressable in 31 bits
+template <class F>
+static bool msm_handle_fusable(const bases_handle_t<F>& h, int window_bits) {
+    if (!msm_fuse_enabled() || h.tables <= 1 || h.table_bits < 12 || h.table_bits > 16 || (window_bits != 0 && window_bits != h.table_bits) ||
+        (size_t)h.tables * h.n >= ((size_t)1 << 31) || h.n >= ((size_t)1 << 31))
+        return false;
+    const msm_plan_t pl = msm_make_plan(SORT_TILE, h.table_bits, h.tables, h.table_bits);  // what msm_run will ask of a fused group
+    return pl.W == 1 && pl.c == h.table_bits;
 }
 template <class F>
-static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, const size_t* offsets, const size_t* npoints, const void* const* scalars,
-                          int scalars_on_device, int scalars_montgomery, int window_bits, const size_t* off1 = nullptr, const size_t* n1 = nullptr) {
-    // instance k: bases [offsets[k], + npoints[k]) followed by [off1[k], + n1[k]) (KZG10's hiding range; optional), n0 + n1 scalars
-    auto total = [&](size_t k) { return npoints[k] + (n1 ? n1[k] : 0); };
+static void msm_batch_run(const bases_handle_t<F>& h, const msm_req_t* req, size_t count, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    auto total = [&](size_t k) { return req[k].n0 + req[k].n1; };
     const int nd = g_rt.ndev();
     std::vector<std::vector<size_t>> per_dev(nd);
     size_t largest = 0;
     for (size_t k = 0; k < count; k++) {
-        if (offsets[k] + npoints[k] > h.n || (n1 && off1[k] + n1[k] > h.n))
+        if (req[k].off0 + req[k].n0 > h.n || (req[k].n1 && req[k].off1 + req[k].n1 > h.n))
             throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
-        if (total(k) && !scalars[k]) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null scalar vector", __LINE__};
+        if (total(k) && !req[k].scalars) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null scalar vector", __LINE__};
+        if (!req[k].out) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null output", __LINE__};
         largest = total(k) > largest ? total(k) : largest;
         int dev = (int)(k % (size_t)nd);
         if (scalars_on_device && total(k)) {
-            dev = g_rt.device_of(scalars[k]);
+            dev = g_rt.device_of(req[k].scalars);
             if (dev < 0) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: scalars are not on a device in use", __LINE__};
         }
         per_dev[dev].push_back(k);
@@ -1212,10 +1323,9 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
     for (int d = 0; d < nd; d++)
         if (!per_dev[d].empty()) devs.push_back(d);
     const size_t slot = msm_plane_bytes<F>();
-    const size_t out_bytes = sizeof(jac_mem_t<F>);
-    // geometry of the handle eligible for fused groups: one bucket window of 12 .. 16 bits per table set, slots addressable in 31 bits
-    const bool fusable_handle = msm_fuse_enabled() && h.tables > 1 && h.table_bits >= 12 && h.table_bits <= 16 && (window_bits == 0 || window_bits == h.table_bits) &&
-                                (size_t)h.tables * h.n < ((size_t)1 << 31) && h.n < ((size_t)1 << 31);
+    const bool fusable_handle = msm_handle_fusable(h, window_bits);
+    // planes a fused instance leaves: two tail windows (row sums, column sums) of fold_m + 1 bits, fold_m = table_bits / 2 (msm_run)
+    const size_t fuse_planes = 2 * ((size_t)h.table_bits / 2 + 1);
     auto padded = [](size_t n) { return (n + SORT_TILE - 1) / SORT_TILE * SORT_TILE; };
     for_each_device(devs, [&](int dev) {
         const std::vector<size_t>& mine = per_dev[dev];
@@ -1225,8 +1335,7 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
             std::vector<size_t> group;
             size_t group_entries = 0;
             auto flush = [&] {
-                if (group.size() == 1) jobs.push_back(group);  // a lone instance takes the single-MSM path (its own planner)
-                else if (!group.empty()) jobs.push_back(group);
+                if (!group.empty()) jobs.push_back(group);  // a lone instance takes the single-MSM path (its own planner)
                 group.clear();
                 group_entries = 0;
             };
@@ -1237,7 +1346,7 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
                     continue;
                 }
                 const size_t e = padded(total(k)) * (size_t)h.tables;
-                if (!group.empty() && (group.size() >= MSM_FUSE_MAX_K || group_entries + e > MSM_FUSE_MAX_ENTRIES)) flush();
+                if (!group.empty() && (group.size() >= msm_fuse_max_k() || group_entries + e > MSM_FUSE_MAX_ENTRIES)) flush();
                 group.push_back(k);
                 group_entries += e;
             }
@@ -1253,7 +1362,7 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
         for (size_t i = 0; i < jobs.size(); i++) {
             const size_t K = jobs[i].size();
             plane_off[i] = lane_bytes[i % L];
-            lane_bytes[i % L] += K > 1 ? K * MSM_FUSE_PLANES * sizeof(xyzz_mem_t<F>) : slot;
+            lane_bytes[i % L] += K > 1 ? K * fuse_planes * sizeof(xyzz_mem_t<F>) : slot;
             table_off[i] = lane_bytes[i % L];
             lane_bytes[i % L] += K > 1 ? ((K + 1) * sizeof(msm_inst_t) + 255) / 256 * 256 : 0;
         }
@@ -1265,16 +1374,17 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
             lane_t& c = *lg.lanes[i % L];
             uint8_t* host_planes = c.pin.template as<uint8_t>() + plane_off[i];
             if (jobs[i].size() == 1) {
-                const size_t k = jobs[i][0];
-                const uint4* d_sc = (const uint4*)scalars[k];
-                if (!scalars_on_device && total(k)) {
+                const msm_req_t& r = req[jobs[i][0]];
+                const size_t n = r.n0 + r.n1;
+                const uint4* d_sc = (const uint4*)r.scalars;
+                if (!scalars_on_device && n) {
                     // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
-                    c.scalars.ensure(total(k) * 32);
-                    HIP_TRY(hipMemcpyAsync(c.scalars.p, scalars[k], total(k) * 32, hipMemcpyHostToDevice, c.stream));
+                    c.scalars.ensure(n * 32);
+                    HIP_TRY(hipMemcpyAsync(c.scalars.p, r.scalars, n * 32, hipMemcpyHostToDevice, c.stream));
                     d_sc = c.scalars.template as<uint4>();
                 }
-                pend[i] = msm_run<F>(c, h.d[dev] + offsets[k], d_sc, total(k), host_planes, window_bits, n1 ? h.d[dev] + off1[k] : nullptr,
-                                     n1 ? npoints[k] : ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits);
+                pend[i] = msm_run<F>(c, h.d[dev] + r.off0, d_sc, n, host_planes, window_bits, r.n1 ? h.d[dev] + r.off1 : nullptr, r.n1 ? r.n0 : ~(size_t)0,
+                                     scalars_montgomery, h.tables, h.n, false, h.table_bits);
             } else {
                 // fused group: instance table (pinned -> device), scalars of host callers packed into the lane's scalar buffer
                 const size_t K = jobs[i].size();
@@ -1284,22 +1394,23 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
                 if (!scalars_on_device) c.scalars.ensure(sc_bytes);
                 size_t sc_off = 0;
                 for (size_t q = 0; q < K; q++) {
-                    const size_t k = jobs[i][q];
+                    const msm_req_t& r = req[jobs[i][q]];
+                    const size_t n = r.n0 + r.n1;
                     msm_inst_t& in = tab[q];
-                    in.n = (uint32_t)total(k);
-                    in.n0 = n1 ? (uint32_t)npoints[k] : in.n;
-                    in.off0 = (uint32_t)offsets[k];
-                    in.off1 = n1 ? (uint32_t)off1[k] : 0u;
+                    in.n = (uint32_t)n;
+                    in.n0 = r.n1 ? (uint32_t)r.n0 : in.n;
+                    in.off0 = (uint32_t)r.off0;
+                    in.off1 = r.n1 ? (uint32_t)r.off1 : 0u;
                     in.pstart = (uint32_t)npad;
-                    in.ptiles = (uint32_t)(padded(total(k)) / SORT_TILE);
-                    npad += padded(total(k));
+                    in.ptiles = (uint32_t)(padded(n) / SORT_TILE);
+                    npad += padded(n);
                     if (scalars_on_device) {
-                        in.scalars = (const uint4*)scalars[k];
+                        in.scalars = (const uint4*)r.scalars;
                     } else {
                         uint8_t* dst = c.scalars.template as<uint8_t>() + sc_off;
-                        HIP_TRY(hipMemcpyAsync(dst, scalars[k], total(k) * 32, hipMemcpyHostToDevice, c.stream));
+                        HIP_TRY(hipMemcpyAsync(dst, r.scalars, n * 32, hipMemcpyHostToDevice, c.stream));
                         in.scalars = (const uint4*)dst;
-                        sc_off += total(k) * 32;
+                        sc_off += n * 32;
                     }
                 }
                 tab[K] = msm_inst_t{nullptr, 0, 0, 0, 0, (uint32_t)npad, 0};  // sentinel
@@ -1310,27 +1421,159 @@ static void msm_batch_run(void* outs, const bases_handle_t<F>& h, size_t count, 
                 mu.K = (uint32_t)K;
                 mu.npad = npad;
                 mu.hn = h.n;
+                mu.plane_capacity = K * fuse_planes;  // checked by msm_run BEFORE it enqueues the copy into the staging area
                 pend[i] = msm_run<F>(c, h.d[dev], nullptr, npad, host_planes, 0, nullptr, ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits, &mu);
-                if ((size_t)pend[i].nplanes > K * MSM_FUSE_PLANES) throw hip_failure{hipErrorInvalidValue, "msm batch: plane staging too small", __LINE__};
             }
             done[i] = c.new_event();
             HIP_TRY(hipEventRecord(done[i], c.stream));
         }
-        // the host finishes job i while the GPU works on the later ones
-        std::unique_ptr<msm_accum_t<F>> acc;
+        // the host finishes job i while the GPU works on the later ones; the instances of a fused group on several host threads
         for (size_t i = 0; i < jobs.size(); i++) {
             HIP_TRY(hipEventSynchronize(done[i]));
-            for (size_t q = 0; q < jobs[i].size(); q++) {
-                acc.reset(new msm_accum_t<F>());
-                if (jobs[i].size() == 1)
-                    msm_collect<F>(*acc, pend[i]);
-                else
+            if (jobs[i].size() == 1) {
+                std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
+                msm_collect<F>(*acc, pend[i]);
+                acc->finish(req[jobs[i][0]].out);
+            } else {
+                host_parallel_for(jobs[i].size(), 8, [&](size_t q) {
+                    std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
                     msm_collect_inst<F>(*acc, pend[i], (int)q);
-                acc->finish((uint8_t*)outs + out_bytes * jobs[i][q]);
+                    acc->finish(req[jobs[i][q]].out);
+                });
             }
         }
         for (int l = 0; l < L; l++) lg.lanes[l]->end_call();
     });
+}
+// contiguous outputs (outs + k * sizeof(Jacobian)): the batch entry points of the C ABI
+template <class F>
+static std::vector<msm_req_t> msm_requests(void* outs, size_t count, const size_t* off0, const size_t* n0, const size_t* off1, const size_t* n1,
+                                           const void* const* scalars) {
+    std::vector<msm_req_t> req(count);
+    for (size_t k = 0; k < count; k++) {
+        req[k].off0 = off0[k];
+        req[k].n0 = n0[k];
+        req[k].off1 = (n1 && n1[k]) ? off1[k] : 0;
+        req[k].n1 = n1 ? n1[k] : 0;
+        req[k].scalars = scalars[k];
+        req[k].out = (uint8_t*)outs + sizeof(jac_mem_t<F>) * k;
+    }
+    return req;
+}
+
+// ---- in-library coalescing of concurrent callers ---------------------------------------------------------------------------
+// The reference prover issues one MSM per polynomial from rayon workers (sonic_pc/mod.rs:186-245, kzg10/mod.rs:117-119): many
+// threads inside snarkvm_hip_msm_registered* at the same time, each with ONE proof-sized instance - the shape that runs at a
+// third of the fused rate when every call travels alone.  Here such calls meet: a caller whose MSM is small enough for a fused
+// group (msm_handle_fusable, <= 2^18 pairs) queues a ticket on the HANDLE; whoever finds a free dispatcher slot (two per handle:
+// while one batch computes, the next is being enqueued) takes every compatible ticket that is waiting and runs them as ONE
+// msm_batch_run - group commit.  While a batch is in flight new arrivals pile up, so the batch size adapts to the concurrency by
+// itself; a dispatcher additionally waits `coalesce_us` for stragglers when another thread called within the last 300 us (a
+// rayon fan-out arrives within tens of microseconds).  A lone caller (one thread, sequential calls) never waits and runs exactly
+// the launch sequence of the direct path.  Results are bit-identical to the per-instance path: the same kernels on the same
+// operands, only grouped (tests/test_gpu_coalesce.py).  tuning coalesce=0 switches it off.
+struct msm_ticket_t {
+    msm_req_t req;
+    int on_device = 0, montgomery = 0, window_bits = 0;
+    int state = 0;  // 0 queued, 1 in flight, 2 done, 3 failed
+    std::exception_ptr err;
+};
+static bool msm_other_caller_recently() {
+    static std::atomic<uint64_t> last_ns{0}, last_tid{0};
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const uint64_t now = (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+    const uint64_t tid = (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1u;
+    const uint64_t pt = last_ns.exchange(now), pid = last_tid.exchange(tid);
+    return pid != 0 && pid != tid && now - pt < 300000ull;
+}
+template <class F>
+static bool msm_coalescible(const bases_handle_t<F>& h, size_t n, int window_bits) {
+    return tuning().coalesce && n > 0 && n <= MSM_FUSE_MAX_PAIRS && !g_rt.profiling.load(std::memory_order_relaxed) && msm_handle_fusable(h, window_bits);
+}
+template <class F>
+static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t count) {
+    if (!count) return;
+    scope_flush();  // another thread may run these tickets: what they read must be complete
+    const bool hint = msm_other_caller_recently();
+    std::unique_lock<std::mutex> lk(h.co_mu);
+    for (size_t i = 0; i < count; i++) h.co_q.push_back(&tix[i]);
+    auto mine_done = [&] {
+        for (size_t i = 0; i < count; i++)
+            if (tix[i].state < 2) return false;
+        return true;
+    };
+    bool waited = false;
+    while (!mine_done()) {
+        if (h.co_leaders < 2 && !h.co_q.empty()) {
+            h.co_leaders++;
+            if (!waited && (hint || h.co_leaders > 1) && tuning().coalesce_us > 0) {
+                waited = true;  // once per call: stragglers of the same fan-out
+                h.co_cv.wait_for(lk, std::chrono::microseconds(tuning().coalesce_us));
+            }
+            std::vector<msm_ticket_t*> batch;
+            if (!h.co_q.empty()) {
+                const msm_ticket_t key = *h.co_q.front();
+                std::deque<msm_ticket_t*> rest;
+                for (msm_ticket_t* t : h.co_q) {
+                    if (batch.size() < 1024 && t->on_device == key.on_device && t->montgomery == key.montgomery && t->window_bits == key.window_bits) {
+                        t->state = 1;
+                        batch.push_back(t);
+                    } else {
+                        rest.push_back(t);
+                    }
+                }
+                h.co_q.swap(rest);
+            }
+            lk.unlock();
+            std::exception_ptr err;
+            if (!batch.empty()) {
+                try {
+                    std::vector<msm_req_t> req(batch.size());
+                    for (size_t i = 0; i < batch.size(); i++) req[i] = batch[i]->req;
+                    msm_batch_run<F>(h, req.data(), req.size(), batch[0]->on_device, batch[0]->montgomery, batch[0]->window_bits);
+                } catch (...) {
+                    err = std::current_exception();
+                }
+            }
+            lk.lock();
+            for (msm_ticket_t* t : batch) {
+                t->err = err;
+                t->state = err ? 3 : 2;
+            }
+            h.co_leaders--;
+            h.co_cv.notify_all();
+        } else {
+            h.co_cv.wait(lk);
+        }
+    }
+    lk.unlock();
+    for (size_t i = 0; i < count; i++)
+        if (tix[i].state == 3 && tix[i].err) std::rethrow_exception(tix[i].err);
+}
+// a batch of requests through the coalescer when every one of them qualifies, else straight to msm_batch_run
+template <class F>
+static void msm_batch_dispatch(const bases_handle_t<F>& h, std::vector<msm_req_t>& req, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    bool all_small = !req.empty();
+    for (const msm_req_t& r : req) {
+        if (r.off0 + r.n0 > h.n || (r.n1 && r.off1 + r.n1 > h.n)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
+        if ((r.n0 + r.n1) && !r.scalars) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null scalar vector", __LINE__};
+        if (scalars_on_device && (r.n0 + r.n1) && g_rt.device_of(r.scalars) < 0)
+            throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: scalars are not on a device in use", __LINE__};
+        all_small = all_small && msm_coalescible(h, r.n0 + r.n1, window_bits);
+    }
+    if (!all_small) {
+        msm_batch_run<F>(h, req.data(), req.size(), scalars_on_device, scalars_montgomery, window_bits);
+        return;
+    }
+    std::vector<msm_ticket_t> tix(req.size());
+    for (size_t i = 0; i < req.size(); i++) {
+        tix[i].req = req[i];
+        tix[i].on_device = scalars_on_device ? 1 : 0;
+        tix[i].montgomery = scalars_montgomery ? 1 : 0;
+        tix[i].window_bits = window_bits;
+    }
+    msm_coalesced<F>(h, tix.data(), tix.size());
 }
 
 // ------------------------------------------------------------------------------------------------

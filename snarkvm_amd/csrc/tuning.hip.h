@@ -1,0 +1,102 @@
+// tuning.hip.h - the ONE place where the backend reads launch-geometry / algorithm-variant switches.
+//
+// A prover library should not change its arithmetic or its launch geometry because some variable happens to be set in the
+// environment of the process that loaded it (round-3 review: ~25 getenv sites in the product path).  Everything that is an
+// experiment knob now lives in one struct, filled ONCE from ONE variable:
+//
+//     SNARKVM_HIP_TUNING="key=value,key=value,..."        (unknown keys are an error reported on stderr and ignored)
+//
+// Every key is an A/B switch whose two sides return bit-identical results (tests/test_gpu_multidevice.py runs the suite's
+// MSM / NTT checks under each of them); the defaults are the measured winners and are what DESIGN.md describes.  Operational
+// configuration - not tuning - keeps its own, documented variables: SNARKVM_HIP_DEVICES (device set), SNARKVM_HIP_BASE_CACHE /
+// _MB (the opt-in base cache of snarkvm_msm), SNARKVM_HIP_NTT_TW_MB (HBM cap of the closing-twiddle cache), SNARKVM_HIP_TRACE
+// (chunk timeline on stderr).
+//
+//   key             default  meaning
+//   lazy            1        G1 accumulation on the signed-limb arithmetic of ffl.hip.h (0: exact kernel)
+//   lazy2           1        G2 accumulation on the signed-limb Fq2 arithmetic (0: exact kernel)
+//   fused           1        wide windows: scalar read fused with the level-1 partition (0: stand-alone digit matrix)
+//   hist            2        scalar-read kernel variant (1: one 2 048-scalar tile per workgroup, round 3; 2: streaming, several tiles
+//                            per workgroup with the next tile's loads in flight)
+//   hist_tiles      8        tiles per workgroup of the streaming scalar-read kernel
+//   prefetch        2        base gather software pipeline: 0 never, 1 single-round grids, 2 always
+//   acc_lds         98304    dynamic LDS request that keeps a second accumulate workgroup off a CU (single-round grids); 0: off
+//   acc_one_wg      0        1: one accumulate workgroup per CU for multi-round grids too
+//   reduce_rounds   2        fixed reduce rounds of a multi-round MSM (0 .. 8)
+//   fold_flat       1        flattened-list fold for every MSM (0: per-bucket lists for big ones)
+//   fuse_batch      1        small instances of a batch travel as fused multi-instance groups
+//   fuse_max_k      64       instances per fused group
+//   coalesce        1        concurrent callers of small registered MSMs are fused by an in-library dispatcher
+//   coalesce_us     40       how long a dispatcher waits for further callers when others are inside the library
+//   lanes           0        lanes a batch cycles through (0: 8 below 2^20 pairs, 3 above)
+//   msm_chunk_lg    21       pairs per upload / compute chunk of snarkvm_msm (host bases)
+//   scalar_chunk_lg 22       pairs per scalar chunk of a host-scalar MSM over registered bases
+//   taper           1        snarkvm_msm: the last chunks shrink so that little compute is exposed after the final upload
+//   seg             0        accumulate segment length override (0: planner)
+//   seg2            0        reduce-round group size override
+//   fold_l          0        planner L override
+//   scan1           1        single-launch scan for mid-size counter arrays
+//   ntt_min_tiles   256      workgroups a small-transform pass is spread over
+//   ntt_full_tw     1        materialised closing-twiddle tables
+//   ntt_fold        1        2^261 [/ n] folded into the table of the pass before the last
+//   ntt_signed      1        NTT butterflies on signed limbs (0: the unsigned lazy butterflies of round 3)
+//   ntt_batch       1        snarkvm_hip_ntt_device_batch: one launch per pass for all vectors of a (direction, type) group
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace sv {
+
+struct tuning_t {
+    int lazy = 1, lazy2 = 1, fused = 1, hist = 2, hist_tiles = 8, prefetch = 2;
+    long acc_lds = 96 * 1024;
+    int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, coalesce = 1, coalesce_us = 40, lanes = 0;
+    int msm_chunk_lg = 21, scalar_chunk_lg = 22, taper = 1, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
+    int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 1, ntt_batch = 1;
+
+    bool set(const char* key, long v) {
+#define SV_TUNE_KEY(name)                  \
+    if (!strcmp(key, #name)) {             \
+        name = (decltype(name))v;          \
+        return true;                       \
+    }
+        SV_TUNE_KEY(lazy) SV_TUNE_KEY(lazy2) SV_TUNE_KEY(fused) SV_TUNE_KEY(hist) SV_TUNE_KEY(hist_tiles) SV_TUNE_KEY(prefetch) SV_TUNE_KEY(acc_lds)
+        SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(coalesce)
+        SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
+        SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
+        SV_TUNE_KEY(ntt_batch)
+#undef SV_TUNE_KEY
+        return false;
+    }
+    void parse(const char* s) {
+        while (s && *s) {
+            while (*s == ',' || *s == ' ') s++;
+            const char* eq = strchr(s, '=');
+            const char* end = strchr(s, ',');
+            if (!end) end = s + strlen(s);
+            if (!*s) break;
+            char key[32] = {0};
+            if (!eq || eq > end || (size_t)(eq - s) >= sizeof key) {
+                fprintf(stderr, "[snarkvm_hip] SNARKVM_HIP_TUNING: malformed item at \"%s\" (ignored)\n", s);
+            } else {
+                memcpy(key, s, (size_t)(eq - s));
+                char* num_end = nullptr;
+                const long v = strtol(eq + 1, &num_end, 0);
+                if (num_end == eq + 1 || !set(key, v)) fprintf(stderr, "[snarkvm_hip] SNARKVM_HIP_TUNING: unknown key or bad value \"%s\" (ignored)\n", key);
+            }
+            s = end;
+        }
+    }
+};
+// parsed on first use, once per process (the variable is not consulted again)
+inline const tuning_t& tuning() {
+    static const tuning_t t = [] {
+        tuning_t v;
+        v.parse(getenv("SNARKVM_HIP_TUNING"));
+        return v;
+    }();
+    return t;
+}
+
+}  // namespace sv

@@ -13,7 +13,14 @@ No circuit and no protocol logic: only the MSM / NTT / polynomial calls the prov
 
 `ProofBatch` replays many such proofs concurrently: worker threads (the reference's rayon workers, one commitment / proof
 each) call the C ABI at the same time and the backend hands every call its own (device, stream) lane; with several devices
-in use the proofs' working sets are spread over them and every call runs where its data lives.
+in use the proofs' working sets are spread over them and every call runs where its data lives.  Their proof-sized MSMs meet in
+the library's coalescer (csrc/runtime.hip.h::msm_coalesced) and travel as fused groups.
+
+`LockstepBatch` replays P proofs in LOCK STEP from one thread - `VarunaSNARK::prove_batch` (snark/varuna/varuna.rs:336) is a batch
+by construction: step k of all P proofs is issued together, i.e. round k's commitments of all proofs are ONE
+snarkvm_hip_msm_registered_batch_ex call (P x m instances -> fused groups), the transforms of a step are ONE
+snarkvm_hip_ntt_device_batch call per size (one kernel launch per pass for up to 48 vectors) and the pointwise passes are enqueued
+without a synchronisation each (snarkvm_hip_scope_begin / _end).
 """
 import ctypes
 import threading
@@ -218,6 +225,203 @@ def normalize_results(results):
             zi2 = synthetic._fq2_mul(zi, zi)
             out.append(repr((synthetic._fq2_mul(X, zi2), synthetic._fq2_mul(Y, synthetic._fq2_mul(zi2, zi)))).encode())
     return out
+
+
+class LockstepWorkspace:
+    """Device buffers of P proofs replayed in lock step on one device: four work matrices [P, nmax] (row p = proof p) + the data pool."""
+
+    def __init__(self, keys, count, device_index=0):
+        import torch
+
+        self.keys = keys
+        self.count = count
+        self.device = torch.device("cuda", device_index)
+        with torch.cuda.device(self.device):
+            self.pool = torch.from_numpy(keys.pool_host.view(np.int64).reshape(-1)).to(self.device)
+            self.work = [torch.empty((count, keys.shape.nmax * 4), dtype=torch.int64, device=self.device) for _ in range(4)]
+            torch.cuda.synchronize()
+        self.rem = np.zeros((3, count, 4), dtype=np.uint64)
+        self.times = {"msm": 0.0, "ntt": 0.0, "poly": 0.0, "g2": 0.0, "load": 0.0}
+
+
+def replay_lockstep(ws, salts, collect=False):
+    """The hot-path calls of len(salts) <= ws.count proofs, issued step by step for all proofs together (same calls, sizes and
+    operands as `replay` per proof: results are the same group elements).  Returns per proof the list of its 14 commitments (+ the
+    G2 result) when collect is set."""
+    import torch
+
+    L = _lib.lib()
+    keys = ws.keys
+    sh = keys.shape
+    P = len(salts)
+    assert 0 < P <= ws.count
+    nR, nK = 1 << sh.lg_r, 1 << sh.lg_k
+    A, B, C, D = range(4)
+    pool = ws.pool
+    t = ws.times
+    stride = ws.work[0].stride(0) * 8
+    results = [[] for _ in range(P)] if collect else None
+    step = salts[1] - salts[0] if P > 1 else 1
+    arithmetic = all(salts[i] == salts[0] + i * step for i in range(P)) and step > 0
+
+    def vec(v, p):
+        return ws.work[v].data_ptr() + p * stride
+
+    class scope:  # device-resident calls between loads: enqueued on one stream, one wait at the end
+        def __enter__(self):
+            _lib.check(L.snarkvm_hip_scope_begin(ctypes.c_void_p(pool.data_ptr())))
+
+        def __exit__(self, *exc):
+            _lib.check(L.snarkvm_hip_scope_end())
+            return False
+
+    def timed(kind, fn):
+        t0 = time.perf_counter()
+        fn()
+        t[kind] += time.perf_counter() - t0
+
+    def load(v, n, shift):  # a fresh "polynomial" of n coefficients per proof (device copies on torch's stream: not part of the hot path)
+        t0 = time.perf_counter()
+        w = ws.work[v]
+        with torch.cuda.device(ws.device):
+            if arithmetic:
+                w[:P, : 4 * n].copy_(pool.as_strided((P, 4 * n), (4 * step, 1), 4 * (shift + salts[0])))
+            else:
+                for p in range(P):
+                    s0 = 4 * (shift + salts[p])
+                    w[p, : 4 * n].copy_(pool[s0 : s0 + 4 * n])
+            if w.shape[1] > 4 * n:
+                w[:P, 4 * n :].zero_()
+            torch.cuda.current_stream().synchronize()
+        t["load"] += time.perf_counter() - t0
+
+    def ntt_all(vs, lg, direction, kind=0):  # the same transform of vectors `vs` of every proof: one call, one launch per pass per 48 vectors
+        ptr_list = [vec(v, p) for v in vs for p in range(P)]
+        k = len(ptr_list)
+        ptrs = (ctypes.c_void_p * k)(*ptr_list)
+        dirs = (ctypes.c_int * k)(*([direction] * k))
+        kinds = (ctypes.c_int * k)(*([kind] * k))
+        timed("ntt", lambda: _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(k), ctypes.c_uint32(lg), 0, dirs, kinds)))
+
+    def product(x, y, lg):  # PolyMultiplier::multiply per proof, result in x
+        ntt_all((x, y), lg, 0)
+        for p in range(P):
+            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_mul_device(ctypes.c_void_p(vec(x, p)), ctypes.c_void_p(vec(x, p)), ctypes.c_void_p(vec(y, p)), ctypes.c_size_t(1 << lg))))
+        ntt_all((x,), lg, 1)
+
+    def commit_round(polys):
+        """One SonicKZG10::commit round of ALL proofs: P x len(polys) instances in one batched call (proof-major).  polys: (pointer(p), n, hiding)."""
+        m = len(polys)
+        k = m * P
+        ptrs = (ctypes.c_void_p * k)(*[fp(p) for p in range(P) for fp, _, _ in polys])
+        off0 = (ctypes.c_size_t * k)(*([0] * k))
+        n0 = (ctypes.c_size_t * k)(*[n for _ in range(P) for _, n, _ in polys])
+        off1 = (ctypes.c_size_t * k)(*([sh.nmax] * k))
+        n1 = (ctypes.c_size_t * k)(*[h for _ in range(P) for _, _, h in polys])
+        outs = np.zeros(k, dtype=G1_PROJECTIVE)
+        timed("msm", lambda: _lib.check(L.snarkvm_hip_msm_registered_batch_ex(ctypes.c_void_p(outs.ctypes.data), keys.h, k, off0, n0, off1, n1, ptrs, 1, 1, 0)))
+        if collect:
+            for p in range(P):
+                results[p].extend(outs[p * m + j : p * m + j + 1].tobytes() for j in range(m))
+
+    def work_ptr(v):
+        return lambda p: vec(v, p)
+
+    load(A, nR, 1); load(B, nR, 2)                                                                                 # round 1
+    with scope():
+        ntt_all((A,), sh.lg_r, 1); ntt_all((B,), sh.lg_r, 0)
+    commit_round([(work_ptr(A), nR - 2, 2)])
+    for i, v in enumerate((A, B, C)):                                                                             # round 2
+        load(v, nR, 10 + i)
+    with scope():
+        ntt_all((A, B, C), sh.lg_r, 1)
+    with torch.cuda.device(ws.device):
+        ws.work[D][:P].copy_(ws.work[C][:P])
+        torch.cuda.current_stream().synchronize()
+    with scope():
+        product(A, B, sh.lg_r + 1)
+        for p in range(P):
+            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_vec_op(1, ctypes.c_void_p(vec(A, p)), ctypes.c_void_p(vec(A, p)), ctypes.c_void_p(vec(D, p)), None, None, ctypes.c_size_t(2 * nR), 1)))
+            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_vanishing(ctypes.c_void_p(vec(B, p)), ctypes.c_void_p(vec(C, p)), ctypes.c_void_p(vec(A, p)),
+                                                                                   ctypes.c_size_t(2 * nR), ctypes.c_size_t(nR), 1)))
+    commit_round([(work_ptr(B), nR, 0)])
+    for m in range(3):                                                                                            # round 3
+        load(A, nR, 20 + m); load(B, nR, 30 + m)
+        with scope():
+            ntt_all((A,), sh.lg_r, 1)
+            product(A, B, sh.lg_r + 1)
+    commit_round([(work_ptr(A), nR - 1, 2), (work_ptr(B), nR, 0)])                                                # g_1 (hiding), h_1
+    r4 = (A, B, C)                                                                                                # round 4: g_a, g_b, g_c
+    for m in range(3):
+        v = r4[m]
+        load(v, nK, 40 + m); load(D, nK, 50 + m)
+        with scope():
+            ntt_all((v, D), sh.lg_k, 1)
+        load(D, nK, 60 + m)
+        with scope():
+            ntt_all((D,), sh.lg_k, 1, 1)
+        if m == 0:
+            load(D, nK, 70)
+            with scope():
+                product(v, D, sh.lg_k + 1)
+    commit_round([(work_ptr(A), nK - 1, 0), (work_ptr(B), nK - 1, 0), (work_ptr(C), nK - 1, 0)])
+    base = pool.data_ptr()                                                                                        # round 5
+    commit_round([((lambda p, o=o: base + 32 * (o + salts[p])), n, 0) for o, n in ((3, nK - 2), (5, nK), (9, nR), (11, nK))])
+    opens = []                                                                                                    # openings
+    for i, ((s, n), q) in enumerate(zip(((13, nK), (17, nR), (19, nK)), (B, C, D))):
+        load(A, n, s)
+        with scope():
+            for p in range(P):
+                timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_linear(ctypes.c_void_p(vec(q, p)), ctypes.c_void_p(ws.rem[i, p].ctypes.data), ctypes.c_void_p(vec(A, p)),
+                                                                                    ctypes.c_size_t(n), ctypes.c_void_p(keys.point.ctypes.data), 1)))
+        opens.append((work_ptr(q), n - 1, 0))
+    commit_round(opens)                                                                                           # batch_open: the three witness commitments
+    if keys.hg2:                                                                                                 # G2 leg: one batched call
+        n2 = 1 << sh.lg_g2
+        ptrs = (ctypes.c_void_p * P)(*[pool.data_ptr() + 32 * (23 + salts[p]) for p in range(P)])
+        offs = (ctypes.c_size_t * P)(*([0] * P))
+        ns = (ctypes.c_size_t * P)(*([n2] * P))
+        outs2 = np.zeros(P, dtype=G2_PROJECTIVE)
+        timed("g2", lambda: _lib.check(L.snarkvm_hip_msm_g2_registered_batch(ctypes.c_void_p(outs2.ctypes.data), keys.hg2, P, offs, ns, ptrs, 1, 0)))
+        if collect:
+            for p in range(P):
+                results[p].append(outs2[p : p + 1].tobytes())
+    return results
+
+
+class LockstepBatch:
+    """`count` proofs in groups of `group` replayed in lock step by one thread per device (see the module docstring)."""
+
+    def __init__(self, keys, group=16, devices=None):
+        import torch
+
+        self.keys = keys
+        ndev = torch.cuda.device_count()
+        devices = list(range(ndev)) if devices is None else list(devices)
+        self.group = group
+        self.workspaces = [LockstepWorkspace(keys, group, d) for d in devices]
+
+    def run(self, salts, collect=False):
+        """Replay one proof per entry of `salts`; returns (wall seconds, [commitment lists] or None)."""
+        nws = len(self.workspaces)
+        chunks = [salts[i : i + self.group] for i in range(0, len(salts), self.group)]
+        results = [None] * len(chunks)
+
+        def one(ci):
+            results[ci] = replay_lockstep(self.workspaces[ci % nws], chunks[ci], collect)
+
+        t0 = time.perf_counter()
+        if nws == 1:
+            for ci in range(len(chunks)):
+                one(ci)
+        else:  # one thread per device, each taking every nws-th group
+            def dev_worker(w):
+                for ci in range(w, len(chunks), nws):
+                    one(ci)
+            with ThreadPoolExecutor(nws) as ex:
+                list(ex.map(dev_worker, range(nws)))
+        dt = time.perf_counter() - t0
+        return dt, ([r for ch in results for r in ch] if collect else None)
 
 
 class ProofBatch:

@@ -75,5 +75,11 @@ def test_product_never_imports_the_oracle():
                 elif f.endswith((".hip", ".h", ".hpp", ".cpp")):
                     assert not pat_c.search(open(path).read()), path
     bench = open(os.path.join(util.ROOT, "bench.py")).read()
-    first = bench.index("from oracle import")
-    assert bench.count("from oracle import") == 1 and first > bench.index("CPU baseline + oracle checks (rank 0, N = 1 only)")
+    # every oracle import of bench.py sits inside a checking leg that runs after the timed region of its function
+    markers = ("CPU baseline + oracle checks (rank 0, N = 1 only)", "# ---- checks (outside the timed regions)")
+    for m in re.finditer(r"from oracle import", bench):
+        func_start = bench.rfind("\ndef ", 0, m.start())
+        body = bench[func_start : m.start()]
+        assert any(k in body for k in markers), bench[m.start() - 200 : m.start() + 40]
+        assert "time.perf_counter() - t0" in body  # the timed region of that function has ended before the import
+    assert len(re.findall(r"from oracle import", bench)) >= 2

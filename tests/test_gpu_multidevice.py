@@ -187,9 +187,9 @@ print("RING_OK")
 
 
 def test_chunk_ring_single_device():
-    """The pipelined host-buffer paths at test size: SNARKVM_HIP_MSM_CHUNK_LG=16 cuts a 2^19 `snarkvm_msm` into 9 chunks over
-    the three-lane ring (runtime.hip.h::lane_ring_run), SNARKVM_HIP_SCALAR_CHUNK_LG=18 cuts the cached call's scalars into 3."""
-    env = dict(os.environ, SNARKVM_HIP_DEVICES="0", SNARKVM_HIP_MSM_CHUNK_LG="16", SNARKVM_HIP_SCALAR_CHUNK_LG="18", SNARKVM_HIP_BASE_CACHE="16")
+    """The pipelined host-buffer paths at test size: tuning msm_chunk_lg=16 cuts a 2^19 `snarkvm_msm` into chunks over the
+    three-lane ring (runtime.hip.h::lane_ring_run), scalar_chunk_lg=18 cuts the cached call's scalars into 3."""
+    env = dict(os.environ, SNARKVM_HIP_DEVICES="0", SNARKVM_HIP_TUNING="msm_chunk_lg=16,scalar_chunk_lg=18", SNARKVM_HIP_BASE_CACHE="16")
     script = RING_SCRIPT % (util.ROOT, os.path.join(util.ROOT, "tests", "golden", "beta_h_g2.bin"))
     r = subprocess.run([sys.executable, "-u", "-c", script], capture_output=True, text=True, env=env, timeout=1200, cwd=util.ROOT)
     assert "RING_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
@@ -210,7 +210,7 @@ from tests import util
 G = util.g1_generator_affine()
 def closed(s, start=1):
     return oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(s, start=start), 4)))
-# NTT at proof sizes, all four transforms (the tile rule, SNARKVM_HIP_NTT_MIN_TILES)
+# NTT at proof sizes, all four transforms (the tile rule, tuning ntt_min_tiles)
 for lg in (12, 14, 15, 16, 17):
     x = oracle.fr_op("from_bigint", synthetic.random_fr_integers(1 << lg, 4100 + lg))
     for d in (NTTDirection.Forward, NTTDirection.Inverse):
@@ -238,10 +238,10 @@ print("AB_OK")
 '''
 
 
-@pytest.mark.parametrize("env", [
-    {"SNARKVM_HIP_NTT_MIN_TILES": "1"}, {"SNARKVM_HIP_NTT_MIN_TILES": "1024"}, {"SNARKVM_HIP_LAZY": "0"}, {"SNARKVM_HIP_PREFETCH": "0"},
-    {"SNARKVM_HIP_ACC_ONE_WG": "1", "SNARKVM_HIP_ACC_LDS": "83968"}, {"SNARKVM_HIP_FUSE_BATCH": "0"}, {"SNARKVM_HIP_FUSED": "0"},
-    {"SNARKVM_HIP_S": "96"}, {"SNARKVM_HIP_REDUCE_ROUNDS": "0"}], ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
-def test_ab_switches_are_bit_exact(env):
-    r = subprocess.run([sys.executable, "-c", AB_SCRIPT % util.ROOT], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900, cwd=util.ROOT)
+@pytest.mark.parametrize("tuning", [
+    "ntt_min_tiles=1", "ntt_min_tiles=1024", "lazy=0", "prefetch=0", "acc_one_wg=1,acc_lds=83968", "fuse_batch=0", "fused=0", "seg=96", "reduce_rounds=0",
+    "hist=1", "hist_tiles=3", "ntt_signed=0", "ntt_batch=0", "coalesce=0", "taper=0", "fuse_max_k=2"])
+def test_ab_switches_are_bit_exact(tuning):
+    """csrc/tuning.hip.h: one variable, parsed once per process; every key selects another kernel / launch shape for the same mathematics."""
+    r = subprocess.run([sys.executable, "-c", AB_SCRIPT % util.ROOT], capture_output=True, text=True, env=dict(os.environ, SNARKVM_HIP_TUNING=tuning), timeout=900, cwd=util.ROOT)
     assert r.returncode == 0 and "AB_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,0 +1,218 @@
+"""Round-4 paths of the prover-shaped workload, all through the C ABI, all against the CPU oracle:
+
+* the in-library coalescer (csrc/runtime.hip.h::msm_coalesced): concurrent callers of proof-sized registered MSMs - the
+  reference's rayon fan-out, one `snarkvm_msm`-sized call per polynomial (sonic_pc/mod.rs:186-245) - are fused into groups;
+  every caller still gets ITS result, bit-identical to the per-instance path;
+* the deferred-synchronisation scope (snarkvm_hip_scope_begin / _end) and the batched NTT launches (one launch per pass for up to
+  48 vectors);
+* the lock-step replay of several proofs (snarkvm_amd/proofs.py::replay_lockstep, `VarunaSNARK::prove_batch`'s shape,
+  varuna.rs:336): all 15 results of every proof against oracle/proof_replay.py, and against the per-proof replay.
+"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import cpu as oracle
+from oracle import proof_replay
+from snarkvm_amd import _lib, kzg10, msm, proofs, synthetic
+from snarkvm_amd.layout import G1_PROJECTIVE, G2_PROJECTIVE
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _closed(G, s, start=1):
+    return oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(s, start=start), 4)))
+
+
+@pytest.mark.parametrize("threads,calls", [(12, 6), (3, 10)])
+def test_concurrent_callers_are_coalesced_bit_exactly(threads, calls):
+    """`threads` host threads issue `calls` single-instance MSMs each over one registered vector at the same time (sizes around
+    the fused-instance limits, host and device scalars in different threads): every result equals the closed form
+    sum_i s_i (off + i + 1) G evaluated by the oracle."""
+    import torch
+
+    G = util.g1_generator_affine()
+    n = 1 << 16
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    sizes = [1, 2, 77, 4096, 8191, 8192, 8193, 30000, 50000, 65536]
+    pool = synthetic.random_fr_integers(n, 9090)
+    d_pool = torch.from_numpy(pool.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    errors, done = [], []
+    barrier = threading.Barrier(threads)
+
+    def worker(t):
+        try:
+            barrier.wait()
+            for k in range(calls):
+                m = sizes[(3 * t + 5 * k) % len(sizes)]
+                off = (17 * t + k) % (n - m + 1)
+                lo = (t * 131 + k * 7) % (n - m + 1)
+                if t % 2:
+                    got = rb.msm(pool[lo : lo + m], offset=off)
+                else:
+                    got = rb.msm(device_ptr=d_pool.data_ptr() + 32 * lo, npoints=m, offset=off)
+                if not util.affine_equal(oracle.g1_to_affine(got), _closed(G, pool[lo : lo + m], start=off + 1)):
+                    errors.append((t, k, m, off))
+            done.append(t)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    rb.close()
+    assert not errors, errors[:5]
+    assert len(done) == threads
+
+
+def test_batch_of_many_instances_fused_groups_and_parallel_finish():
+    """One batch call with 150 proof-sized instances (more than one fused group, host finishes on several threads): each result
+    against its closed form; an instance of zero pairs returns the point at infinity."""
+    G = util.g1_generator_affine()
+    n = 1 << 15
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=16, window_bits=16)
+    pool = synthetic.random_fr_integers(n + 4096, 4711)
+    sizes = [(1 + 37 * k * k) % n + 1 for k in range(149)] + [0]
+    offs = [(k * 101) % (n - s + 1) for k, s in enumerate(sizes)]
+    scal = [pool[k : k + s] for k, s in enumerate(sizes)]
+    res = rb.msm_batch(scal, offsets=offs)
+    for k, (s, o) in enumerate(zip(sizes, offs)):
+        got = oracle.g1_to_affine(res[k : k + 1])
+        if s == 0:
+            assert int(got["infinity"][0]) == 1
+        else:
+            assert util.affine_equal(got, _closed(G, scal[k], start=o + 1)), k
+    rb.close()
+
+
+@pytest.mark.parametrize("lg", [9, 10, 13, 16, 17, 18])
+def test_ntt_batched_launches_vs_oracle(lg):
+    """snarkvm_hip_ntt_device_batch with runs of distinct vectors (one launch per pass per run), mixed directions / types, more
+    than 48 vectors, and a vector listed twice in a row: every element of every result against oracle.ntt."""
+    import torch
+
+    L = _lib.lib()
+    nv = 53 if lg <= 13 else 7
+    n = 1 << lg
+    xs = [oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 600 + 10 * lg + i)) for i in range(nv)]
+    dev = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in xs]
+    torch.cuda.synchronize()
+    order = list(range(nv)) + [2, 2, 0]                  # vectors 2 and 0 are transformed again (2 twice in a row)
+    dirs = [0] * (nv - 3) + [1, 1, 1] + [1, 1, 1]        # a forward run, then inverse ones
+    kinds = [0] * (nv - 1) + [1] + [0, 0, 1]
+    ptrs = (ctypes.c_void_p * len(order))(*[dev[i].data_ptr() for i in order])
+    _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(len(order)), ctypes.c_uint32(lg), 0, (ctypes.c_int * len(order))(*dirs),
+                                              (ctypes.c_int * len(order))(*kinds)))
+    want = [x.copy() for x in xs]
+    for i, d, k in zip(order, dirs, kinds):
+        want[i] = oracle.ntt(want[i], oracle.ORDER_NN, d, k)
+    for i in range(nv):
+        assert np.array_equal(dev[i].cpu().numpy().view(np.uint64).reshape(-1, 4), want[i]), (lg, i)
+
+
+def test_scope_defers_synchronisation_not_results():
+    """A chain of device-resident calls inside snarkvm_hip_scope_begin / _end (transforms, a pointwise product, a subtraction, the
+    division by the vanishing polynomial, p / (X - z) with its host remainder) gives the oracle's values; an MSM issued inside the
+    scope sees the scope's results; a second scope_begin on the same thread is refused."""
+    import torch
+
+    L = _lib.lib()
+    lg = 12
+    n = 1 << lg
+    a0 = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 1))
+    b0 = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 2))
+    z = oracle.fr_op("from_bigint", synthetic.random_fr_integers(1, 3))
+    da = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    db = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    dq = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    dr = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    da[: 4 * n] = torch.from_numpy(a0.view(np.int64).reshape(-1)).cuda()
+    db[: 4 * n] = torch.from_numpy(b0.view(np.int64).reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rem = np.zeros((1, 4), dtype=np.uint64)
+    G = util.g1_generator_affine()
+    bases = oracle.g1_gen_bases(G, 1, 2 * n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    _lib.check(L.snarkvm_hip_scope_begin(P(da)))
+    err = L.snarkvm_hip_scope_begin(P(da))
+    assert err.code != 0
+    _lib._libc.free(err.message)
+    ptrs = (ctypes.c_void_p * 2)(da.data_ptr(), db.data_ptr())
+    _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(2), ctypes.c_uint32(lg + 1), 0, None, None))
+    _lib.check(L.snarkvm_hip_fr_mul_device(P(da), P(da), P(db), ctypes.c_size_t(2 * n)))
+    _lib.check(L.snarkvm_hip_ntt_device(P(da), ctypes.c_uint32(lg + 1), 0, 1, 0))
+    _lib.check(L.snarkvm_hip_fr_divide_by_vanishing(P(dq), P(dr), P(da), ctypes.c_size_t(2 * n), ctypes.c_size_t(n), 1))
+    _lib.check(L.snarkvm_hip_fr_divide_by_linear(P(db), ctypes.c_void_p(rem.ctypes.data), P(da), ctypes.c_size_t(2 * n), ctypes.c_void_p(z.ctypes.data), 1))
+    got_msm = rb.msm_batch(device_ptrs=[dq.data_ptr()], npoints=[n], montgomery=True)  # leaves the scope's lane: waits for the scope's queued work first
+    _lib.check(L.snarkvm_hip_scope_end())
+    prod = oracle.polymul(lg + 1, [a0, b0])
+    one = oracle.fr_op("from_bigint", np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    wq, wr = oracle.poly_divide(prod, [(0, oracle.fr_op("neg", one)[0]), (n, one[0])])
+    host = lambda t, k: t[: 4 * k].cpu().numpy().view(np.uint64).reshape(-1, 4)  # noqa: E731
+    assert np.array_equal(host(da, 2 * n), prod)
+    assert np.array_equal(host(dq, wq.shape[0]), wq) and np.array_equal(host(dr, wr.shape[0]), wr)
+    lq, _ = oracle.poly_divide(prod, [(0, oracle.fr_op("neg", z)[0]), (1, one[0])])
+    assert np.array_equal(host(db, lq.shape[0]), lq)
+    assert np.array_equal(rem, oracle.poly_evaluate(prod, z))
+    want = oracle.g1_msm(bases[:n], oracle.fr_op("to_bigint", _pad(wq, n)))
+    assert util.affine_equal(oracle.g1_to_affine(got_msm), oracle.g1_to_affine(want))
+    rb.close()
+
+
+def _pad(v, n):
+    out = np.zeros((n, 4), dtype=np.uint64)
+    out[: v.shape[0]] = v
+    return out
+
+
+def _check_against_oracle(keys, shape, salt, got):
+    want = proof_replay.expected_results(keys.pool_host, keys.g1_host, keys.g2_host, keys.point, shape.lg_r, shape.lg_k, shape.lg_g2, shape.nmax, salt)
+    assert len(got) == 15
+    for j in range(14):
+        ga = kzg10.to_affine(np.frombuffer(got[j], dtype=G1_PROJECTIVE))
+        assert util.affine_equal(ga, want[j]), (salt, j)
+    assert oracle.g2_to_affine(np.frombuffer(got[14], dtype=G2_PROJECTIVE)).tobytes() == want[14].tobytes(), (salt, "g2")
+
+
+def test_lockstep_replay_every_result_vs_oracle():
+    """Three proofs of a reduced shape (|R| = 2^12, |K| = 2^13, G2 2^10) replayed in lock step - arithmetic and arbitrary salts -
+    and one by one: all 14 commitments and the G2 result of every proof against the oracle's restatement of the data flow; the
+    two replays agree."""
+    shape = proofs.ProofShape(lg_r=12, lg_k=13, lg_g2=10)
+    keys = proofs.ProverKeys(shape, seed=5)
+    ws = proofs.LockstepWorkspace(keys, 3)
+    for salts in ([0, 1, 2], [7, 0, 3]):
+        got = proofs.replay_lockstep(ws, salts, collect=True)
+        for s, g in zip(salts, got):
+            _check_against_oracle(keys, shape, s, g)
+    single = proofs.ProofBatch(keys, workers=1)
+    _, one_by_one = single.run([7, 0, 3], collect=True)
+    lock = proofs.replay_lockstep(ws, [7, 0, 3], collect=True)
+    for a, b in zip(one_by_one, lock):
+        assert proofs.normalize_results(a) == proofs.normalize_results(b)
+    keys.close()
+
+
+def test_concurrent_replays_meet_in_the_coalescer_vs_oracle():
+    """Six caller threads replay eight proofs of the reduced shape concurrently (their commit rounds are fused by the coalescer):
+    every result of two of them against the oracle, all of them against a serial replay."""
+    shape = proofs.ProofShape(lg_r=12, lg_k=13, lg_g2=10)
+    keys = proofs.ProverKeys(shape, seed=6)
+    salts = list(range(8))
+    batch = proofs.ProofBatch(keys, workers=6)
+    _, got = batch.run(salts, collect=True)
+    for s in (0, 7):
+        _check_against_oracle(keys, shape, s, got[s])
+    _, serial = proofs.ProofBatch(keys, workers=1).run(salts, collect=True)
+    for a, b in zip(got, serial):
+        assert proofs.normalize_results(a) == proofs.normalize_results(b)
+    keys.close()

@@ -35,7 +35,7 @@ def main():
     sc = synthetic.random_fr_integers(nmax, 5)
     x = synthetic.random_fr_integers(nmax, 6)
     mode = "uncached" if os.environ.get("SNARKVM_HIP_BASE_CACHE") == "0" else "cached (second call onwards)"
-    print(f"mode: {mode}; chunk lg: {os.environ.get('SNARKVM_HIP_MSM_CHUNK_LG', '21 (default)')}")
+    print(f"mode: {mode}; tuning: {os.environ.get('SNARKVM_HIP_TUNING', '(defaults)')}")
     print("| lg n | snarkvm_msm ms (host bases + scalars) | pairs/s | snarkvm_ntt ms (host vector) | elements/s |")
     print("|---|---|---|---|---|")
     rows_poly = []

@@ -6,7 +6,7 @@
   single    one synchronous call per instance
 Device-resident scalars; every result is checked against the closed form (bases (i + 1) G).  Run twice for the A/B:
   python tools/bench_round.py                       # fused groups (default)
-  SNARKVM_HIP_FUSE_BATCH=0 python tools/bench_round.py   # every instance through its own launch sequence on its own lane
+  SNARKVM_HIP_TUNING=fuse_batch=0 python tools/bench_round.py   # every instance through its own launch sequence on its own lane
 """
 import ctypes
 import json
@@ -70,7 +70,7 @@ def main():
     def single():
         return np.concatenate([rb.msm(device_ptr=p, npoints=k) for p, k in zip(ptrs, sizes)])
 
-    res = {"fuse_batch": os.environ.get("SNARKVM_HIP_FUSE_BATCH", "1"), "tables_x_bits": f"{tables} x {bits}", "pairs": sum(sizes), "instances": len(sizes)}
+    res = {"fuse_batch": os.environ.get("SNARKVM_HIP_TUNING", "(defaults)"), "tables_x_bits": f"{tables} x {bits}", "pairs": sum(sizes), "instances": len(sizes)}
     modes = os.environ.get("BENCH_ROUND_MODES", "all14,rounds,single").split(",")  # e.g. all14 alone under rocprofv3
     for name, fn in (("all14", all14), ("rounds", by_rounds), ("single", single)):
         if name not in modes:

@@ -8,7 +8,7 @@ done
 cat $O/phases.md | grep -v "^|---\|msm_digits\|msm_scalar_read"; cat $O/g2.md
 unset SNARKVM_HIP_LIB
 A="--steps 6 --warmup 1 --no-cpu-baseline --no-extra-legs"
-for r in 2 1 0; do SNARKVM_HIP_REDUCE_ROUNDS=$r timeout 300 python bench.py $A > $O/rr$r.json 2> $O/rr$r.err; python - "$O/rr$r.json" <<'PY'
+for r in 2 1 0; do SNARKVM_HIP_TUNING=reduce_rounds=$r timeout 300 python bench.py $A > $O/rr$r.json 2> $O/rr$r.err; python - "$O/rr$r.json" <<'PY'
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); print(sys.argv[1], "ms/step", round(d["ms_per_step"],3), {k:round(v,2) for k,v in d["phase_ms"].items()})

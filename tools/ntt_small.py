@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device-resident Fr NTTs at the domain sizes of a proof (2^12 .. 2^20): microseconds per transform over back-to-back calls on one
-lane, for one value of SNARKVM_HIP_NTT_MIN_TILES (the rule that narrows the tiles of small transforms so that the launch covers
-the chip; 1 = the [2^a x 8] tiles of round 2).  usage: SNARKVM_HIP_NTT_MIN_TILES=k python tools/ntt_small.py"""
+lane, for one value of the tuning key ntt_min_tiles (the rule that narrows the tiles of small transforms so that the launch covers
+the chip; 1 = the [2^a x 8] tiles of round 2).  usage: SNARKVM_HIP_TUNING=ntt_min_tiles=k python tools/ntt_small.py"""
 import ctypes
 import os
 import sys
@@ -17,7 +17,7 @@ from snarkvm_amd import _lib, synthetic  # noqa: E402
 def main():
     L = _lib.lib()
     torch.cuda.set_device(0)
-    print(f"SNARKVM_HIP_NTT_MIN_TILES={os.environ.get('SNARKVM_HIP_NTT_MIN_TILES', '(default)')}")
+    print(f"SNARKVM_HIP_TUNING={os.environ.get('SNARKVM_HIP_TUNING', '(defaults)')}")
     print("| lg n | us per forward NTT (200 back-to-back device calls) | elements/s |")
     print("|---|---|---|")
     for lg in range(12, 21):
