@@ -792,9 +792,20 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             uint32_t* choff = csum + ngroups;
             phase_begin("msm_scalar_read");
             const size_t hist_lds = (size_t)keys * 4;
+            // hist = 2 / 3: the streaming kernel (several tiles per workgroup, the next tile's loads in flight; 2: non-temporal loads);
+            // hist_tiles = 0: as many tiles per workgroup as leave one round of two workgroups per CU
+            const int hist_variant = tuning().hist;
+            uint32_t tpw = tuning().hist_tiles > 0 ? (uint32_t)tuning().hist_tiles : (ntiles + 511u) / 512u;
+            if (tpw < 1) tpw = 1;
+            const uint32_t hist_wgs = (ntiles + tpw - 1) / tpw;
 #define SV_FUSED_HIST(CB)                                                                                                                         \
     case CB:                                                                                                                                      \
-        hipLaunchKernelGGL((radix_hist1_fused_kernel<CB>), dim3(ntiles), dim3(FUSED_THREADS), hist_lds, st, d_scalars, counts1, rp, dp);         \
+        if (hist_variant == 2)                                                                                                                    \
+            hipLaunchKernelGGL((radix_hist1_stream_kernel<CB, true>), dim3(hist_wgs), dim3(FUSED_THREADS), 2 * hist_lds, st, d_scalars, counts1, rp, dp, tpw);  \
+        else if (hist_variant == 3)                                                                                                               \
+            hipLaunchKernelGGL((radix_hist1_stream_kernel<CB, false>), dim3(hist_wgs), dim3(FUSED_THREADS), 2 * hist_lds, st, d_scalars, counts1, rp, dp, tpw); \
+        else                                                                                                                                      \
+            hipLaunchKernelGGL((radix_hist1_fused_kernel<CB>), dim3(ntiles), dim3(FUSED_THREADS), hist_lds, st, d_scalars, counts1, rp, dp);     \
         break;
             switch (pl.c) { SV_FUSED_HIST(17) SV_FUSED_HIST(18) SV_FUSED_HIST(19) SV_FUSED_HIST(20) SV_FUSED_HIST(21) SV_FUSED_HIST(22) }
 #undef SV_FUSED_HIST
