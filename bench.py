@@ -579,6 +579,8 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
     # ---- lock step
     lock = proofs.LockstepBatch(keys, group=min(args.proof_group, max(1, len(mine))), devices=[dev_index])
     lock.run(mine[: lock.group])  # warm-up: allocations, twiddle tables
+    for ws in lock.workspaces:
+        ws.times = {k: 0.0 for k in ws.times}
     barrier()
     t0 = time.perf_counter()
     _, got_lock = lock.run(mine, collect=True)
@@ -648,6 +650,9 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
             "g1_pairs_per_s": args.proofs * shape.pairs() / dt_lock,
             "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt_lock,
             "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_lock.items()},
+            # the fused G1 rate on the proof mix: pairs of this rank / wall time spent inside its snarkvm_hip_msm_registered_batch_ex calls
+            "g1_pairs_per_s_inside_msm_calls": (len(mine) * shape.pairs() / t_lock["msm"]) if t_lock.get("msm") else None,
+            "g2_pairs_per_s_inside_msm_calls": (len(mine) * (1 << shape.lg_g2) / t_lock["g2"]) if t_lock.get("g2") else None,
             "concurrent_callers": {"value": args.proofs / dt_thr, "unit": "proofs/s", "ms_per_proof": dt_thr / args.proofs * 1e3,
                                    "caller_threads_per_rank": len(batch.workspaces), "g1_pairs_per_s": args.proofs * shape.pairs() / dt_thr,
                                    "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_thr.items()},

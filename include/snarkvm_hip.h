@@ -264,6 +264,19 @@ RustError snarkvm_hip_fr_divide_by_vanishing(void *quotient, void *remainder, co
 /* DensePolynomial::mul_by_vanishing_poly (dense.rs:153-159): out (len + domain_size coefficients) = p * (X^D - 1). */
 RustError snarkvm_hip_fr_mul_by_vanishing(void *out, const void *poly, size_t len, size_t domain_size, int on_device);
 
+/* Strided batches of the passes above on device memory - the same pass over one vector of every proof of a batch proved in lock
+ * step (VarunaSNARK::prove_batch, snark/varuna/varuna.rs:336): member y of the batch uses every vector pointer advanced by
+ * y * stride elements (stride >= the vector length); ONE kernel launch sequence for the whole batch.  fr_vec_op_strided: `scalar`
+ * is shared.  fr_divide_by_linear_strided: one opening `point` for all members (a batch opening at one challenge point,
+ * sonic_pc/mod.rs:316-337), `remainders` = count x 32 bytes of HOST memory.  Inside a snarkvm_hip_scope the calls are only
+ * enqueued, like their single-vector forms. */
+RustError snarkvm_hip_fr_vec_op_strided(int op, void *out, const void *a, const void *b, const void *c, const void *scalar,
+                                        size_t n, size_t count, size_t stride);
+RustError snarkvm_hip_fr_divide_by_linear_strided(void *quotients, void *remainders, const void *polys, size_t n,
+                                                  const void *point, size_t count, size_t stride);
+RustError snarkvm_hip_fr_divide_by_vanishing_strided(void *quotients, void *remainders, const void *polys, size_t len,
+                                                     size_t domain_size, size_t count, size_t stride);
+
 /* Synthetic base set for benchmarks: out[i] = (start + i) * G as Rust G1Affine (104 B stride) in
  * device memory. */
 RustError snarkvm_hip_g1_generate_bases_device(void *d_out, uint64_t start, size_t npoints);

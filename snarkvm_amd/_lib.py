@@ -20,6 +20,7 @@ SYMBOLS = [
     "snarkvm_hip_fr_vec_op", "snarkvm_hip_fr_divide_by_linear", "snarkvm_hip_fr_batch_inversion_and_mul",
     "snarkvm_hip_fr_distribute_powers", "snarkvm_hip_fr_lagrange_coefficients", "snarkvm_hip_fr_divide_by_vanishing",
     "snarkvm_hip_fr_mul_by_vanishing",
+    "snarkvm_hip_fr_vec_op_strided", "snarkvm_hip_fr_divide_by_linear_strided", "snarkvm_hip_fr_divide_by_vanishing_strided",
     "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum", "snarkvm_hip_g2_deserialize", "snarkvm_hip_g2_serialize", "snarkvm_hip_g2_deserialize_compressed", "snarkvm_hip_g2_serialize_compressed",
     "snarkvm_hip_register_bases_g2", "snarkvm_hip_free_bases_g2", "snarkvm_hip_msm_g2_registered", "snarkvm_hip_msm_g2_registered_batch",
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
@@ -65,6 +66,7 @@ def lib():
                    "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
                    "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device", "snarkvm_hip_synchronize",
                    "snarkvm_hip_fr_vec_op", "snarkvm_hip_fr_divide_by_linear", "snarkvm_hip_fr_batch_inversion_and_mul", "snarkvm_hip_fr_distribute_powers", "snarkvm_hip_fr_lagrange_coefficients", "snarkvm_hip_fr_divide_by_vanishing", "snarkvm_hip_fr_mul_by_vanishing",
+                   "snarkvm_hip_fr_vec_op_strided", "snarkvm_hip_fr_divide_by_linear_strided", "snarkvm_hip_fr_divide_by_vanishing_strided",
                    "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum", "snarkvm_hip_g2_deserialize", "snarkvm_hip_g2_serialize", "snarkvm_hip_g2_deserialize_compressed", "snarkvm_hip_g2_serialize_compressed",
                    "snarkvm_hip_register_bases_g2", "snarkvm_hip_msm_g2_registered", "snarkvm_hip_msm_g2_registered_batch",
                    "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",

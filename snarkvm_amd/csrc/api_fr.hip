@@ -225,9 +225,16 @@ static void fr_call_done(lane_t& c, int on_device) {
         HIP_TRY(hipStreamSynchronize(c.stream));
 }
 
-RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b, const void* c3, const void* scalar, size_t n, int on_device) {
+static void check_strided(size_t n, size_t count, size_t stride, int on_device, const char* who) {
+    (void)who;
+    if (count == 0 || (count > 1 && (!on_device || stride < n)) || count > 65535)
+        throw hip_failure{hipErrorInvalidValue, "strided batch of an Fr vector pass: needs device operands, 1 <= count <= 65535 and stride >= the vector length", __LINE__};
+}
+static RustError fr_vec_op_impl(int op, void* out, const void* a, const void* b, const void* c3, const void* scalar, size_t n, int on_device, size_t count,
+                                size_t stride) {
     API_BEGIN_DEV(device_for(a, (on_device && n) ? 1 : 0))
     if (op < 0 || op > FR_OP_RSUB_SCALAR) throw hip_failure{hipErrorInvalidValue, "fr_vec_op: unknown op", __LINE__};
+    check_strided(n, count, stride, on_device, "fr_vec_op");
     const bool need_b = op == FR_OP_ADD || op == FR_OP_SUB || op == FR_OP_MUL || op == FR_OP_MUL_SUB || op == FR_OP_AXPY;
     const bool need_c = op == FR_OP_MUL_SUB;
     const bool need_s = op == FR_OP_SCALE || op == FR_OP_SUB_SCALAR || op == FR_OP_AXPY || op == FR_OP_RSUB_SCALAR;
@@ -240,17 +247,26 @@ RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b,
         const fr_mem_t* db = need_b ? fr_stage_in(c, 1, b, n, on_device) : nullptr;
         const fr_mem_t* dc = need_c ? fr_stage_in(c, 2, c3, n, on_device) : nullptr;
         fr_mem_t* dout = fr_stage_out(c, 3, out, n, on_device);
-        hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, c.stream, op, dout, da, db, dc, s, n);
+        hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n), (unsigned)count), dim3(256), 0, c.stream, op, dout, da, db, dc, s, n, stride);
         HIP_TRY(hipGetLastError());
         fr_finish_out(c, dout, out, n, on_device);
         fr_call_done(c, on_device);
     }
     API_END
 }
+RustError snarkvm_hip_fr_vec_op(int op, void* out, const void* a, const void* b, const void* c3, const void* scalar, size_t n, int on_device) {
+    return fr_vec_op_impl(op, out, a, b, c3, scalar, n, on_device, 1, 0);
+}
+RustError snarkvm_hip_fr_vec_op_strided(int op, void* out, const void* a, const void* b, const void* c3, const void* scalar, size_t n, size_t count, size_t stride) {
+    return fr_vec_op_impl(op, out, a, b, c3, scalar, n, 1, count, stride);
+}
 
 // out[i - shift] = h_i = sum_{k >= i} in[k] m^(k - i) (and *first = h_0 when shift == 1); `out` may be null (only h_0 wanted).
 // Scratch for the chunk values of every level lives in the lane's poly[4].
-static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr_mem_t& m, fr_mem_t* d_out, int shift, fr_mem_t* d_first) {
+static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr_mem_t& m, fr_mem_t* d_out, int shift, fr_mem_t* d_first, size_t count = 1,
+                             size_t in_stride = 0, size_t out_stride = 0) {
+    // `count` vectors in one launch sequence (blockIdx.y): inputs / outputs `in_stride` / `out_stride` elements apart, the chunk values
+    // of vector y in its own slice of the scratch area, d_first[y] = h_0 of vector y
     hipStream_t st = c.stream;
     int levels = 1;
     size_t total = 0;
@@ -259,21 +275,23 @@ static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr
         total += t;
         levels++;
     }
-    c.poly[4].ensure(sizeof(fr_mem_t) * (total + levels + 2));
+    c.poly[4].ensure(sizeof(fr_mem_t) * (total * count + levels + 2));
     fr_mem_t* mult = c.poly[4].as<fr_mem_t>();
     fr_mem_t* cvbase = mult + levels + 1;
+    const unsigned ny = (unsigned)count;
     hipLaunchKernelGGL(fr_horner_multipliers_kernel, dim3(1), dim3(1), 0, st, m, mult, levels);
     // up-sweep: level k holds the chunk values of level k - 1 (level 0 = the input)
     std::vector<const fr_mem_t*> in_at{d_in};
-    std::vector<size_t> n_at{n};
+    std::vector<size_t> n_at{n}, stride_at{in_stride};
     fr_mem_t* next = cvbase;
     while (n_at.back() > 1) {
         const size_t cur = n_at.back();
         const size_t T = (cur + POLY_CHUNK - 1) / POLY_CHUNK;
         const int k = (int)n_at.size() - 1;
-        hipLaunchKernelGGL(fr_horner_up_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, in_at.back(), cur, mult + k, next, T);
+        hipLaunchKernelGGL(fr_horner_up_kernel, dim3((unsigned)((T + 255) / 256), ny), dim3(256), 0, st, in_at.back(), cur, mult + k, next, T, stride_at.back(), total);
         in_at.push_back(next);
         n_at.push_back(T);
+        stride_at.push_back(total);
         next += T;
     }
     // the single value of the top level is h_0 of every level below; down-sweep turns each level's chunk values into
@@ -285,36 +303,45 @@ static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr
         const fr_mem_t* carry = (k < top) ? in_at[k + 1] : nullptr;
         if (k > 0) {
             if (k == top) continue;  // one element: it already is its own suffix sum
-            hipLaunchKernelGGL(fr_horner_down_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, in_at[k], cur, mult + k, carry, T,
-                               (fr_mem_t*)in_at[k], 0, (fr_mem_t*)nullptr);
+            hipLaunchKernelGGL(fr_horner_down_kernel, dim3((unsigned)((T + 255) / 256), ny), dim3(256), 0, st, in_at[k], cur, mult + k, carry, T,
+                               (fr_mem_t*)in_at[k], 0, (fr_mem_t*)nullptr, total, total, total);
         } else if (d_out) {
-            hipLaunchKernelGGL(fr_horner_down_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, d_in, cur, mult, carry, T, d_out, shift,
-                               d_first);
+            hipLaunchKernelGGL(fr_horner_down_kernel, dim3((unsigned)((T + 255) / 256), ny), dim3(256), 0, st, d_in, cur, mult, carry, T, d_out, shift,
+                               d_first, in_stride, total, out_stride);
         } else if (d_first) {
             // only h_0: the value of the top level, or of the lone input element
-            HIP_TRY(hipMemcpyAsync(d_first, top > 0 ? in_at[top] : d_in, sizeof(fr_mem_t), hipMemcpyDeviceToDevice, st));
+            for (size_t y = 0; y < count; y++)
+                HIP_TRY(hipMemcpyAsync(d_first + y, (top > 0 ? in_at[top] : d_in) + y * (top > 0 ? total : in_stride), sizeof(fr_mem_t), hipMemcpyDeviceToDevice, st));
         }
     }
     HIP_TRY(hipGetLastError());
 }
 
-RustError snarkvm_hip_fr_divide_by_linear(void* quotient, void* remainder, const void* poly, size_t n, const void* point, int on_device) {
+static RustError fr_divide_by_linear_impl(void* quotient, void* remainder, const void* poly, size_t n, const void* point, int on_device, size_t count,
+                                          size_t stride) {
     API_BEGIN_DEV(device_for(poly, (on_device && n) ? 1 : 0))
     if (!point || (n && !poly)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_linear: missing operand", __LINE__};
+    check_strided(n, count, stride, on_device, "fr_divide_by_linear");
     if (n == 0) {
-        if (remainder) memset(remainder, 0, sizeof(fr_mem_t));
+        if (remainder) memset(remainder, 0, sizeof(fr_mem_t) * count);
     } else {
         const fr_mem_t z = fr_mem_from_host(point);
         const fr_mem_t* din = fr_stage_in(c, 0, poly, n, on_device);
         fr_mem_t* dq = (quotient && n > 1) ? fr_stage_out(c, 1, quotient, n - 1, on_device) : nullptr;
-        c.poly[2].ensure(sizeof(fr_mem_t));
+        c.poly[2].ensure(sizeof(fr_mem_t) * count);
         fr_mem_t* drem = c.poly[2].as<fr_mem_t>();
-        fr_suffix_horner(c, din, n, z, dq, 1, drem);
+        fr_suffix_horner(c, din, n, z, dq, 1, drem, count, stride, stride);
         if (dq) fr_finish_out(c, dq, quotient, n - 1, on_device);
-        if (remainder) c.host_result(remainder, drem, sizeof(fr_mem_t));  // inside a scope: delivered by snarkvm_hip_scope_end
+        if (remainder) c.host_result(remainder, drem, sizeof(fr_mem_t) * count);  // inside a scope: delivered by snarkvm_hip_scope_end
         fr_call_done(c, on_device);
     }
     API_END
+}
+RustError snarkvm_hip_fr_divide_by_linear(void* quotient, void* remainder, const void* poly, size_t n, const void* point, int on_device) {
+    return fr_divide_by_linear_impl(quotient, remainder, poly, n, point, on_device, 1, 0);
+}
+RustError snarkvm_hip_fr_divide_by_linear_strided(void* quotients, void* remainders, const void* polys, size_t n, const void* point, size_t count, size_t stride) {
+    return fr_divide_by_linear_impl(quotients, remainders, polys, n, point, 1, count, stride);
 }
 
 static void fr_batch_inverse_run(lane_t& c, fr_mem_t* d_v, size_t n, const fr_mem_t& coeff) {
@@ -382,7 +409,7 @@ RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const voi
         fr_mem_t l_mem;
         ((t_size - fr_t::one()) * fr_t::from_u32((uint32_t)n).inverse()).to_mem_mont().store(&l_mem);
         hipLaunchKernelGGL(fr_vec_op_kernel, dim3(fr_grid(n)), dim3(256), 0, st, (int)FR_OP_RSUB_SCALAR, du, (const fr_mem_t*)du, (const fr_mem_t*)nullptr,
-                           (const fr_mem_t*)nullptr, tau_mem, n);  // tau - omega^i
+                           (const fr_mem_t*)nullptr, tau_mem, n, (size_t)0);  // tau - omega^i
         fr_batch_inverse_run(c, du, n, one_mem);
         fr_distribute_powers_run(c, du, n, omega_mem, l_mem);  // * l * omega^i
     }
@@ -392,9 +419,11 @@ RustError snarkvm_hip_fr_lagrange_coefficients(void* out, uint32_t lg, const voi
     API_END
 }
 
-RustError snarkvm_hip_fr_divide_by_vanishing(void* quotient, void* remainder, const void* poly, size_t len, size_t domain_size, int on_device) {
+static RustError fr_divide_by_vanishing_impl(void* quotient, void* remainder, const void* poly, size_t len, size_t domain_size, int on_device, size_t count,
+                                             size_t stride) {
     API_BEGIN_DEV(device_for(poly, (on_device && len) ? 1 : 0))
     if (domain_size == 0) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_vanishing: empty domain", __LINE__};
+    check_strided(len, count, stride, on_device, "fr_divide_by_vanishing");
     if (len) {
         if (!poly || !remainder || (len > domain_size && !quotient)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_vanishing: missing operand", __LINE__};
         const size_t qlen = len > domain_size ? len - domain_size : 0;
@@ -403,13 +432,20 @@ RustError snarkvm_hip_fr_divide_by_vanishing(void* quotient, void* remainder, co
         fr_mem_t* dq = qlen ? fr_stage_out(c, 1, quotient, qlen, on_device) : nullptr;
         fr_mem_t* dr = fr_stage_out(c, 2, remainder, rlen, on_device);
         const size_t threads = qlen > rlen ? qlen : rlen;
-        hipLaunchKernelGGL(fr_fold_vanishing_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c.stream, din, len, domain_size, dq, dr);
+        hipLaunchKernelGGL(fr_fold_vanishing_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)count), dim3(256), 0, c.stream, din, len, domain_size, dq, dr,
+                           stride);
         HIP_TRY(hipGetLastError());
         if (qlen) fr_finish_out(c, dq, quotient, qlen, on_device);
         fr_finish_out(c, dr, remainder, rlen, on_device);
         fr_call_done(c, on_device);
     }
     API_END
+}
+RustError snarkvm_hip_fr_divide_by_vanishing(void* quotient, void* remainder, const void* poly, size_t len, size_t domain_size, int on_device) {
+    return fr_divide_by_vanishing_impl(quotient, remainder, poly, len, domain_size, on_device, 1, 0);
+}
+RustError snarkvm_hip_fr_divide_by_vanishing_strided(void* quotients, void* remainders, const void* polys, size_t len, size_t domain_size, size_t count, size_t stride) {
+    return fr_divide_by_vanishing_impl(quotients, remainders, polys, len, domain_size, 1, count, stride);
 }
 RustError snarkvm_hip_fr_mul_by_vanishing(void* out, const void* poly, size_t len, size_t domain_size, int on_device) {
     API_BEGIN_DEV(device_for(out, (on_device && out) ? 1 : 0))

@@ -382,6 +382,29 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const xyzz_mem_t<F>* __
     store_xyzz<F>(&out[t], acc);
 }
 
+// acc[k * L + slot] += the partial sums of bucket k (the bucket sink of a chunked MSM, runtime.hip.h::msm_bucket_sink_t)
+template <class F>
+__global__ void __launch_bounds__(256) msm_bucket_merge_kernel(const xyzz_mem_t<F>* __restrict__ part, const uint32_t* __restrict__ start,
+                                                               const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ acc, uint32_t nbt, uint32_t L,
+                                                               uint32_t slot) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nbt) return;
+    const uint32_t c = cnt[k];
+    if (!c) return;
+    const uint32_t lo = start[k];
+    xyzz_mem_t<F>* dst = &acc[(size_t)k * L + slot];
+    xyzz_t<F> a = load_xyzz<F>(dst);
+    for (uint32_t i = 0; i < c; i++) a.add(load_xyzz<F>(&part[lo + i]));
+    store_xyzz<F>(dst, a);
+}
+// the lists a tail kernel reads from a sink: bucket k owns the L consecutive slots [k * L, (k + 1) * L)
+static __global__ void msm_sink_lists_kernel(uint32_t* __restrict__ start, uint32_t* __restrict__ cnt, uint32_t nbt, uint32_t L) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nbt) return;
+    start[k] = k * L;
+    cnt[k] = k < nbt ? L : 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // 7.-9. tail: weighted bucket sum  sum_b (b + 1) B_b  per window, then the combination of the windows.
 //

@@ -296,15 +296,6 @@ __device__ __forceinline__ uint32_t recoded_digit(const uint32_t* s, int r) {
     return x & ((1u << C) - 1);
 }
 static constexpr int FUSED_MAX_ROWS = 16;  // 288 digit bits / 17-bit windows
-typedef uint32_t sv_u32x4 __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ uint4 load_scalar_half(const uint4* p) {
-    if (NT) {
-        const sv_u32x4 v = __builtin_nontemporal_load((const sv_u32x4*)p);
-        return make_uint4(v.x, v.y, v.z, v.w);
-    }
-    return *p;
-}
 // Coalesced read of 2 * FUSED_THREADS consecutive scalars (half a tile) into `stage` (4 * FUSED_THREADS uint4 = 32 KB): every
 // thread issues its four 16-byte loads before anything waits on them.
 __device__ __forceinline__ void fused_stage_half(const uint4* __restrict__ scalars, size_t first, size_t n, uint4* stage) {
@@ -313,7 +304,7 @@ __device__ __forceinline__ void fused_stage_half(const uint4* __restrict__ scala
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t idx = threadIdx.x + k * FUSED_THREADS;
-        v[k] = ((size_t)(idx >> 1) < cnt) ? load_scalar_half<true>(&scalars[first * 2 + idx]) : make_uint4(0, 0, 0, 0);  // last read of these lines
+        v[k] = ((size_t)(idx >> 1) < cnt) ? scalars[first * 2 + idx] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) stage[threadIdx.x + k * FUSED_THREADS] = v[k];
@@ -358,65 +349,58 @@ __global__ void __launch_bounds__(FUSED_THREADS) radix_hist1_fused_kernel(const 
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < keys; i += FUSED_THREADS) cnt[(size_t)t * keys + i] = hist[i];
 }
-// The same counts, STREAMING (round 4; tuning hist=2, the default): a workgroup owns `tiles_per_wg` consecutive tiles and keeps the
-// loads of tile t + 1 in flight while it recodes and counts tile t, so a CU never sits between "all loads consumed" and "next
-// workgroup's loads issued" (the one-tile kernel above reads at 4.1 - 4.3 TB/s, 0.50 - 0.53 of the 8 TB/s spec depending on the
-// box).  Two LDS histograms alternate: the counters of tile t are written out and cleared while tile t + 1 is counted into the
-// other one - one barrier per tile.  The scalars are read with non-temporal loads (nothing in this kernel touches a line twice).
-// The output is identical to radix_hist1_fused_kernel's: one row of counters per 2 048-scalar tile.
-template <int C, bool NT>
-__global__ void __launch_bounds__(FUSED_THREADS) radix_hist1_stream_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ cnt,
-                                                                    msm_radix_params_t p, msm_digit_params_t dp, uint32_t tiles_per_wg) {
-    extern __shared__ uint32_t fused_hist[];  // 2 * keys counters
+// The same counts from a WIDER workgroup with REPLICATED histograms (round 4; tuning hist=2, the default).  tools/exp/histbench.hip
+// took the one-tile kernel above apart on 2^24 scalars: reading alone takes 85 - 88 us (6.1 - 6.3 TB/s), reading + recoding + digit
+// extraction 93 us, the full kernel 124 - 127 us - the LDS atomics are what is left, and they serialise when lanes of a wave hit
+// the same counter (64 lanes into 128 bins of a row).  Four private copies of the histogram (copy = lane & 3, interleaved so that
+// different copies never share a bank) cut those collisions fourfold; 1 024 threads x 2 scalars instead of 512 x 4 keep twice the
+// waves per tile in flight with half the registers each.  Measured: 102.8 us = 5.2 TB/s = 0.65 of the 8 TB/s spec (one copy:
+// 126 us, two: 105, eight: 121; 512 x 4 with four copies: 115; a streaming variant that kept the next tile's loads in flight while
+// counting - fewer, fatter workgroups - was slower than the round-3 kernel: 153 us).  Same output: one row of counters per tile.
+static constexpr int HISTW_THREADS = 1024;
+static constexpr int HISTW_SPT = FUSED_TILE / HISTW_THREADS;  // 2
+static constexpr int HISTW_COPIES = 4;
+template <int C>
+__global__ void __launch_bounds__(HISTW_THREADS) radix_hist1_wide_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ cnt, msm_radix_params_t p,
+                                                                  msm_digit_params_t dp) {
+    extern __shared__ uint32_t fused_hist[];  // keys * HISTW_COPIES counters, copy-interleaved
     const uint32_t B1 = 1u << p.HB;
     const uint32_t rows = (uint32_t)dp.W;
     const uint32_t keys = rows * B1;
-    const uint32_t ntiles = p.tiles_per_row;
-    const uint32_t t0 = blockIdx.x * tiles_per_wg;
-    const uint32_t t1 = t0 + tiles_per_wg < ntiles ? t0 + tiles_per_wg : ntiles;
-    if (t0 >= t1) return;
-    uint4 lo[FUSED_SPT], hi[FUSED_SPT];
-    auto fetch = [&](uint32_t t, uint4* l, uint4* h) {
+    const uint32_t t = blockIdx.x;
+    uint4 lo[HISTW_SPT], hi[HISTW_SPT];
 #pragma unroll
-        for (int q = 0; q < FUSED_SPT; q++) {
-            const size_t i = (size_t)t * FUSED_TILE + (size_t)q * FUSED_THREADS + threadIdx.x;
-            if (i < p.n) {
-                l[q] = load_scalar_half<NT>(&scalars[2 * i]);
-                h[q] = load_scalar_half<NT>(&scalars[2 * i + 1]);
-            } else {
-                l[q] = h[q] = make_uint4(0, 0, 0, 0);
-            }
+    for (int q = 0; q < HISTW_SPT; q++) {
+        const size_t i = (size_t)t * FUSED_TILE + (size_t)q * HISTW_THREADS + threadIdx.x;
+        if (i < p.n) {
+            lo[q] = scalars[2 * i];
+            hi[q] = scalars[2 * i + 1];
+        } else {
+            lo[q] = hi[q] = make_uint4(0, 0, 0, 0);
         }
-    };
-    fetch(t0, lo, hi);
-    for (uint32_t i = threadIdx.x; i < 2 * keys; i += FUSED_THREADS) fused_hist[i] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < keys * HISTW_COPIES; i += HISTW_THREADS) fused_hist[i] = 0;
     __syncthreads();
     const int half = 1 << (p.c - 1);
-    for (uint32_t t = t0; t < t1; t++) {
-        uint32_t* hist = fused_hist + ((t - t0) & 1u) * keys;
-        uint4 nlo[FUSED_SPT], nhi[FUSED_SPT];
-        if (t + 1 < t1) fetch(t + 1, nlo, nhi);  // in flight while this tile is counted
+    const uint32_t copy = threadIdx.x & (HISTW_COPIES - 1);
 #pragma unroll
-        for (int q = 0; q < FUSED_SPT; q++) {
-            if ((size_t)t * FUSED_TILE + (size_t)q * FUSED_THREADS + threadIdx.x >= p.n) continue;
-            uint32_t s[11];
-            recode_scalar(lo[q], hi[q], dp, s);
+    for (int q = 0; q < HISTW_SPT; q++) {
+        if ((size_t)t * FUSED_TILE + (size_t)q * HISTW_THREADS + threadIdx.x >= p.n) continue;
+        uint32_t s[11];
+        recode_scalar(lo[q], hi[q], dp, s);
 #pragma unroll
-            for (int r = 0; r < FUSED_MAX_ROWS; r++) {
-                uint32_t b, neg;
-                if (C * r < MSM_BIAS_BITS && (uint32_t)r < rows && digit_bucket(recoded_digit<C>(s, r), half, b, neg)) atomicAdd(&hist[r * B1 + (b >> p.LB)], 1u);
-            }
+        for (int r = 0; r < FUSED_MAX_ROWS; r++) {
+            uint32_t b, neg;
+            if (C * r < MSM_BIAS_BITS && (uint32_t)r < rows && digit_bucket(recoded_digit<C>(s, r), half, b, neg))
+                atomicAdd(&fused_hist[(r * B1 + (b >> p.LB)) * HISTW_COPIES + copy], 1u);
         }
-        __syncthreads();
-        // this tile's row of counters leaves, its histogram is cleared for tile t + 2 (the barrier after tile t + 1's count orders the two)
-        for (uint32_t i = threadIdx.x; i < keys; i += FUSED_THREADS) {
-            cnt[(size_t)t * keys + i] = hist[i];
-            hist[i] = 0;
-        }
-        if (t + 1 < t1) {
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < keys; i += HISTW_THREADS) {
+        uint32_t v = 0;
 #pragma unroll
-            for (int q = 0; q < FUSED_SPT; q++) lo[q] = nlo[q], hi[q] = nhi[q];
-        }
+        for (int k = 0; k < HISTW_COPIES; k++) v += fused_hist[i * HISTW_COPIES + k];
+        cnt[(size_t)t * keys + i] = v;
     }
 }
 // key = (j * W + w) * B1 + bin  ->  position of (q = w * B1 + bin, j) in the scan order

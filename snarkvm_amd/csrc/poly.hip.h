@@ -21,7 +21,15 @@ namespace sv {
 
 enum { FR_OP_ADD = 0, FR_OP_SUB = 1, FR_OP_MUL = 2, FR_OP_MUL_SUB = 3, FR_OP_SCALE = 4, FR_OP_SUB_SCALAR = 5, FR_OP_AXPY = 6, FR_OP_RSUB_SCALAR = 7 };
 
-static __global__ void fr_vec_op_kernel(int op, fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, const fr_mem_t* c, fr_mem_t s_mem, size_t n) {
+// Strided batches (lock-step proving: the same pass over vector v of every proof of a batch): blockIdx.y selects the vector, every
+// vector operand of batch member y starts `stride` elements after that of member y - 1.  A single call is a batch of one.
+static __global__ void fr_vec_op_kernel(int op, fr_mem_t* out, const fr_mem_t* a, const fr_mem_t* b, const fr_mem_t* c, fr_mem_t s_mem, size_t n, size_t stride) {
+    {
+        const size_t off = (size_t)blockIdx.y * stride;
+        out += off, a += off;
+        if (b) b += off;
+        if (c) c += off;
+    }
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     const fr_t s_shift = fr_t::load(&s_mem);
@@ -61,9 +69,11 @@ static __global__ void fr_horner_multipliers_kernel(fr_mem_t m_mem, fr_mem_t* mu
     }
 }
 static __global__ void fr_horner_up_kernel(const fr_mem_t* __restrict__ in, size_t n, const fr_mem_t* __restrict__ m_mem, fr_mem_t* __restrict__ cv,
-                                    size_t T) {
+                                    size_t T, size_t in_stride, size_t cv_stride) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= T) return;
+    in += (size_t)blockIdx.y * in_stride;
+    cv += (size_t)blockIdx.y * cv_stride;
     const fr_t m = fr_t::load(m_mem).from_mem_mont();
     const size_t lo = t * POLY_CHUNK;
     const size_t hi = (lo + POLY_CHUNK < n) ? lo + POLY_CHUNK : n;
@@ -75,9 +85,13 @@ static __global__ void fr_horner_up_kernel(const fr_mem_t* __restrict__ in, size
 // for i >= shift and *first = h_0 when shift == 1 (quotient by X - m: q_(i-1) = h_i, remainder = h_0).
 // in == out is allowed when shift == 0.
 static __global__ void fr_horner_down_kernel(const fr_mem_t* in, size_t n, const fr_mem_t* __restrict__ m_mem, const fr_mem_t* __restrict__ carry,
-                                      size_t T, fr_mem_t* out, int shift, fr_mem_t* first) {
+                                      size_t T, fr_mem_t* out, int shift, fr_mem_t* first, size_t in_stride, size_t carry_stride, size_t out_stride) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= T) return;
+    in += (size_t)blockIdx.y * in_stride;
+    if (carry) carry += (size_t)blockIdx.y * carry_stride;
+    out += (size_t)blockIdx.y * out_stride;
+    if (first) first += blockIdx.y;
     const fr_t m = fr_t::load(m_mem).from_mem_mont();
     const size_t lo = t * POLY_CHUNK;
     const size_t hi = (lo + POLY_CHUNK < n) ? lo + POLY_CHUNK : n;
@@ -152,7 +166,12 @@ static __global__ void fr_onehot_kernel(fr_mem_t* v, size_t n, fr_mem_t x_mem, f
 // Long division of a (len coefficients) by X^D - 1 folds the coefficient classes mod D:
 //   quotient_i = sum_{k >= 1} a_(i + kD)   (i < len - D),   remainder_i = sum_{k >= 0} a_(i + kD)   (i < min(D, len)).
 static __global__ void fr_fold_vanishing_kernel(const fr_mem_t* __restrict__ a, size_t len, size_t D, fr_mem_t* __restrict__ quot,
-                                         fr_mem_t* __restrict__ rem) {
+                                         fr_mem_t* __restrict__ rem, size_t stride) {
+    {
+        const size_t off = (size_t)blockIdx.y * stride;
+        a += off, rem += off;
+        if (quot) quot += off;
+    }
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t qlen = len > D ? len - D : 0;
     const size_t rlen = len < D ? len : D;

@@ -127,6 +127,7 @@ struct lane_t {
     dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
     dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
     dev_buf fold_sums;                                                        // two-axis bucket fold
+    dev_buf sink_acc;                                                         // bucket sink of a chunked MSM (msm_bucket_sink_t)
     dev_buf fchunk;                                                           // chunk sums / offsets of the fused level-1 scan
     dev_buf bases_tmp, scalars_tmp, gen_pts, gen_prod;
     // NTT / polynomial staging
@@ -628,6 +629,72 @@ static size_t msm_acc_lds() {
 static bool msm_lazy_enabled();
 template <class F>
 static constexpr bool msm_lazy_field();
+// Tail geometry of an MSM with `nwin` bucket windows of 2^(c - 1) buckets: windows of >= 2^11 buckets are first folded into two tail
+// windows of 2^fold_m / 2^fold_hb - 1 entries; so are smaller windows when there are too few (window, bit) pairs to spread an
+// unfolded tail over the chip (registered tables below 4 096 points: 2 windows x 8 bits would be 16 workgroups walking every
+// partial sum; the fold gives 48).  Fills the pending record the host finish reads.
+struct msm_tail_geom_t {
+    int fold_m, fold_hb, tail_windows, nbits;
+    bool fold;
+};
+static msm_tail_geom_t msm_tail_geometry(const msm_plan_t& pl, uint32_t nwin, msm_pending_t& pd, int ninst) {
+    msm_tail_geom_t g;
+    const int K = pl.c - 1;
+    g.fold_m = (K + 1) / 2;
+    g.fold_hb = K - g.fold_m;
+    g.fold = K >= 11 || (K >= 4 && pl.c * pl.W < 128);
+    g.tail_windows = g.fold ? 2 * (int)nwin : (int)nwin;
+    g.nbits = g.fold ? g.fold_m + 1 : pl.c;  // weights run up to 2^fold_m (L sums) / 2^(c-1) (plain buckets)
+    pd.tail_windows = g.tail_windows;
+    pd.nbits = g.nbits;
+    pd.nplanes = g.tail_windows * g.nbits;
+    pd.c = pl.c;
+    pd.m = g.fold_m;
+    pd.folded = g.fold;
+    pd.ninst = ninst;
+    if ((!ninst && pd.nplanes > MSM_MAX_POS) || pl.c * (pl.W - 1) + (g.fold ? g.fold_m : 0) + g.nbits > MSM_MAX_POS)
+        throw hip_failure{hipErrorInvalidValue, "msm: window geometry exceeds the tail's bit-position range", __LINE__};
+    return g;
+}
+// 7.-9. of msm_run: per-bucket partial-sum lists (sums, start, cnt) -> fold -> bit-plane sums -> copy to `host_planes` (the host runs
+// the Horner chain).  flat: flattened-list fold (any distribution of the partial sums over the buckets).
+template <class F>
+static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom_t& g, uint32_t nwin, uint32_t nbt, const xyzz_mem_t<F>* sums,
+                            const uint32_t* start, const uint32_t* cnt, bool flat, const msm_pending_t& pd, void* host_planes) {
+    hipStream_t st = c.stream;
+    c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
+    if (g.fold) {
+        c.fold_sums.ensure(((size_t)nwin << (g.fold_m + 1)) * sizeof(xyzz_mem_t<F>));
+        // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
+        // (<= 512 workgroups at two waves per SIMD); many windows (table-less small MSMs: 20 windows x 128 outputs) or many
+        // buckets are throughput-bound: one wave per output
+        const unsigned fold_blocks = ((1u << g.fold_m) + (1u << g.fold_hb)) * (unsigned)nwin;
+        const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
+        if (flat || fold_threads == 256u)
+            hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
+                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb);
+        else
+            hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
+                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb);
+        const unsigned plane_threads = g.fold_m <= 6 ? 64u : g.fold_m == 7 ? 128u : 256u;  // one lane per entry of a plane (<= 2^fold_m)
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)g.nbits, (unsigned)g.tail_windows), dim3(plane_threads), 0, st,
+                           (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, g.fold_m, g.fold_hb);
+    } else {
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, false>), dim3((unsigned)g.nbits, (unsigned)g.tail_windows), dim3(256), 0, st, sums, start, cnt,
+                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_planes, c.planes.p, (size_t)pd.nplanes * sizeof(xyzz_mem_t<F>), hipMemcpyDeviceToHost, st));
+}
+// A bucket sink: the chunks of ONE big MSM (snarkvm_msm over host bases: point-range chunks that arrive over PCIe one after the other)
+// leave their per-bucket partial sums in a persistent accumulator instead of each running its own fold / bit-plane tail; the tail runs
+// once, over the accumulator, after the last chunk.  L lanes work on the chunks concurrently: each owns one slot per bucket
+// (bucket k, lane l -> acc[k * L + l]), so no two streams ever touch the same slot.
+struct msm_bucket_sink_t {
+    void* acc = nullptr;  // xyzz_mem_t<F>[nbt * L], zero-initialised (the point at infinity)
+    uint32_t L = 1, slot = 0, nbt = 0;
+};
 // Device side of one MSM on lane `c`: d_bases = converted device bases; d_scalars = device scalars (32 B each).  Everything
 // is enqueued on the lane's stream, ending with the copy of the bit-plane sums into `host_planes` (pinned, >=
 // msm_plane_bytes<F>(...)); the caller synchronises the stream and runs msm_collect / msm_accum_t::finish.
@@ -638,7 +705,8 @@ static size_t msm_plane_bytes() {
 template <class F>
 static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* host_planes, int window_bits,
                              const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
-                             size_t table_stride = 0, bool profile = true, int table_bits = 0, const msm_multi_t* mu = nullptr) {
+                             size_t table_stride = 0, bool profile = true, int table_bits = 0, const msm_multi_t* mu = nullptr,
+                             const msm_bucket_sink_t* sink = nullptr) {
     // mu != nullptr: fused multi-instance run (msm_sort.hip.h): n = mu->npad padded positions, d_bases = the handle's table array,
     // d_scalars unused (the instance table carries the pointers), one bucket window per instance; host_planes holds
     // mu->K * 2 * (fold_m + 1) planes.
@@ -679,24 +747,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
     c.part_a.ensure(T0_max * sizeof(xyzz_mem_t<F>));
     c.part_b.ensure(T1_max * sizeof(xyzz_mem_t<F>));
-    // tail geometry: windows of >= 2^11 buckets are first folded into two tail windows of 2^fold_m / 2^fold_hb - 1 entries; so are
-    // smaller windows when there are too few (window, bit) pairs to spread an unfolded tail over the chip (registered tables
-    // below 4 096 points: 2 windows x 8 bits would be 16 workgroups walking every partial sum; the fold gives 48)
-    const int K = pl.c - 1;
-    const int fold_m = (K + 1) / 2, fold_hb = K - fold_m;
-    const bool fold = K >= 11 || (K >= 4 && pl.c * pl.W < 128);
-    const int tail_windows = fold ? 2 * (int)nwin : (int)nwin;
-    const int nbits = fold ? fold_m + 1 : pl.c;  // weights run up to 2^fold_m (L sums) / 2^(c-1) (plain buckets)
-    pd.tail_windows = tail_windows;
-    pd.nbits = nbits;
-    pd.nplanes = tail_windows * nbits;
-    pd.c = pl.c;
-    pd.m = fold_m;
-    pd.folded = fold;
-    pd.ninst = mu ? (int)mu->K : 0;
-    if ((!mu && pd.nplanes > MSM_MAX_POS) || pl.c * (pl.W - 1) + (fold ? fold_m : 0) + nbits > MSM_MAX_POS)
-        throw hip_failure{hipErrorInvalidValue, "msm: window geometry exceeds the tail's bit-position range", __LINE__};
+    const int K = pl.c - 1;  // bucket-index bits
+    const msm_tail_geom_t tg = msm_tail_geometry(pl, nwin, pd, mu ? (int)mu->K : 0);
     if (mu && (size_t)pd.nplanes > mu->plane_capacity) throw hip_failure{hipErrorInvalidValue, "msm: plane staging of the fused group too small", __LINE__};
+    if (sink && (mu || sink->nbt != nbt)) throw hip_failure{hipErrorInvalidValue, "msm: bucket sink does not match the plan", __LINE__};
     c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
 
     // 1. scalar read.  Wide windows: fused with the level-1 partition below (the digits never exist in memory); otherwise the
@@ -792,18 +846,12 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             uint32_t* choff = csum + ngroups;
             phase_begin("msm_scalar_read");
             const size_t hist_lds = (size_t)keys * 4;
-            // hist = 2 / 3: the streaming kernel (several tiles per workgroup, the next tile's loads in flight; 2: non-temporal loads);
-            // hist_tiles = 0: as many tiles per workgroup as leave one round of two workgroups per CU
+            // hist = 2: 1 024-thread workgroups with four private histogram copies (msm_sort.hip.h); 1: the round-3 kernel
             const int hist_variant = tuning().hist;
-            uint32_t tpw = tuning().hist_tiles > 0 ? (uint32_t)tuning().hist_tiles : (ntiles + 511u) / 512u;
-            if (tpw < 1) tpw = 1;
-            const uint32_t hist_wgs = (ntiles + tpw - 1) / tpw;
 #define SV_FUSED_HIST(CB)                                                                                                                         \
     case CB:                                                                                                                                      \
         if (hist_variant == 2)                                                                                                                    \
-            hipLaunchKernelGGL((radix_hist1_stream_kernel<CB, true>), dim3(hist_wgs), dim3(FUSED_THREADS), 2 * hist_lds, st, d_scalars, counts1, rp, dp, tpw);  \
-        else if (hist_variant == 3)                                                                                                               \
-            hipLaunchKernelGGL((radix_hist1_stream_kernel<CB, false>), dim3(hist_wgs), dim3(FUSED_THREADS), 2 * hist_lds, st, d_scalars, counts1, rp, dp, tpw); \
+            hipLaunchKernelGGL((radix_hist1_wide_kernel<CB>), dim3(ntiles), dim3(HISTW_THREADS), hist_lds * HISTW_COPIES, st, d_scalars, counts1, rp, dp); \
         else                                                                                                                                      \
             hipLaunchKernelGGL((radix_hist1_fused_kernel<CB>), dim3(ntiles), dim3(FUSED_THREADS), hist_lds, st, d_scalars, counts1, rp, dp);     \
         break;
@@ -973,33 +1021,37 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         T_in_max = T_out_max;
     }
     phase_end();
+    if (sink) {
+        // a chunk of a bigger MSM: its per-bucket partial sums join the sink; the tail runs once, after the last chunk (msm_tail_from_sink)
+        phase_begin("msm_bucket_merge");
+        hipLaunchKernelGGL((msm_bucket_merge_kernel<F>), dim3((nbt + 255) / 256), dim3(256), 0, st, (const xyzz_mem_t<F>*)pin, (const uint32_t*)start_in,
+                           (const uint32_t*)cnt_in, (xyzz_mem_t<F>*)sink->acc, nbt, sink->L, sink->slot);
+        phase_end();
+        HIP_TRY(hipGetLastError());
+        pd.nplanes = 0;
+        return pd;
+    }
     // 7.-9. fold -> bit-plane sums -> (host) Horner
     phase_begin("msm_bucket_reduce");
-    if (fold) {
-        c.fold_sums.ensure(((size_t)nwin << (fold_m + 1)) * sizeof(xyzz_mem_t<F>));
-        // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
-        // (<= 512 workgroups at two waves per SIMD); many windows (table-less small MSMs: 20 windows x 128 outputs) or many
-        // buckets are throughput-bound: one wave per output
-        const unsigned fold_blocks = ((1u << fold_m) + (1u << fold_hb)) * (unsigned)nwin;
-        const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
-        const int flat_env = tuning().fold_flat;  // A/B switch
-        if (single_round || fold_threads == 256u || flat_env)  // flattened lists: any distribution of the partial sums over the buckets
-            hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, pin, start_in,
-                               cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
-        else
-            hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << fold_m) + (1u << fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, pin, start_in,
-                               cnt_in, c.fold_sums.as<xyzz_mem_t<F>>(), fold_m, fold_hb);
-        const unsigned plane_threads = fold_m <= 6 ? 64u : fold_m == 7 ? 128u : 256u;  // one lane per entry of a plane (<= 2^fold_m)
-        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(plane_threads), 0, st,
-                           (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, fold_m, fold_hb);
-    } else {
-        hipLaunchKernelGGL((msm_bitplane_kernel<F, false>), dim3((unsigned)nbits, (unsigned)tail_windows), dim3(256), 0, st, pin, start_in, cnt_in,
-                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0);
-    }
+    msm_tail_launch<F>(c, pl, tg, nwin, nbt, pin, start_in, cnt_in, single_round || tuning().fold_flat != 0, pd, host_planes);
     phase_end();
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host_planes, c.planes.p, (size_t)pd.nplanes * sizeof(xyzz_mem_t<F>), hipMemcpyDeviceToHost, st));
+    return pd;
+}
+// The tail of a chunked MSM: fold + bit planes over the bucket sink (every bucket holds L partial sums, one per lane).
+template <class F>
+static msm_pending_t msm_tail_from_sink(lane_t& c, size_t chunk_n, int window_bits, const msm_bucket_sink_t& sink, void* host_planes) {
+    msm_pending_t pd;
+    pd.planes = host_planes;
+    const msm_plan_t pl = msm_make_plan(chunk_n, window_bits, 1, 0);
+    const uint32_t nwin = (uint32_t)pl.W, nbt = nwin * pl.nb;
+    if (nbt != sink.nbt) throw hip_failure{hipErrorInvalidValue, "msm: bucket sink does not match the plan", __LINE__};
+    const msm_tail_geom_t tg = msm_tail_geometry(pl, nwin, pd, 0);
+    c.start_a.ensure(((size_t)nbt + 1) * 4);
+    c.cnt_a.ensure(((size_t)nbt + 1) * 4);
+    hipLaunchKernelGGL(msm_sink_lists_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, c.stream, c.start_a.as<uint32_t>(), c.cnt_a.as<uint32_t>(), nbt, sink.L);
+    c.phase_begin("msm_bucket_reduce");
+    msm_tail_launch<F>(c, pl, tg, nwin, nbt, (const xyzz_mem_t<F>*)sink.acc, c.start_a.as<uint32_t>(), c.cnt_a.as<uint32_t>(), true, pd, host_planes);
+    c.phase_end();
     return pd;
 }
 // synchronous single MSM: run, wait, finish on the host into `out` (Jacobian memory image)
@@ -1179,6 +1231,19 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
     const double t_begin = host_now_ms();
     size_t nchunks = npoints < 2 * MSM_SPLIT_MIN ? 1 : (npoints + msm_chunk_pairs() - 1) / msm_chunk_pairs();
     if (nchunks == 1 && npoints >= 2 * MSM_SPLIT_MIN && (nd > 1 || npoints >= ((size_t)1 << 20))) nchunks = 2;  // 2^20: 7.2 -> 7.0 ms, 2^21: 13.0 -> 12.4
+    // chunk boundaries.  The upload is the critical path and nothing of the last chunk can start before its last byte has
+    // arrived, so the LAST chunk is cut again into 1/2, 1/4, 1/4 (tuning taper): what is exposed after the final upload is the
+    // computation of a quarter chunk plus the one tail (round 3: a whole 2^21-pair chunk, 8.4 ms of the 62 at 2^24).
+    std::vector<size_t> bound;
+    for (size_t i = 0; i <= nchunks; i++) bound.push_back(npoints * i / nchunks);
+    const bool taper = tuning().taper != 0 && nchunks >= 3 && bound[nchunks] - bound[nchunks - 1] >= MSM_SPLIT_MIN;
+    if (taper) {
+        const size_t lo = bound[nchunks - 1], len = npoints - lo;
+        bound.back() = lo + len / 2;
+        bound.push_back(lo + len / 2 + len / 4);
+        bound.push_back(npoints);
+        nchunks += 2;
+    }
     const int ndu = (int)(nchunks < (size_t)nd ? nchunks : (size_t)nd);
     std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
     std::mutex acc_mu;
@@ -1194,22 +1259,42 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
         lane_guard lg;
         lg.acquire(dev, mine.size() > 2 ? 3 : (int)mine.size());
         const int L = (int)lg.lanes.size();
-        std::vector<msm_pending_t> pend(mine.size());
+        // Several chunks on this device: they share ONE set of buckets (16-bit windows whatever the chunk length) - every chunk
+        // adds its per-bucket partial sums to a sink and the fold / bit-plane tail runs once, after the last chunk, instead of once
+        // per chunk (~1.5 ms each at 2^21 pairs x 16 windows).  tuning taper=0: every chunk runs its own tail (round 3).
+        const bool use_sink = tuning().taper != 0 && mine.size() >= 2;
+        const int chunk_c = use_sink ? 16 : 0;
+        std::vector<msm_pending_t> pend(use_sink ? 1 : mine.size());
         size_t max_cnt = 0;
         for (size_t j = 0; j < mine.size(); j++) {
-            const size_t cnt = npoints * (mine[j] + 1) / nchunks - npoints * mine[j] / nchunks;
+            const size_t cnt = bound[mine[j] + 1] - bound[mine[j]];
             max_cnt = cnt > max_cnt ? cnt : max_cnt;
         }
         const size_t aff_bytes = (max_cnt * sizeof(aff_mem_t<F>) + 255) & ~(size_t)255;
         for (int l = 0; l < L; l++) {
             lane_t& c = *lg.lanes[l];
             c.begin_call();
-            c.pin.ensure(slot * ((mine.size() + L - 1) / L));
+            c.pin.ensure(slot * (use_sink ? 1 : (mine.size() + L - 1) / L));
             c.bases_tmp.ensure(aff_bytes + max_cnt * stride);
             c.scalars_tmp.ensure(max_cnt * 32);
         }
-        auto chunk_lo = [&](size_t j) { return npoints * mine[j] / nchunks; };
-        auto chunk_cnt = [&](size_t j) { return npoints * (mine[j] + 1) / nchunks - npoints * mine[j] / nchunks; };
+        msm_bucket_sink_t sink;
+        hipEvent_t sink_ready = nullptr;
+        if (use_sink) {
+            lane_t& c0 = *lg.lanes[0];
+            const msm_plan_t pl = msm_make_plan(max_cnt, chunk_c, 1, 0);
+            sink.nbt = (uint32_t)pl.W * pl.nb;
+            sink.L = (uint32_t)L;
+            const size_t bytes = (size_t)sink.nbt * L * sizeof(xyzz_mem_t<F>);
+            c0.sink_acc.ensure(bytes);
+            sink.acc = c0.sink_acc.p;
+            HIP_TRY(hipMemsetAsync(sink.acc, 0, bytes, c0.stream));  // all-zero = the point at infinity
+            sink_ready = c0.new_event();
+            HIP_TRY(hipEventRecord(sink_ready, c0.stream));
+            for (int l = 1; l < L; l++) HIP_TRY(hipStreamWaitEvent(lg.lanes[l]->stream, sink_ready, 0));
+        }
+        auto chunk_lo = [&](size_t j) { return bound[mine[j]]; };
+        auto chunk_cnt = [&](size_t j) { return bound[mine[j] + 1] - bound[mine[j]]; };
         // upload of chunk j into its lane's staging buffers (host-blocking: the caller's memory is pageable)
         auto upload = [&](size_t j, hipStream_t st) {
             lane_t& c = *lg.lanes[j % L];
@@ -1223,8 +1308,12 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
             if (prof) c.phase_begin("msm_convert_bases");
             convert_bases<F>(c, raw, stride, chunk_cnt(j), c.bases_tmp.template as<aff_mem_t<F>>(), nullptr, true);
             if (prof) c.phase_end();
-            pend[j] = msm_run<F>(c, c.bases_tmp.template as<aff_mem_t<F>>(), c.scalars_tmp.template as<uint4>(), chunk_cnt(j), c.pin.template as<uint8_t>() + slot * (j / L),
-                                 0, nullptr, ~(size_t)0, 0, 1, 0, prof, 0);
+            msm_bucket_sink_t mine_sink = sink;
+            mine_sink.slot = (uint32_t)(j % L);
+            const msm_pending_t pd = msm_run<F>(c, c.bases_tmp.template as<aff_mem_t<F>>(), c.scalars_tmp.template as<uint4>(), chunk_cnt(j),
+                                                c.pin.template as<uint8_t>() + (use_sink ? 0 : slot * (j / L)), chunk_c, nullptr, ~(size_t)0, 0, 1, 0, prof, 0, nullptr,
+                                                use_sink ? &mine_sink : nullptr);
+            if (!use_sink) pend[j] = pd;
         };
         if (mine.size() == 1) {
             lane_t& c = *lg.lanes[0];
@@ -1234,6 +1323,15 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
             compute(0, true);
         } else {
             lane_ring_run(lg, mine.size(), upload, [&](size_t j) { compute(j, false); }, trace, t_begin);
+        }
+        if (use_sink) {  // every lane's last merge, then the one tail on lane 0
+            lane_t& c0 = *lg.lanes[0];
+            for (int l = 1; l < L; l++) {
+                hipEvent_t e = lg.lanes[l]->new_event();
+                HIP_TRY(hipEventRecord(e, lg.lanes[l]->stream));
+                HIP_TRY(hipStreamWaitEvent(c0.stream, e, 0));
+            }
+            pend[0] = msm_tail_from_sink<F>(c0, max_cnt, chunk_c, sink, c0.pin.p);
         }
         for (int l = 0; l < L; l++) {
             HIP_TRY(hipStreamSynchronize(lg.lanes[l]->alt));

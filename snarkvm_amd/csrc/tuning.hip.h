@@ -16,9 +16,8 @@
 //   lazy            1        G1 accumulation on the signed-limb arithmetic of ffl.hip.h (0: exact kernel)
 //   lazy2           1        G2 accumulation on the signed-limb Fq2 arithmetic (0: exact kernel)
 //   fused           1        wide windows: scalar read fused with the level-1 partition (0: stand-alone digit matrix)
-//   hist            2        scalar-read kernel variant (1: one 2 048-scalar tile per workgroup, round 3; 2: streaming - several tiles per
-//                            workgroup with the next tile's loads in flight, non-temporal loads; 3: streaming with plain loads)
-//   hist_tiles      0        tiles per workgroup of the streaming scalar-read kernel (0: one round of two workgroups per CU)
+//   hist            2        scalar-read kernel variant (1: 512 threads x 4 scalars, one LDS histogram - round 3; 2: 1 024 threads x 2
+//                            scalars, four private histogram copies)
 //   prefetch        2        base gather software pipeline: 0 never, 1 single-round grids, 2 always
 //   acc_lds         98304    dynamic LDS request that keeps a second accumulate workgroup off a CU (single-round grids); 0: off
 //   acc_one_wg      0        1: one accumulate workgroup per CU for multi-round grids too
@@ -49,7 +48,7 @@
 namespace sv {
 
 struct tuning_t {
-    int lazy = 1, lazy2 = 1, fused = 1, hist = 2, hist_tiles = 0, prefetch = 2;
+    int lazy = 1, lazy2 = 1, fused = 1, hist = 2, prefetch = 2;
     long acc_lds = 96 * 1024;
     int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 21, scalar_chunk_lg = 22, taper = 1, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
@@ -61,7 +60,7 @@ struct tuning_t {
         name = (decltype(name))v;          \
         return true;                       \
     }
-        SV_TUNE_KEY(lazy) SV_TUNE_KEY(lazy2) SV_TUNE_KEY(fused) SV_TUNE_KEY(hist) SV_TUNE_KEY(hist_tiles) SV_TUNE_KEY(prefetch) SV_TUNE_KEY(acc_lds)
+        SV_TUNE_KEY(lazy) SV_TUNE_KEY(lazy2) SV_TUNE_KEY(fused) SV_TUNE_KEY(hist) SV_TUNE_KEY(prefetch) SV_TUNE_KEY(acc_lds)
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)

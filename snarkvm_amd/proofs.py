@@ -19,8 +19,8 @@ the library's coalescer (csrc/runtime.hip.h::msm_coalesced) and travel as fused 
 `LockstepBatch` replays P proofs in LOCK STEP from one thread - `VarunaSNARK::prove_batch` (snark/varuna/varuna.rs:336) is a batch
 by construction: step k of all P proofs is issued together, i.e. round k's commitments of all proofs are ONE
 snarkvm_hip_msm_registered_batch_ex call (P x m instances -> fused groups), the transforms of a step are ONE
-snarkvm_hip_ntt_device_batch call per size (one kernel launch per pass for up to 48 vectors) and the pointwise passes are enqueued
-without a synchronisation each (snarkvm_hip_scope_begin / _end).
+snarkvm_hip_ntt_device_batch call per size (one kernel launch per pass for up to 48 vectors), the pointwise passes are ONE strided
+launch sequence per step (snarkvm_hip_fr_*_strided), and none of these waits for the GPU by itself (snarkvm_hip_scope_begin / _end).
 """
 import ctypes
 import threading
@@ -303,10 +303,14 @@ def replay_lockstep(ws, salts, collect=False):
         kinds = (ctypes.c_int * k)(*([kind] * k))
         timed("ntt", lambda: _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(k), ctypes.c_uint32(lg), 0, dirs, kinds)))
 
+    estride = ctypes.c_size_t(stride // 32)  # elements between the vectors of consecutive proofs
+
+    def vp(v):
+        return ctypes.c_void_p(vec(v, 0))
+
     def product(x, y, lg):  # PolyMultiplier::multiply per proof, result in x
         ntt_all((x, y), lg, 0)
-        for p in range(P):
-            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_mul_device(ctypes.c_void_p(vec(x, p)), ctypes.c_void_p(vec(x, p)), ctypes.c_void_p(vec(y, p)), ctypes.c_size_t(1 << lg))))
+        timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_vec_op_strided(2, vp(x), vp(x), vp(y), None, None, ctypes.c_size_t(1 << lg), ctypes.c_size_t(P), estride)))
         ntt_all((x,), lg, 1)
 
     def commit_round(polys):
@@ -340,10 +344,8 @@ def replay_lockstep(ws, salts, collect=False):
         torch.cuda.current_stream().synchronize()
     with scope():
         product(A, B, sh.lg_r + 1)
-        for p in range(P):
-            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_vec_op(1, ctypes.c_void_p(vec(A, p)), ctypes.c_void_p(vec(A, p)), ctypes.c_void_p(vec(D, p)), None, None, ctypes.c_size_t(2 * nR), 1)))
-            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_vanishing(ctypes.c_void_p(vec(B, p)), ctypes.c_void_p(vec(C, p)), ctypes.c_void_p(vec(A, p)),
-                                                                                   ctypes.c_size_t(2 * nR), ctypes.c_size_t(nR), 1)))
+        timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_vec_op_strided(1, vp(A), vp(A), vp(D), None, None, ctypes.c_size_t(2 * nR), ctypes.c_size_t(P), estride)))
+        timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_vanishing_strided(vp(B), vp(C), vp(A), ctypes.c_size_t(2 * nR), ctypes.c_size_t(nR), ctypes.c_size_t(P), estride)))
     commit_round([(work_ptr(B), nR, 0)])
     for m in range(3):                                                                                            # round 3
         load(A, nR, 20 + m); load(B, nR, 30 + m)
@@ -371,9 +373,8 @@ def replay_lockstep(ws, salts, collect=False):
     for i, ((s, n), q) in enumerate(zip(((13, nK), (17, nR), (19, nK)), (B, C, D))):
         load(A, n, s)
         with scope():
-            for p in range(P):
-                timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_linear(ctypes.c_void_p(vec(q, p)), ctypes.c_void_p(ws.rem[i, p].ctypes.data), ctypes.c_void_p(vec(A, p)),
-                                                                                    ctypes.c_size_t(n), ctypes.c_void_p(keys.point.ctypes.data), 1)))
+            timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_divide_by_linear_strided(vp(q), ctypes.c_void_p(ws.rem[i].ctypes.data), vp(A), ctypes.c_size_t(n),
+                                                                                        ctypes.c_void_p(keys.point.ctypes.data), ctypes.c_size_t(P), estride)))
         opens.append((work_ptr(q), n - 1, 0))
     commit_round(opens)                                                                                           # batch_open: the three witness commitments
     if keys.hg2:                                                                                                 # G2 leg: one batched call

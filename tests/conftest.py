@@ -25,7 +25,9 @@ def golden():
         srs = f.read()
     with open(os.path.join(here, "beta_h_g2.bin"), "rb") as f:
         beta_h = f.read()
-    return {"constants": consts, "varuna": varuna, "srs_g1": srs, "beta_h_g2": beta_h}
+    with open(os.path.join(here, "srs_g1_32768.bin"), "rb") as f:
+        srs_full = f.read()
+    return {"constants": consts, "varuna": varuna, "srs_g1": srs, "srs_g1_full": srs_full, "beta_h_g2": beta_h}
 
 
 @pytest.fixture(scope="session", autouse=True)

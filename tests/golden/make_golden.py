@@ -12,6 +12,8 @@ Outputs
                        algorithms/src/snark/varuna/resources/circuit_0/**
   srs_g1_1024.bin    first 1024 points of
                        parameters/src/mainnet/resources/powers-of-beta-15.usrs
+  srs_g1_32768.bin   all 32768 points of the same file (3 MB): SURVEY.md 8(d) config 1 runs on exactly these points followed by
+                       their negations (algorithms/benches/msm/variable_base.rs:29-32, msm/tests.rs:39-67)
                        (96 B each, uncompressed, canonical LE integers, flag bits
                        cleared - format per curves/src/templates/macros.rs:86-95)
   beta_h_g2.bin      the one G2 point of beta-h.usrs (192 B)
@@ -139,6 +141,10 @@ def main():
         assert flags == 0, "unexpected SW flags on an SRS point"
     with open(os.path.join(OUT, "srs_g1_1024.bin"), "wb") as f:
         f.write(bytes(pts))
+    allpts = raw[8 : 8 + 96 * count]
+    assert all((allpts[96 * i + 95] & 0xC0) == 0 for i in range(count)), "unexpected SW flags on an SRS point"
+    with open(os.path.join(OUT, "srs_g1_32768.bin"), "wb") as f:
+        f.write(allpts)
     with open(os.path.join(REF, "parameters/src/mainnet/resources/beta-h.usrs"), "rb") as f:
         raw = f.read()
     with open(os.path.join(OUT, "beta_h_g2.bin"), "wb") as f:

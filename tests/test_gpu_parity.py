@@ -533,6 +533,56 @@ def test_msm_2_20_pseudo_random_bases():
     rb.close()
 
 
+def test_msm_config1_real_srs_points_and_negations(golden):
+    """SURVEY.md 8(d) config 1 exactly as written: the 32 768 points of powers-of-beta-15.usrs followed by their negations
+    (2^16 bases, benches/msm/variable_base.rs:29-32), random scalars.  The table-less FFI symbol, registered 17 x 15-bit tables as
+    a single call, and the same MSM as one instance of a fused batch (beside a shorter instance over the same points), all
+    against the oracle's batched::msm; and P_i, -P_i with equal scalars sum to the point at infinity on every path."""
+    bases = util.srs_config1_bases(golden["srs_g1_full"])
+    n = bases.shape[0]
+    sc = synthetic.random_fr_integers(n, 0xC0F1)
+    want = oracle.g1_to_affine(oracle.g1_msm(bases, sc, oracle.MSM_BATCHED))
+    assert util.affine_equal(oracle.g1_to_affine(VariableBase.msm(bases, sc)), want)
+    rb = RegisteredBases(bases, tables=17, window_bits=15)
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc)), want)
+    m = 40000
+    res = rb.msm_batch([sc, sc[:m], sc], offsets=[0, 100, 0])
+    assert util.affine_equal(oracle.g1_to_affine(res[0:1]), want) and util.affine_equal(oracle.g1_to_affine(res[2:3]), want)
+    assert util.affine_equal(oracle.g1_to_affine(res[1:2]), oracle.g1_to_affine(oracle.g1_msm(bases[100 : 100 + m], sc[:m], oracle.MSM_BATCHED)))
+    sc2 = sc.copy()
+    sc2[n // 2 :] = sc2[: n // 2]
+    for got in (VariableBase.msm(bases, sc2), rb.msm(sc2), rb.msm_batch([sc2, sc2])[1:2]):
+        assert int(oracle.g1_to_affine(got)["infinity"][0]) == 1
+    rb.close()
+
+
+def test_msm_2_24_pseudo_random_bases():
+    """BASELINE configs[1] at its full size on UNSTRUCTURED bases: P_i = k_i G with k_i from a SplitMix64 stream (built on the
+    device in four slabs), 12 x 22-bit tables, uniform scalars: sum_i s_i P_i = (sum_i s_i k_i mod r) G.  Every other 2^24 check uses
+    the structured family (i + 1) G."""
+    import torch
+
+    n, slab = 1 << 24, 1 << 22
+    dev = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
+    ks = []
+    for j in range(n // slab):
+        b, k = _pseudo_random_bases(slab, 0xBA5E7 + j)
+        dev[j * slab * G1_AFFINE.itemsize : (j + 1) * slab * G1_AFFINE.itemsize] = torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda()
+        ks.append(k)
+        del b
+    torch.cuda.synchronize()
+    rb = RegisteredBases(device_ptr=dev.data_ptr(), npoints=n, tables=12, window_bits=22)
+    del dev
+    sc = synthetic.random_fr_integers(n, 0x5CA1C)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    got = rb.msm(device_ptr=d_sc.data_ptr(), npoints=n)
+    k = np.concatenate(ks)
+    want = oracle.g1_to_affine(oracle.g1_mul(util.g1_generator_affine(), _inner_product_mod_r(oracle.fr_op("from_bigint", sc), k)[0]))
+    assert util.affine_equal(oracle.g1_to_affine(got), want)
+    rb.close()
+
+
 def test_msm_2_22_own_plan_closed_form():
     """2^22 pairs over the plan that size gets (13 tables x 20-bit windows, three sort levels, S = 64, reduce rounds) - the
     geometry was only exercised at n = 40 000 before.  Uniform and witness-like scalars, closed form over bases (i + 1) G; and

@@ -291,6 +291,22 @@ def test_msm_variants_agree_medium(golden, n):
     assert util.affine_equal(oracle.g1_to_affine(oracle.g1_msm(aff, sc, oracle.MSM_BATCHED)), ref)
 
 
+def test_msm_config1_full_real_srs_differential(golden):
+    """SURVEY.md 8(d) config 1 as written: the 32 768 real SRS points followed by their negations (2^16 bases) - the closest thing
+    to a reference-held MSM input (the reference holds no MSM KAT, msm/tests.rs:27-67 is differential).  batched::msm ==
+    standard::msm on random scalars; and with equal scalars on P_i and -P_i the sum is the point at infinity."""
+    bases = util.srs_config1_bases(golden["srs_g1_full"])
+    n = bases.shape[0]
+    assert n == 1 << 16 and oracle.g1_is_on_curve(bases[::257]) and oracle.g1_is_on_curve(bases[-3:])
+    sc = synthetic.random_fr_integers(n, 0xC0F1)
+    a = oracle.g1_to_affine(oracle.g1_msm(bases, sc, oracle.MSM_BATCHED))
+    b = oracle.g1_to_affine(oracle.g1_msm(bases, sc, oracle.MSM_STANDARD))
+    assert util.affine_equal(a, b) and not int(a["infinity"][0])
+    sc[n // 2 :] = sc[: n // 2]
+    z = oracle.g1_to_affine(oracle.g1_msm(bases, sc, oracle.MSM_BATCHED))
+    assert int(z["infinity"][0]) == 1
+
+
 def test_msm_unequal_lengths(golden):
     """msm/tests.rs:54-67: more bases than scalars - extra bases ignored."""
     _, aff = _bases(golden, 1024)

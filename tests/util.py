@@ -94,6 +94,13 @@ def srs_points_ints(raw, n=None):
     return pts
 
 
+def srs_config1_bases(raw):
+    """every point of powers-of-beta-15.usrs followed by its negation (x, q - y) - 2 * 32768 = 2^16 bases,
+    Rust-layout affine records (benches/msm/variable_base.rs:29-32 tiles real SRS points the same way)."""
+    pts = srs_points_ints(raw)
+    return g1_affine_from_ints(pts + [(x, (pyref.Q_MOD - y) % pyref.Q_MOD) for x, y in pts])
+
+
 def affine_equal(a, b):
     """Rust `Affine == Affine` (derive(PartialEq): x, y, infinity all equal)."""
     a = np.asarray(a, dtype=G1_AFFINE).reshape(-1)
