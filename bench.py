@@ -55,6 +55,49 @@ def weighted_sum_mod_r(scalars, start=1):
     return total % R_MOD
 
 
+class SclkSampler:
+    """Samples the GPU's shader clock (amdgpu hwmon freq1_input, Hz) from a host thread while a timed region runs: the effective clock
+    the round-3 review asked for next to `mad_frac` (the arithmetic ceilings were calibrated at the 2.4 GHz peak clock; dense VALU work
+    sustains less).  Reports None when the file is not readable on this box."""
+
+    def __init__(self, dev_index=0, period_s=0.002):
+        import glob
+        import threading
+
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        self.path = self.paths[dev_index] if dev_index < len(self.paths) else (self.paths[0] if self.paths else None)
+        self.period = period_s
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                with open(self.path) as f:
+                    self.samples.append(int(f.read().strip()) / 1e6)
+            except Exception:
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._th:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th:
+            self._th.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"mean_mhz": sum(v) / len(v), "min_mhz": v[0], "max_mhz": v[-1], "median_mhz": v[len(v) // 2], "samples": len(v), "source": self.path}
+
+
 def load_profile_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -128,8 +171,17 @@ def main():
             return float(t.item())
         return dt
 
+    def gather_over_ranks(dt):
+        """every rank's own time of a region (rank order): lets a scaling run be checked rank by rank against N x the single-GPU figure"""
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            out = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return [float(x.item()) for x in out]
+        return [dt]
+
     if args.workload == "proofs64":
-        return proofs64(args, rank, world, dev_index, barrier, max_over_ranks)
+        return proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks)
 
     gen = np.zeros(1, dtype=G1_AFFINE)
     gen["x"] = G1_GEN_X
@@ -197,15 +249,20 @@ def main():
         lanes = L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n))
         rb.msm_batch(device_ptrs=[d_scalars.data_ptr()] * (lanes * args.warmup), npoints=[n] * (lanes * args.warmup), window_bits=args.window_bits)
     barrier()
-    t0 = time.perf_counter()
-    if args.no_pipeline:
-        res = np.concatenate([rb.msm(device_ptr=d.data_ptr(), npoints=n, window_bits=args.window_bits) for d in d_step])
-    else:
-        # K independent MSM instances (a batch of commitments) pipelined over the backend's HIP streams: the
-        # latency-bound tail of one instance overlaps the accumulation of the next.  Every step does the full work.
-        res = rb.msm_batch(device_ptrs=[d.data_ptr() for d in d_step], npoints=[n] * args.steps, window_bits=args.window_bits)
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    sclk = SclkSampler(dev_index)
+    with sclk:
+        t0 = time.perf_counter()
+        if args.no_pipeline:
+            res = np.concatenate([rb.msm(device_ptr=d.data_ptr(), npoints=n, window_bits=args.window_bits) for d in d_step])
+        else:
+            # K independent MSM instances (a batch of commitments) pipelined over the backend's HIP streams: the
+            # latency-bound tail of one instance overlaps the accumulation of the next.  Every step does the full work.
+            res = rb.msm_batch(device_ptrs=[d.data_ptr() for d in d_step], npoints=[n] * args.steps, window_bits=args.window_bits)
+        barrier()
+        dt_rank = time.perf_counter() - t0
+        dt = max_over_ranks(dt_rank)
+    rank_dts = gather_over_ranks(dt_rank)
+    print(f"[bench rank {rank}] {dt_rank / args.steps * 1e3:.3f} ms per step on this rank", file=sys.stderr)
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = world * n * args.steps / dt
     want_affine = check_results(res, scalars, "timed_msm", shifts)  # outside the timed region
@@ -336,7 +393,7 @@ def main():
             firsts.append(time.perf_counter() - t0)
             first = min(firsts)
             # the EXTENSION a caller opts into (rust/: resident::Bases): the SRS registered once with precomputed tables, host scalars per call
-            tb, bits = (12, 22) if lg >= 23 else (13, 20) if lg >= 21 else (16, 0) if lg >= 18 else (17, 15)
+            tb, bits = (12, 22) if lg >= 24 else (13, 20) if lg >= 21 else (16, 0) if lg >= 18 else (17, 15)
             rbx = rb if (lg == args.lg_msm and tb == args.tables) else RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=m, tables=tb, window_bits=bits)
             rbx.msm(hs)
             t0 = time.perf_counter()
@@ -462,7 +519,12 @@ def main():
                 "peak_mads_per_s": ceil.get("v_mad_u64_u32_per_s"),
                 "mad_frac": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)) / (acc_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"] if ceil.get("v_mad_u64_u32_per_s") else None,
                 "source": "profiles/r03_alu_ceilings.json (tools/ecbench.hip k_lazy at the kernel's occupancy, tools/microbench.hip: wall-clock, whole chip)",
+                # the shader clock sampled by a host thread during the timed MSM steps (amdgpu hwmon): the ceilings above assume the 2.4 GHz
+                # peak clock, so mad_frac against what the chip could issue at the clock it actually sustained is mad_frac * 2400 / mean_mhz
+                "sclk_during_timed_steps": sclk.summary(),
             }
+            if alu["sclk_during_timed_steps"] and alu.get("mad_frac"):
+                alu["mad_frac_at_sustained_clock"] = alu["mad_frac"] * 2400.0 / alu["sclk_during_timed_steps"]["mean_mhz"]
         alu_ntt = None
         if ceil and ntt_kernel_ms and ceil.get("v_mad_u64_u32_per_s"):
             # Fr products per element: lg / 2 butterfly products + one closing product per non-last pass + the final reduction (~half)
@@ -483,6 +545,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "rank_ms_per_step": [d / args.steps * 1e3 for d in rank_dts],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,  # the reference publishes no number for this metric
@@ -558,7 +621,7 @@ def main():
         dist.destroy_process_group()
 
 
-def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
+def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks):
     """BASELINE.json configs[4]: a batch of Varuna-proof-shaped call lists, sharded over the ranks (64 / N proofs each).  Inside a
     rank two ways of issuing them are timed, one after the other, on the same proofs:
       lockstep   `VarunaSNARK::prove_batch` is a batch by construction (varuna.rs:336): round k of all proofs of a group is ONE
@@ -570,7 +633,7 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
     import torch
     import torch.distributed as dist
 
-    from snarkvm_amd import proofs
+    from snarkvm_amd import _lib, proofs
 
     shape = proofs.ProofShape()
     keys = proofs.ProverKeys(shape)
@@ -585,7 +648,10 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
     t0 = time.perf_counter()
     _, got_lock = lock.run(mine, collect=True)
     barrier()
-    dt_lock = max_over_ranks(time.perf_counter() - t0)
+    dt_lock_rank = time.perf_counter() - t0
+    dt_lock = max_over_ranks(dt_lock_rank)
+    rank_dts = gather_over_ranks(dt_lock_rank)
+    print(f"[bench rank {rank}] lock-step: {len(mine)} proofs in {dt_lock_rank * 1e3:.1f} ms on this rank", file=sys.stderr)
     t_lock = dict(lock.workspaces[0].times)
     del lock
     torch.cuda.empty_cache()
@@ -595,10 +661,14 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
     for ws in batch.workspaces:
         ws.times = {k: 0.0 for k in ws.times}
     barrier()
+    L = _lib.lib()
+    L.snarkvm_hip_coalescer_stats(None, 1)
     t0 = time.perf_counter()
     _, got_thr = batch.run(mine, collect=True)
     barrier()
     dt_thr = max_over_ranks(time.perf_counter() - t0)
+    co = (ctypes.c_uint64 * 4)()
+    L.snarkvm_hip_coalescer_stats(co, 0)
     t_thr = {k: sum(ws.times[k] for ws in batch.workspaces) for k in batch.workspaces[0].times}
     # ---- checks (outside the timed regions)
     norm_lock = [proofs.normalize_results(r) for r in got_lock]
@@ -655,9 +725,11 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks):
             "g2_pairs_per_s_inside_msm_calls": (len(mine) * (1 << shape.lg_g2) / t_lock["g2"]) if t_lock.get("g2") else None,
             "concurrent_callers": {"value": args.proofs / dt_thr, "unit": "proofs/s", "ms_per_proof": dt_thr / args.proofs * 1e3,
                                    "caller_threads_per_rank": len(batch.workspaces), "g1_pairs_per_s": args.proofs * shape.pairs() / dt_thr,
+                                   "coalescer": {"batches": int(co[0]), "msm_instances": int(co[1]), "largest_batch": int(co[2]), "single_instance_batches": int(co[3]),
+                                                 "instances_per_batch": (co[1] / co[0]) if co[0] else None},
                                    "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_thr.items()},
                                    "what": "one proof per caller thread at a time (the reference's rayon fan-out); proof-sized MSMs of concurrent callers fused by the in-library coalescer"},
-            "rank_ms_per_step": dt_lock / max(1, len(mine)) * 1e3,
+            "rank_ms_per_proof": [d / max(1, len(mine)) * 1e3 for d in rank_dts],
             "checks": checks,
         }))
     keys.close()

@@ -67,7 +67,7 @@ RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoint
  * call and nothing about them is retained after return.
  * Opt-in extension (off unless SNARKVM_HIP_BASE_CACHE=1/2/4/8/16 is set in the environment): a host base range passed a SECOND
  * time with the same address and length is kept in HBM (converted, with precomputed tables - 17 x 15-bit below 2^18 points,
- * 16 x 16, 13 x 20 from 2^21, 12 x 22 from 2^23 - on every device) and later calls whose bases are a slice of it skip upload
+ * 16 x 16, 13 x 20 from 2^21, 12 x 22 from 2^24 - on every device) and later calls whose bases are a slice of it skip upload
  * and conversion - the reference's callers always pass slices of one long-lived `powers_of_beta_g` vector
  * (kzg10/mod.rs:117-119).  By setting the variable the caller promises that such vectors are immutable while the process
  * uses them (a hit is verified against raw copies of every 64th point of the slice, which cannot catch every mutation);
@@ -288,6 +288,10 @@ int snarkvm_hip_get_phase_count(void);
 const char *snarkvm_hip_get_phase_name(int i);
 double snarkvm_hip_get_phase_ms(int i);
 
+/* How the in-library coalescer grouped concurrent callers of proof-sized G1 MSMs so far: out[4] = {batches dispatched, tickets
+ * (MSM instances) in them, largest batch, batches of a single ticket}; reset != 0 clears the counters. */
+void snarkvm_hip_coalescer_stats(uint64_t *out, int reset);
+
 /* Block until all queued work of every device in use has finished. */
 RustError snarkvm_hip_synchronize(void);
 
@@ -315,6 +319,15 @@ int snarkvm_hip_selftest_g1_finish(const void *planes_projective, const int32_t 
  * chained mixed additions (doublings, cancellations and restarts from infinity included) compared coordinate by coordinate,
  * then the field routines at the edges of their operand ranges.  0 = identical; > 0: first differing step; < 0: field case. */
 int snarkvm_hip_selftest_fq_lazy(uint64_t seed, int iters);
+/* The lazy Fq2 arithmetic of the G2 accumulate kernel (csrc/ffl2.hip.h) against the exact arithmetic, on the host: `iters` chained
+ * mixed additions of +- points[k] (npoints >= 2 Rust G2Affine records on the curve, 200-byte stride), doublings, cancellations
+ * and restarts from infinity included, every coordinate compared after every step; products, squares and the raw partial-sum image
+ * on the way.  0 = identical; > 0: first differing step; < 0: a field / conversion case. */
+int snarkvm_hip_selftest_fq2_lazy(const void *points, size_t npoints, uint64_t seed, int iters);
+/* The signed-limb butterfly arithmetic of the NTT passes (csrc/frs.hip.h) against the exact arithmetic, on the host: passes of up
+ * to nine butterfly stages without a canonical form in between, the closing product, the bare reduction and the folded table
+ * form.  0 = identical; > 0: first differing butterfly; < 0: a closing-step case. */
+int snarkvm_hip_selftest_fr_signed(uint64_t seed, int iters);
 /* Same field operations executed by a GPU kernel (one thread per element). */
 RustError snarkvm_hip_devtest_field(int field, int op, const void *a, const void *b, void *out, size_t n);
 

@@ -25,8 +25,8 @@ SYMBOLS = [
     "snarkvm_hip_register_bases_g2", "snarkvm_hip_free_bases_g2", "snarkvm_hip_msm_g2_registered", "snarkvm_hip_msm_g2_registered_batch",
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
-    "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize",
-    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_devtest_field",
+    "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize", "snarkvm_hip_coalescer_stats",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_devtest_field",
 ]
 
 
@@ -78,6 +78,8 @@ def lib():
         L.snarkvm_hip_num_devices.restype = ctypes.c_int
         L.snarkvm_hip_selftest_g1_finish.restype = ctypes.c_int
         L.snarkvm_hip_selftest_fq_lazy.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_fr_signed.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_fq2_lazy.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_count.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_name.restype = ctypes.c_char_p
         L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double
@@ -87,6 +89,7 @@ def lib():
         L.snarkvm_hip_free_bases.restype = None
         L.snarkvm_hip_free_bases_g2.restype = None
         L.snarkvm_hip_set_profiling.restype = None
+        L.snarkvm_hip_coalescer_stats.restype = None
         _libc = ctypes.CDLL(None)
         _libc.free.argtypes = [ctypes.c_void_p]
         _lib = L

@@ -59,6 +59,14 @@ double snarkvm_hip_get_phase_ms(int i) {
     return (i >= 0 && i < (int)g_rt.last_phases.size()) ? g_rt.last_phases[i].second : 0.0;
 }
 
+// coalescer statistics of THIS translation unit's callers (the G1 entry points): out[4] = {batches dispatched, tickets in them, largest
+// batch, single-ticket batches}; reset != 0 clears them
+void snarkvm_hip_coalescer_stats(uint64_t* out, int reset) {
+    for (int i = 0; i < 4; i++) {
+        if (out) out[i] = g_co_stats[i].load();
+        if (reset) g_co_stats[i].store(0);
+    }
+}
 RustError snarkvm_hip_synchronize(void) {
     API_TRY
     g_rt.configure();
@@ -448,11 +456,11 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
             // the remembered range (every sample of it was just verified above); a sub-slice of a range that is not registered
             // yet takes the stateless path.
             if (g_base_cache[i].failed || off != 0 || npoints != g_base_cache[i].n) return nullptr;
-            // table geometry by size, as measured (profiles/r02_size_sweep.md): 12 x 22-bit windows from 2^23 points, 13 x 20-bit from
+            // table geometry by size, as measured (profiles/r02_size_sweep.md, r04_geometry_23.md): 12 x 22-bit windows from 2^24 points, 13 x 20-bit from
             // 2^21, 17 x 15-bit below 2^18 (half the buckets of 16 x 16: the whole fold is one round of 256 workgroups), else the
             // configured count of 256 / tables-bit tables
             int tables = base_cache_tables(), bits = 0;
-            if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 23)) tables = 12, bits = 22;
+            if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 24)) tables = 12, bits = 22;  // 2^23: 13 x 20 is 4 % faster (profiles/r04_geometry_23.md)
             else if (tables == 16 && g_base_cache[i].n >= ((size_t)1 << 21)) tables = 13, bits = 20;
             else if (tables == 16 && g_base_cache[i].n < ((size_t)1 << 18)) tables = 17, bits = 15;
             const size_t need = (size_t)tables * g_base_cache[i].n * sizeof(g1_aff_mem_t);

@@ -532,4 +532,77 @@ RustError snarkvm_hip_g1_group_ntt(void* inout_projective, uint32_t lg, int inve
     API_END
 }
 
+// ---- test hook: the signed-limb butterfly arithmetic of frs.hip.h against the exact arithmetic, on the host --------------------
+// Passes of up to nine butterfly stages over a population of 16 values (u, v) -> (u + v, (u - v) w) with random canonical twiddles
+// (w = 1 takes the product-free branch), no canonical form in between - exactly what ntt_pass_kernel_v2<., ntt_arith_s> does
+// between a pass' loads and its closing product -, every value compared with the exact arithmetic after every stage; then the
+// closing product, the bare reduction, and operands with extreme limbs.  0 = identical; > 0: first failing step; < 0: edge case.
+int snarkvm_hip_selftest_fr_signed(uint64_t seed, int iters) {
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto rnd = [&]() {  // a canonical residue
+        fr_t a;
+        for (int i = 0; i < 9; i++) a.v[i] = (uint32_t)(next() & LIMB_MASK);
+        a.v[8] &= 0x000fffffu;  // < 2^252 < r
+        return a;
+    };
+    const int NV = 16;
+    fr_t ex[NV];
+    frs_t sg[NV];
+    int step = 0;
+    for (int it = 0; it < iters; it++) {
+        for (int i = 0; i < NV; i++) {
+            ex[i] = rnd();
+            if ((it & 7) == 7)
+                for (int l = 0; l < 8; l++) ex[i].v[l] = (i & 1) ? LIMB_MASK : 0u;  // extreme limbs
+            if (!(ex[i].v[8] < FrP::MOD[8])) ex[i].v[8] = FrP::MOD[8] - 1;
+            sg[i] = frs_t::from_canonical(ex[i]);
+        }
+        const int stages = 1 + (int)(next() % 9);
+        for (int s = 0; s < stages; s++) {
+            const int dist = 1 << (s % 4);
+            for (int i = 0; i < NV; i++) {
+                if (i & dist) continue;
+                const int j = i | dist;
+                const bool unit = (next() & 3) == 0;
+                const fr_t w = unit ? fr_t::one() : rnd();  // internal form (w * 2^261)
+                const fr_t e_sum = ex[i] + ex[j], e_dif = (ex[i] - ex[j]) * w;
+                const frs_t s_sum = frs_t::add_norm(sg[i], sg[j]);
+                frs_t s_dif;
+                if (unit) {
+                    frs_t neg;
+                    for (int l = 0; l < 9; l++) neg.v[l] = -sg[j].v[l];
+                    s_dif = frs_t::add_norm(sg[i], neg);
+                } else {
+                    s_dif = frs_t::mul(frs_t::sub_raw(sg[i], sg[j]), frs_t::twiddle_form(w));
+                }
+                ex[i] = e_sum, ex[j] = e_dif, sg[i] = s_sum, sg[j] = s_dif;
+                step++;
+                // (a value that took the sum branch s times is up to 2^s r wide: it is compared after a product by one, the way a pass
+                // ends - to_canonical alone covers (-3 r, 2 r))
+                const fr_t one_s = fr_t::from_table(FrS::C290);
+                if (frs_t::mul(sg[i], one_s).to_canonical() != ex[i] || frs_t::mul(sg[j], one_s).to_canonical() != ex[j]) return step;
+            }
+        }
+        // closing product and bare reduction
+        const fr_t w = rnd();
+        for (int i = 0; i < NV; i++) {
+            step++;
+            if (frs_t::mul(sg[i], frs_t::twiddle_form(w)).to_canonical() != ex[i] * w) return step;
+            fr_t one_plain = fr_t::zero();
+            one_plain.v[0] = 1;
+            if (frs_t::reduce_only(sg[i]).to_canonical() != frs_t::mul(sg[i], one_plain).to_canonical()) return -step;
+            // the folded table form: (x * t 2^580 / 2^290) / 2^290 = x t
+            const fr_t folded = w * fr_t::from_table(FrS::C580);
+            if (frs_t::reduce_only(frs_t::mul(sg[i], folded)).to_canonical() != ex[i] * w) return -(1000000 + step);
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

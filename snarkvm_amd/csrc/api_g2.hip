@@ -53,6 +53,7 @@ RustError snarkvm_hip_register_bases_g2(snarkvm_hip_bases_g2_t** handle, const v
                 HIP_TRY(hipMemcpyAsync(c.bases_tmp.p, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, c.stream));
                 convert_bases<fq2_t>(c, c.bases_tmp.as<uint8_t>(), ffi_affine_sz, npoints, h->d[dev]);
                 precompute_tables_run<fq2_t>(c, h->d[dev], npoints, tables, h->table_bits);
+                bases_to_lazy_form(c, h->d[dev], (size_t)tables * npoints);  // last: the tables are derived from one another in the exact form
                 HIP_TRY(hipStreamSynchronize(c.stream));
             });
         } catch (...) {
@@ -180,6 +181,73 @@ RustError snarkvm_hip_g2_deserialize_compressed(void* out_affine, const void* by
 RustError snarkvm_hip_g2_serialize(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz) { return g2_serialize_impl(out_bytes, affine, n, ffi_affine_sz, 0); }
 RustError snarkvm_hip_g2_serialize_compressed(void* out_bytes, const void* affine, size_t n, size_t ffi_affine_sz) {
     return g2_serialize_impl(out_bytes, affine, n, ffi_affine_sz, 1);
+}
+
+// ---- test hook: the lazy Fq2 arithmetic of the G2 accumulate kernel (ffl2.hip.h) against the exact arithmetic, on the host ----
+// `points`: npoints (>= 2) Rust G2Affine records (200-byte stride) on the curve.  A chain of `iters` mixed additions of +- points[k]
+// (the same point again -> doubling, its negative -> cancellation, restarts from infinity), every coordinate component of the
+// accumulator compared with xyzz_t<fq2_t>::add_affine after every step; then products and squares of tight operands taken from the
+// chain against fq2_t's.  0 = identical; > 0: first differing step; < 0: field case.
+int snarkvm_hip_selftest_fq2_lazy(const void* points, size_t npoints, uint64_t seed, int iters) {
+#ifdef SV_NO_G2
+    (void)points, (void)npoints, (void)seed, (void)iters;
+    return -1;
+#else
+    if (!points || npoints < 2) return -2;
+    std::vector<aff_t<fq2_t>> pool;
+    for (size_t i = 0; i < npoints; i++) {
+        const uint32_t* src = (const uint32_t*)((const uint8_t*)points + 200 * i);
+        pool.push_back({fq2_t::from_raw_words(src), fq2_t::from_raw_words(src + 24)});
+    }
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto lazy_of = [](const fq2_t& v) { return fq2l_t{fql_canonical_from_exact(v.c0), fql_canonical_from_exact(v.c1)}; };
+    auto same = [](const fq2l_t& l, const fq2_t& e) { return l.c0.to_exact() == e.c0 && l.c1.to_exact() == e.c1; };
+    xyzz_t<fq2_t> exact = xyzz_t<fq2_t>::inf();
+    xyzz_lazy2_t lazy = xyzz_lazy2_t::infinity();
+    int prev = -1;
+    bool prev_neg = false;
+    for (int it = 0; it < iters; it++) {
+        const uint64_t r = next();
+        int k = (int)(r % npoints);
+        bool neg = ((r >> 8) & 1) != 0;
+        const int mode = (int)((r >> 16) % 16);
+        if (mode == 0 && prev >= 0) k = prev, neg = prev_neg;
+        if (mode == 1 && prev >= 0) k = prev, neg = !prev_neg;
+        if (mode == 2) {
+            exact = xyzz_t<fq2_t>::inf();
+            lazy = xyzz_lazy2_t::infinity();
+        }
+        prev = k;
+        prev_neg = neg;
+        const aff_t<fq2_t> p = pool[k];
+        exact.add_affine(p, neg);
+        const fq2l_t px = lazy_of(p.x), py = lazy_of(p.y);
+        if (!lazy.madd(px, py, neg)) {
+            xyzz_t<fq2_t> e = lazy.to_exact();
+            e.add_affine(p, neg);
+            lazy = xyzz_lazy2_t::from_exact(e);
+        }
+        if (lazy.inf != exact.is_inf()) return it + 1;
+        if (!lazy.inf && !(same(lazy.x, exact.x) && same(lazy.y, exact.y) && same(lazy.zz, exact.zz) && same(lazy.zzz, exact.zzz))) return it + 1;
+        if (!lazy.inf && (it & 7) == 0) {  // products / squares of the accumulator's own (tight, mixed-sign) components
+            if (!same(fq2l::mul(lazy.zz, lazy.zzz), exact.zz * exact.zzz)) return -(4 * it + 1);
+            if (!same(fq2l::sqr(lazy.zzz), exact.zzz.sqr())) return -(4 * it + 2);
+            if (!same(fq2l::mul(lazy.x, lazy.zz), exact.x * exact.zz)) return -(4 * it + 3);
+            // the raw memory image and the dense conversion
+            alignas(16) g2_lazy_partial_t raw;
+            lazy.store_raw(&raw);
+            const xyzz_t<fq2_t> back = xyzz_lazy2_t::exact_from_raw(&raw);
+            if (!(back.x == exact.x && back.y == exact.y && back.zz == exact.zz && back.zzz == exact.zzz)) return -(4 * it + 4);
+        }
+    }
+    return 0;
+#endif
 }
 
 }  // extern "C"

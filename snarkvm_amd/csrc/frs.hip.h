@@ -38,16 +38,18 @@ struct FrS {
     static constexpr uint32_t C580[9] = {0x11835831u, 0x153c0998u, 0x1220f31eu, 0x1cf40af6u, 0x000bb5fau, 0x1de4b39au, 0x1bd29079u, 0x0137a8ffu, 0x000e9a98u};
 };
 
+// The compiler canonicalises the sign extension of a value it has proven non-negative (a masked limb) into a zero extension and then
+// fails to match "zero-extended x sign-extended" products to ONE v_mad_i64_i32 (ffl.hip.h hides the range with empty asm statements;
+// here they sit inside the pass kernel's loops and keep them from unrolling early enough: the four elements of a radix-4 group end up
+// in scratch memory).  A butterfly product is safe as it stands - its left operand is a raw difference, of unknown sign - ; the one
+// place where a normalised value meets a table word is the closing product of a pass, and there the value goes through hide_range():
+// an exclusive-or with a zero the compiler cannot see (a device variable nobody writes).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define SV_OPAQUE_S(x) asm("" : "+v"(x))  // hides the range of a masked limb from the compiler (see ffl.hip.h: zero- vs sign-extension)
+static __device__ int32_t sv_opaque_zero;
+#define SV_OPAQUE_ZERO() sv_opaque_zero
 #else
-#define SV_OPAQUE_S(x) ((void)0)
+#define SV_OPAQUE_ZERO() 0
 #endif
-#define SV_OPAQUE_9(a)                                                                                       \
-    do {                                                                                                     \
-        SV_OPAQUE_S((a)[0]); SV_OPAQUE_S((a)[1]); SV_OPAQUE_S((a)[2]); SV_OPAQUE_S((a)[3]); SV_OPAQUE_S((a)[4]); \
-        SV_OPAQUE_S((a)[5]); SV_OPAQUE_S((a)[6]); SV_OPAQUE_S((a)[7]); SV_OPAQUE_S((a)[8]);                    \
-    } while (0)
 
 struct frs_t {
     static constexpr int N = 9;
@@ -59,7 +61,6 @@ struct frs_t {
         frs_t r;
 #pragma unroll
         for (int i = 0; i < N; i++) r.v[i] = (int32_t)a.v[i];
-        SV_OPAQUE_9(r.v);
         return r;
     }
     // u + v, carry-normalised.  Operands normalised (or sums of few normalised values: |limbs| < 2^30); same value out.
@@ -73,7 +74,6 @@ struct frs_t {
             c = x >> 29;
         }
         r.v[N - 1] = a.v[N - 1] + b.v[N - 1] + c;
-        SV_OPAQUE_9(r.v);
         return r;
     }
     // u - v limb by limb: no carries.  For normalised operands the limbs lie in (-2^29, 2^29) (top limb: the operands' range)
@@ -108,7 +108,6 @@ struct frs_t {
             }
             acc >>= 29;  // arithmetic
         }
-        SV_OPAQUE_9(r.v);
         return r;
     }
     // x / 2^290 alone (the last pass when the previous pass' closing table carried the missing 2^290): half the multiply-adds
@@ -131,7 +130,14 @@ struct frs_t {
             }
             acc >>= 29;
         }
-        SV_OPAQUE_9(r.v);
+        return r;
+    }
+    // the same value with its limb ranges hidden from the compiler (see SV_OPAQUE_ZERO)
+    SV_HD frs_t hide_range() const {
+        const int32_t z = SV_OPAQUE_ZERO();
+        frs_t r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = v[i] ^ z;
         return r;
     }
     // leaving the lazy domain: the canonical representative of a normalised value within (-3 r, 2 r)

@@ -25,6 +25,7 @@
 
 #include "ec.hip.h"
 #include "ffl.hip.h"
+#include "ffl2.hip.h"
 #include "tuning.hip.h"
 
 namespace sv {
@@ -268,6 +269,28 @@ SV_HD void store_base_slot<fq_t>(aff_mem_t<fq_t>* slot, const uint32_t* xw, cons
         a.y = fq_t::from_raw_words(yw);
     }
     store_aff<fq_t>(slot, a);
+}
+template <>
+SV_HD void store_base_slot<fq2_t>(aff_mem_t<fq2_t>* slot, const uint32_t* xw, const uint32_t* yw, bool inf, int form406) {
+    if (form406) {
+        const fq_t c = fq_t::from_table(FqLConv::C399);  // memory form x 2^384 -> x 2^406, per component
+        g2_lazy_slot_t::store(slot, {fq_t::unpack(xw) * c, fq_t::unpack(xw + 12) * c}, {fq_t::unpack(yw) * c, fq_t::unpack(yw + 12) * c}, inf);
+        return;
+    }
+    aff_t<fq2_t> a = aff_t<fq2_t>::inf();
+    if (!inf) {
+        a.x = fq2_t::from_raw_words(xw);
+        a.y = fq2_t::from_raw_words(yw);
+    }
+    store_aff<fq2_t>(slot, a);
+}
+// in-place: exact slot -> g2_lazy_slot_t (the last step of a G2 registration)
+static __global__ void g2_bases_to_form406_kernel(aff_mem_t<fq2_t>* slots, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fq_t c = fq_t::from_table(FqLConv::C406);
+    const aff_t<fq2_t> a = load_aff<fq2_t>(&slots[i]);
+    g2_lazy_slot_t::store(&slots[i], {a.x.c0 * c, a.x.c1 * c}, {a.y.c0 * c, a.y.c1 * c}, a.is_inf());
 }
 // in-place: exact slot -> g1_lazy_slot_t (the last step of a G1 registration, after the tables have been derived from one another)
 static __global__ void g1_bases_to_form406_kernel(g1_aff_mem_t* slots, size_t n) {

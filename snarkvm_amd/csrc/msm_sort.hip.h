@@ -17,6 +17,7 @@
 // histograms except the order inside a (tile, bin) run (LDS cursor order), which does not change any bucket's content.
 #pragma once
 #include "ffl.hip.h"
+#include "ffl2.hip.h"
 #include "msm.hip.h"
 
 namespace sv {
@@ -938,6 +939,83 @@ __global__ void __launch_bounds__(256, 1) msm_accumulate_lazy_kernel(const g1_af
             acc = tmp;
         }
     }
+}
+
+// ---- G2: the same kernel on the lazily reduced Fq2 arithmetic of ffl2.hip.h (round 4).  Base slots: g2_lazy_slot_t (canonical residues
+// of the four coordinate components times 2^406, unpacked); partial sums leave raw (104 limbs) and g2_partials_to_exact_kernel converts
+// them for the tail kernels; exceptional additions are resolved out of line on the exact arithmetic.
+static __global__ void __launch_bounds__(256) g2_partials_to_exact_kernel(const g2_lazy_partial_t* __restrict__ raw, xyzz_mem_t<fq2_t>* __restrict__ partial,
+                                                                   const uint32_t* __restrict__ start, uint32_t nbt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= start[nbt]) return;
+    store_xyzz<fq2_t>(&partial[i], xyzz_lazy2_t::exact_from_raw(&raw[i]));
+}
+// (inlined: an out-of-line call from this 400-register kernel never returns on gfx950 / ROCm 7.2 - tools/exp/g2lazy_dev.hip reproduces it in
+// 60 lines, with the call the second addition of a doubled point hangs, inlined it matches the host chain; the G1 kernel's 248 registers
+// keep its call working.  The cold code costs the hot loop nothing measurable: the two blocks of the addition keep their instruction counts.)
+static __device__ __forceinline__ void lazy2_exceptional_add(xyzz_lazy2_t* acc, const fq2l_t* px, const fq2l_t* py, bool neg) {
+    xyzz_t<fq2_t> ex = acc->to_exact();
+    const fq_t c348 = fq_t::from_table(FqLConv::C348);
+    fq_t t[4];
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        t[0].v[i] = (uint32_t)px->c0.v[i], t[1].v[i] = (uint32_t)px->c1.v[i];
+        t[2].v[i] = (uint32_t)py->c0.v[i], t[3].v[i] = (uint32_t)py->c1.v[i];
+    }
+    ex.add_affine({{t[0] * c348, t[1] * c348}, {t[2] * c348, t[3] * c348}}, neg);
+    *acc = xyzz_lazy2_t::from_exact(ex);
+}
+template <bool PREFETCH>
+__global__ void __launch_bounds__(256, 1) msm_accumulate_lazy2_kernel(const aff_mem_t<fq2_t>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                               const uint32_t* __restrict__ boff, const uint32_t* __restrict__ start,
+                                                               g2_lazy_partial_t* __restrict__ partial, uint32_t nbt, uint32_t S, uint32_t debug_idx_mask) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = boff[nbt];
+    const uint64_t lo64 = (uint64_t)t * S;
+    if (lo64 >= total) return;
+    const uint32_t lo = (uint32_t)lo64;
+    const uint32_t hi = (total - lo < S) ? total : lo + S;
+    uint32_t k = find_bucket(boff, nbt, lo);
+    uint32_t kend = boff[k + 1];
+    uint32_t kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];  // bucket bookkeeping one bucket ahead (see msm_accumulate_lazy_kernel)
+    uint32_t start_k = start[k];
+    uint32_t part_off = t - boff[k] / S;
+    xyzz_lazy2_t acc = xyzz_lazy2_t::infinity();
+    auto slot_of = [&](uint32_t e) -> const g2_lazy_slot_t* { return (const g2_lazy_slot_t*)&bases[(e & 0x7fffffffu) & debug_idx_mask]; };
+    uint32_t e_cur = sorted[lo];
+    uint32_t e_n1 = lo + 1 < hi ? sorted[lo + 1] : 0u;
+    for (uint32_t pos = lo;; pos++) {
+        const bool end = pos >= hi;
+        if (end || pos >= kend) {
+            acc.store_raw(&partial[start_k + part_off]);
+            if (end) break;
+            part_off = 0;
+            acc.inf = true;
+            k++;
+            kend = kend2;
+            while (pos >= kend) {
+                k++;
+                kend = boff[k + 1];
+            }
+            kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+            start_k = start[k];
+        }
+        const uint32_t e = e_cur;
+        const g2_lazy_slot_t* sp = slot_of(e);
+        e_cur = e_n1;
+        if (pos + 2 < hi) e_n1 = sorted[pos + 2];
+        if (sp->w[52]) continue;  // the point at infinity
+        const bool neg = (e >> 31) != 0;
+        fq2l_t px, py;
+        sp->coords(px, py);
+        if (!acc.madd(px, py, neg)) {
+            xyzz_lazy2_t tmp = acc;
+            const fq2l_t tx = px, ty = py;
+            lazy2_exceptional_add(&tmp, &tx, &ty, neg);
+            acc = tmp;
+        }
+    }
+    (void)PREFETCH;  // the 52-limb slot is read at its use: a second resident slot would not fit the register file
 }
 
 }  // namespace sv

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "ff.hip.h"
+#include "frs.hip.h"
 #include "tuning.hip.h"
 
 namespace sv {
@@ -133,15 +134,17 @@ struct ntt_lds_t {
     uint32_t* tw;    // 9 planes of NL = 2^(a-1) limbs: the powers of this pass' own root w_(2^a) (internal form)
     int NL;
     int E;
-    __device__ __forceinline__ fr_t get(int e) const {
-        fr_t x;
+    template <class E>  // fr_t (unsigned limbs) or frs_t (signed limbs): nine 32-bit words either way
+    __device__ __forceinline__ E get(int e) const {
+        E x;
 #pragma unroll
-        for (int l = 0; l < 9; l++) x.v[l] = data[e * 9 + l];
+        for (int l = 0; l < 9; l++) x.v[l] = static_cast<typename std::remove_reference<decltype(x.v[0])>::type>(data[e * 9 + l]);
         return x;
     }
-    __device__ __forceinline__ void put(int e, const fr_t& x) const {
+    template <class E>
+    __device__ __forceinline__ void put(int e, const E& x) const {
 #pragma unroll
-        for (int l = 0; l < 9; l++) data[e * 9 + l] = x.v[l];
+        for (int l = 0; l < 9; l++) data[e * 9 + l] = (uint32_t)x.v[l];
     }
     __device__ __forceinline__ fr_t twiddle(int idx) const {
         fr_t x;
@@ -162,6 +165,52 @@ __device__ __forceinline__ void lazy_butterfly(fr_t& u, fr_t& v, int s, int tw_i
     v = dif;
 }
 
+// The arithmetic of a pass as a policy: `ntt_arith_u` = the unsigned lazy routines of round 3 (tuning ntt_signed=0), `ntt_arith_s` =
+// the signed limbs of frs.hip.h (default).  tw(): a word of the ff.hip.h twiddle tables (w * 2^261) in the form mul() wants.
+struct ntt_arith_u {
+    typedef fr_t elem;
+    __device__ __forceinline__ static elem from_canonical(const fr_t& x) { return x; }
+    __device__ __forceinline__ static void butterfly(elem& u, elem& v, int s, int tw_idx, const ntt_lds_t& L) { lazy_butterfly(u, v, s, tw_idx, L); }
+    __device__ __forceinline__ static fr_t tw(const fr_t& w_int) { return w_int; }
+    __device__ __forceinline__ static fr_t one() { return fr_t::one(); }
+    __device__ __forceinline__ static elem mul(const elem& x, const fr_t& w) { return x.mul_lazy(w); }
+    __device__ __forceinline__ static elem reduce_only(const elem& x) { return x.mont_reduce_lazy(); }
+    // a radix-2^9 pass ends with values < 2^9 r = 1.17 * 2^261: the closing product is < 2.17 r, one more conditional subtraction
+    __device__ __forceinline__ static fr_t finish(const elem& y, int a) {
+        fr_t z = y.reduce_lazy();
+        if (a > 8) z = z.reduce_lazy();
+        return z;
+    }
+};
+struct ntt_arith_s {
+    typedef frs_t elem;
+    __device__ __forceinline__ static elem from_canonical(const fr_t& x) { return frs_t::from_canonical(x); }
+    // (u, v) -> (u + v, (u - v) w): the sum carry-normalised, the difference raw into the product (frs.hip.h); w = 1: the difference
+    // is only normalised
+    __device__ __forceinline__ static void butterfly(elem& u, elem& v, int s, int tw_idx, const ntt_lds_t& L) {
+        (void)s;
+        const elem sum = frs_t::add_norm(u, v);
+        if (tw_idx != 0) {
+            v = frs_t::mul(frs_t::sub_raw(u, v), L.twiddle(tw_idx));
+        } else {
+            elem neg;
+#pragma unroll
+            for (int i = 0; i < 9; i++) neg.v[i] = -v.v[i];
+            v = frs_t::add_norm(u, neg);
+        }
+        u = sum;
+    }
+    __device__ __forceinline__ static fr_t tw(const fr_t& w_int) { return frs_t::twiddle_form(w_int); }
+    __device__ __forceinline__ static fr_t one() { return fr_t::from_table(FrS::C290); }
+    // the closing product of a pass: a normalised value against a table word (frs.hip.h: hide_range)
+    __device__ __forceinline__ static elem mul(const elem& x, const fr_t& w) { return frs_t::mul(x.hide_range(), w); }
+    __device__ __forceinline__ static elem reduce_only(const elem& x) { return frs_t::reduce_only(x); }
+    __device__ __forceinline__ static fr_t finish(const elem& y, int a) {
+        (void)a;
+        return y.to_canonical();
+    }
+};
+
 __device__ __forceinline__ fr_t load_fr_global(const fr_mem_t* p) {
     const uint4* src = (const uint4*)p;
     const uint4 x0 = src[0], x1 = src[1];
@@ -177,8 +226,8 @@ __device__ __forceinline__ void store_fr_global(fr_mem_t* p, const fr_t& x) {
 }
 
 // K stages (1 or 2) on the 2^K rows {base_row + m * row_step}; s = index of the first of them within the pass.
-template <int K>
-__device__ __forceinline__ void dif_group(fr_t* x, int s, int a, int lo, const ntt_lds_t& L) {
+template <int K, class A>
+__device__ __forceinline__ void dif_group(typename A::elem* x, int s, int a, int lo, const ntt_lds_t& L) {
     // rows of the group differ in the K bits just below bit (a - s); `lo` = the row bits below them
     const int lo_bits = a - s - K;
 #pragma unroll
@@ -190,7 +239,7 @@ __device__ __forceinline__ void dif_group(fr_t* x, int s, int a, int lo, const n
             // pos = row mod half, half = 2^(a - 1 - (s + t)): the group-local bits below `bit`, then `lo`
             const int pos = ((m & (bit - 1)) << lo_bits) | lo;
             const int tw_idx = pos << (s + t);  // exponent of w_(2^a)
-            lazy_butterfly(x[m], x[m | bit], s + t, tw_idx, L);
+            A::butterfly(x[m], x[m | bit], s + t, tw_idx, L);
         }
     }
 }
@@ -205,8 +254,9 @@ struct ntt_batch_t {
     int in_scratch, out_scratch;
 };
 struct ntt_no_batch_t {};
-template <bool BATCH>
+template <bool BATCH, class A>
 __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tables_t tb, typename std::conditional<BATCH, ntt_batch_t, ntt_no_batch_t>::type bt) {
+    typedef typename A::elem elem;
     extern __shared__ uint32_t lds32[];
     if constexpr (BATCH) {
         fr_mem_t* vec = bt.v[blockIdx.y];
@@ -243,7 +293,7 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tabl
     }
     // local twiddles -> LDS planes
     for (int i = tid; i < L.NL; i += nthr) {  // w_(2^a)^i = w_512^(i << (9 - a))
-        const fr_t w = fr_t::load(&tb.local[p.dir][i << (NTT_MAX_RADIX_LG - p.a)]);
+        const fr_t w = A::tw(fr_t::load(&tb.local[p.dir][i << (NTT_MAX_RADIX_LG - p.a)]));
 #pragma unroll
         for (int l = 0; l < 9; l++) L.tw[l * L.NL + i] = w.v[l];
     }
@@ -271,70 +321,60 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel_v2(ntt_pass_t p, ntt_tabl
             const int hi = q >> lo_bits;
             const int row0 = (hi << (p.a - s)) | lo;
             const int row_step = 1 << lo_bits;
-            fr_t x[4];
+            elem x[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 if (m >= (1 << K)) break;
                 const int row = row0 + m * row_step;
                 if (first) {
                     const size_t g = in_base + row * in_rho_stride + col * in_col_stride;
-                    x[m] = load_fr_global(&p.in[g]);
-                    if (p.coset_pre) x[m] = x[m] * tw_lookup(tb.g_lo[0], tb.g_hi[0], (uint32_t)g);
+                    fr_t xin = load_fr_global(&p.in[g]);
+                    if (p.coset_pre) xin = xin * tw_lookup(tb.g_lo[0], tb.g_hi[0], (uint32_t)g);
+                    x[m] = A::from_canonical(xin);
                 } else {
-                    x[m] = L.get(row * T + col);
+                    x[m] = L.get<elem>(row * T + col);
                 }
             }
             if (K == 2)
-                dif_group<2>(x, s, p.a, lo, L);
+                dif_group<2, A>(x, s, p.a, lo, L);
             else
-                dif_group<1>(x, s, p.a, lo, L);
+                dif_group<1, A>(x, s, p.a, lo, L);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 if (m >= (1 << K)) break;
                 const int row = row0 + m * row_step;
                 if (!last_group) {
-                    L.put(row * T + col, x[m]);
+                    L.put<elem>(row * T + col, x[m]);
                     continue;
                 }
                 // ---- closing multiplication + store; row `row` holds output digit k = bitrev_a(row)
                 const uint32_t k = bitrev32((uint32_t)row, p.a);
                 size_t g;
-                fr_t y;
+                elem y;
                 if (!p.last) {
                     g = in_base + ((size_t)k << p.s) + col;
                     if (p.tw_full) {
-                        y = x[m].mul_lazy(fr_t::load(&p.tw_full[((size_t)k << p.s) + inner0 + col]));
+                        y = A::mul(x[m], fr_t::load(&p.tw_full[((size_t)k << p.s) + inner0 + col]));  // the table holds the arithmetic's own form
                     } else {
+                        // composed on the fly from the two-level power tables (no table fits: the first pass of a 2^26 transform)
                         const uint32_t expo = (uint32_t)(((inner0 + col) * (size_t)k) << p.tw_shift);
-                        y = x[m].mul_lazy(fr_t::load(&tb.pow_lo[p.dir][expo & (NTT_TW_SIZE - 1)]));
+                        fr_t w = fr_t::load(&tb.pow_lo[p.dir][expo & (NTT_TW_SIZE - 1)]);
                         const uint32_t h = expo >> NTT_TW_BITS;
-                        if (h) y = y.mul_lazy(fr_t::load(&tb.pow_hi[p.dir][h]));
+                        if (h) w = w * fr_t::load(&tb.pow_hi[p.dir][h]);
+                        y = A::mul(x[m], A::tw(w));
                     }
                 } else {
                     g = (d1_0 + col) + (((size_t)mid + ((size_t)k << p.lg_mid)) << p.a1);
-                    if (p.reduce_only) {
-                        y = x[m];
-                        if (p.scale_post == 2) {
-                            y = y.mul_lazy(fr_t::load(&tb.g_lo[1][(uint32_t)g & (NTT_TW_SIZE - 1)]));
-                            const uint32_t h = (uint32_t)g >> NTT_TW_BITS;
-                            if (h) y = y.mul_lazy(fr_t::load(&tb.g_hi[1][h]));
-                        }
-                        y = y.mont_reduce_lazy();
-                    } else if (p.scale_post == 0) {
-                        y = x[m].mul_lazy(fr_t::one());
-                    } else {
-                        y = x[m].mul_lazy(fr_t::load(&tb.size_inv[p.lg_n]));
-                        if (p.scale_post == 2) {
-                            y = y.mul_lazy(fr_t::load(&tb.g_lo[1][(uint32_t)g & (NTT_TW_SIZE - 1)]));
-                            const uint32_t h = (uint32_t)g >> NTT_TW_BITS;
-                            if (h) y = y.mul_lazy(fr_t::load(&tb.g_hi[1][h]));
-                        }
+                    y = x[m];
+                    if (!p.reduce_only) y = A::mul(y, p.scale_post == 0 ? A::one() : A::tw(fr_t::load(&tb.size_inv[p.lg_n])));
+                    if (p.scale_post == 2) {
+                        y = A::mul(y, A::tw(fr_t::load(&tb.g_lo[1][(uint32_t)g & (NTT_TW_SIZE - 1)])));
+                        const uint32_t h = (uint32_t)g >> NTT_TW_BITS;
+                        if (h) y = A::mul(y, A::tw(fr_t::load(&tb.g_hi[1][h])));
                     }
+                    if (p.reduce_only) y = A::reduce_only(y);
                 }
-                fr_t z = y.reduce_lazy();
-                // a radix-2^9 pass ends with values < 2^9 r = 1.17 * 2^261: the closing product is < 2.17 r, one more conditional
-                // subtraction makes it canonical
-                if (p.a > 8) z = z.reduce_lazy();
+                const fr_t z = A::finish(y, p.a);
                 store_fr_global(&p.out[g], z);
             }
         }
@@ -469,15 +509,18 @@ struct ntt_ctx_t {
     std::vector<void*>* leases;
 };
 // fold: 0 plain, 1 times 2^261, 2 times 2^261 * size_inv (size_inv points at the Montgomery form of n^-1)
+// arith_signed: the table serves frs.hip.h (R = 2^290): plain entries carry 2^290 instead of 2^261, folded ones 2^580 instead of 2^522
 static __global__ void ntt_fill_full_tw_kernel(fr_mem_t* __restrict__ out, int a, int s, int tw_shift, const fr_mem_t* __restrict__ lo,
-                                        const fr_mem_t* __restrict__ hi, int fold, const fr_mem_t* __restrict__ size_inv) {
+                                        const fr_mem_t* __restrict__ hi, int fold, const fr_mem_t* __restrict__ size_inv, int arith_signed) {
     const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (idx >= ((size_t)1 << (a + s))) return;
     const uint32_t k = (uint32_t)(idx >> s), inner = (uint32_t)(idx & (((size_t)1 << s) - 1));
     fr_t t = tw_lookup(lo, hi, (inner * k) << tw_shift);
     if (fold) {
-        t = t * fr_t::from_table(FrP::R2);  // Montgomery form of (2^261 mod r): the stored word becomes t * 2^522
+        t = t * fr_t::from_table(arith_signed ? FrS::C580 : FrP::R2);  // Montgomery form of (2^261 mod r): the stored word becomes t * 2^522 (signed: t * 2^580)
         if (fold == 2) t = t * fr_t::load(size_inv);
+    } else if (arith_signed) {
+        t = frs_t::twiddle_form(t);
     }
     t.store(&out[idx]);
 }
@@ -520,7 +563,7 @@ static inline const fr_mem_t* ntt_get_full_tw(const ntt_ctx_t& cx, int a, int s,
         cache.bytes += need;
         const int fold = !prelast_lg ? 0 : (dir == NTT_INVERSE ? 2 : 1);
         hipLaunchKernelGGL(ntt_fill_full_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.st, slot.p, a, s, tw_shift, cx.tb->pow_lo[dir],
-                           cx.tb->pow_hi[dir], fold, (const fr_mem_t*)(cx.tb->size_inv + (prelast_lg ? prelast_lg : 0)));
+                           cx.tb->pow_hi[dir], fold, (const fr_mem_t*)(cx.tb->size_inv + (prelast_lg ? prelast_lg : 0)), tuning().ntt_signed ? 1 : 0);
         (void)hipStreamSynchronize(cx.st);  // other streams may use the table from now on
     }
     slot.last_use = ++cache.tick;
@@ -538,10 +581,15 @@ static inline void ntt_launch_pass(hipStream_t st, const ntt_pass_t& p, const nt
         if (threads < 64) threads = 64;
         if (threads > 512) threads = 512;
         const size_t shmem = (9 * E + 9 * ((size_t)1 << (p.a ? p.a - 1 : 0))) * sizeof(uint32_t);  // a [2^8 x 8] tile + its twiddles: 78 KB, two workgroups per CU
-        if (bt)
-            hipLaunchKernelGGL((ntt_pass_kernel_v2<true>), dim3((unsigned)ntiles, nvec), dim3(threads), shmem, st, p, tb, *bt);
+        const bool sg = tuning().ntt_signed != 0;
+        if (bt && sg)
+            hipLaunchKernelGGL((ntt_pass_kernel_v2<true, ntt_arith_s>), dim3((unsigned)ntiles, nvec), dim3(threads), shmem, st, p, tb, *bt);
+        else if (bt)
+            hipLaunchKernelGGL((ntt_pass_kernel_v2<true, ntt_arith_u>), dim3((unsigned)ntiles, nvec), dim3(threads), shmem, st, p, tb, *bt);
+        else if (sg)
+            hipLaunchKernelGGL((ntt_pass_kernel_v2<false, ntt_arith_s>), dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb, ntt_no_batch_t{});
         else
-            hipLaunchKernelGGL((ntt_pass_kernel_v2<false>), dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb, ntt_no_batch_t{});
+            hipLaunchKernelGGL((ntt_pass_kernel_v2<false, ntt_arith_u>), dim3((unsigned)ntiles), dim3(threads), shmem, st, p, tb, ntt_no_batch_t{});
     }
 }
 

@@ -346,8 +346,10 @@ static void tu_kernel_attributes(int logical) {
     HIP_TRY(hipFuncSetAttribute((const void*)msm_accumulate_lazy_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 #endif
 #ifdef SV_TU_NTT  // the unit that launches the NTT passes (api_fr.hip)
-    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<false, ntt_arith_u>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<true, ntt_arith_u>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<false, ntt_arith_s>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel_v2<true, ntt_arith_s>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 #endif
     done[logical] = 1;
 }
@@ -626,9 +628,8 @@ static size_t msm_acc_lds() {
     const long env = tuning().acc_lds;
     return env < 0 ? 0 : (size_t)env;
 }
-static bool msm_lazy_enabled();
 template <class F>
-static constexpr bool msm_lazy_field();
+static bool msm_lazy_on();
 // Tail geometry of an MSM with `nwin` bucket windows of 2^(c - 1) buckets: windows of >= 2^11 buckets are first folded into two tail
 // windows of 2^fold_m / 2^fold_hb - 1 entries; so are smaller windows when there are too few (window, bit) pairs to spread an
 // unfolded tail over the chip (registered tables below 4 096 points: 2 windows x 8 bits would be 16 workgroups walking every
@@ -710,8 +711,21 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     // mu != nullptr: fused multi-instance run (msm_sort.hip.h): n = mu->npad padded positions, d_bases = the handle's table array,
     // d_scalars unused (the instance table carries the pointers), one bucket window per instance; host_planes holds
     // mu->K * 2 * (fold_m + 1) planes.
-    auto phase_begin = [&](const char* name) { if (profile) c.phase_begin(name); };
-    auto phase_end = [&]() { if (profile) c.phase_end(); };
+    // SNARKVM_HIP_TRACE=2 (diagnostics): wait for the stream after every phase and name it on stderr - locates a kernel that never returns
+    static const int trace2 = getenv("SNARKVM_HIP_TRACE") ? atoi(getenv("SNARKVM_HIP_TRACE")) : 0;
+    const char* cur_phase = "";
+    auto phase_begin = [&](const char* name) {
+        cur_phase = name;
+        if (trace2 >= 2) fprintf(stderr, "[snarkvm_hip] msm n=%zu: %s ...\n", n, name);
+        if (profile) c.phase_begin(name);
+    };
+    auto phase_end = [&]() {
+        if (profile) c.phase_end();
+        if (trace2 >= 2) {
+            const hipError_t e = hipStreamSynchronize(c.stream);
+            fprintf(stderr, "[snarkvm_hip] msm n=%zu: %s done (%s)\n", n, cur_phase, hipGetErrorString(e));
+        }
+    };
     msm_pending_t pd;
     pd.planes = host_planes;
     if (n0 > n) n0 = n;
@@ -959,6 +973,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             // a bucket of s entries is touched by at most (s - 1) / S + 2 segment threads
             const int env_rounds = tuning().reduce_rounds;
             if (!single_round) rounds = env_rounds < 0 ? 0 : (env_rounds > 8 ? 8 : env_rounds);
+            // fused groups: optional reduce rounds (tuning fuse_reduce).  They bound what one fold workgroup can meet when an instance's
+            // scalars are all equal (a 2^18-pair instance then leaves ~70 000 partial sums in ONE bucket: 1 100 dependent additions per
+            // lane of its row) at the price of one more pass over the partial sums of well-behaved instances.
+            if (mu && tuning().fuse_reduce > 0) rounds = tuning().fuse_reduce > 4 ? 4 : tuning().fuse_reduce;
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
@@ -969,8 +987,8 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
 #endif
             // (a 3-waves-per-SIMD build of this kernel - 168 VGPRs - and a software-pipelined gather were measured: no gain)
             const int prefetch_env = tuning().prefetch;  // 0: never, 1: single-round launches only, 2: always (lazy kernel: -2 .. 3 %)
-            if constexpr (msm_lazy_field<F>()) {
-                if (msm_lazy_enabled()) {
+            if constexpr (sizeof(F) == sizeof(fq_t)) {
+                if (msm_lazy_on<F>()) {
                     // raw partial sums (208 B each) go to their own buffer; the dense conversion pass fills part_a for the tail
                     const size_t tmax = nthreads + nbt + 1;  // every thread leaves >= 1 partial sum, one more per bucket boundary inside its segment
                     c.part_raw.ensure(tmax * sizeof(g1_lazy_partial_t));
@@ -991,6 +1009,19 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                                        (const uint32_t*)c.start_a.as<uint32_t>(), nbt);
                     goto accumulated;
                 }
+            } else {
+#ifndef SV_NO_G2
+                if (msm_lazy_on<F>()) {  // G2 on the lazy Fq2 arithmetic of ffl2.hip.h: raw 416-byte partial sums, then the dense conversion
+                    const size_t tmax = nthreads + nbt + 1;
+                    c.part_raw.ensure(tmax * sizeof(g2_lazy_partial_t));
+                    hipLaunchKernelGGL((msm_accumulate_lazy2_kernel<false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,
+                                       c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_raw.as<g2_lazy_partial_t>(), nbt, pl.S, dbg_mask);
+                    hipLaunchKernelGGL(g2_partials_to_exact_kernel, dim3((unsigned)((tmax + 255) / 256)), dim3(256), 0, st,
+                                       (const g2_lazy_partial_t*)c.part_raw.as<g2_lazy_partial_t>(), c.part_a.as<xyzz_mem_t<fq2_t>>(),
+                                       (const uint32_t*)c.start_a.as<uint32_t>(), nbt);
+                    goto accumulated;
+                }
+#endif
             }
             if (single_round && prefetch_ok && prefetch_env)
                 hipLaunchKernelGGL((msm_accumulate_seg_kernel<F, 1, true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,
@@ -1070,28 +1101,33 @@ static void msm_run_sync(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_
     c.phase_host("msm_host_finish", host_now_ms() - t0);  // the Horner chain over the bit planes, on the calling thread
 }
 
-// G1 accumulation runs on the lazily reduced arithmetic of ffl.hip.h (tuning lazy=0: the exact kernel, A/B switch).  Process
-// wide: every G1 base slot an MSM reads - registered tables and the staging of table-less calls - then holds form406.
-static bool msm_lazy_enabled() {
-    return tuning().lazy != 0;
-}
+// Accumulation runs on the lazily reduced arithmetic: G1 on ffl.hip.h (tuning lazy=0: the exact kernel), G2 on ffl2.hip.h (tuning
+// lazy2=0).  Process wide: every base slot an MSM of that group reads - registered tables and the staging of table-less calls - then
+// holds form406.
 template <class F>
-static constexpr bool msm_lazy_field() {
-    return sizeof(F) == sizeof(fq_t);  // G1 only; the Fq2 instantiations keep the exact arithmetic
+static bool msm_lazy_on() {
+    return sizeof(F) == sizeof(fq_t) ? tuning().lazy != 0 : tuning().lazy2 != 0;
 }
 template <class F>
 static void convert_bases(lane_t& c, const uint8_t* d_in, size_t stride, size_t n, aff_mem_t<F>* d_out, hipStream_t st = nullptr, bool for_msm = false) {
     if (!n) return;
-    const int form406 = for_msm && msm_lazy_field<F>() && msm_lazy_enabled() ? 1 : 0;
+    const int form406 = for_msm && msm_lazy_on<F>() ? 1 : 0;
     hipLaunchKernelGGL((convert_bases_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st ? st : c.stream, d_in, stride, n, d_out, form406);
     HIP_TRY(hipGetLastError());
 }
 // the last step of a G1 registration: every slot of every table, exact internal form -> form406
 static void bases_to_lazy_form(lane_t& c, g1_aff_mem_t* d, size_t slots) {
-    if (!slots || !msm_lazy_enabled()) return;
+    if (!slots || !msm_lazy_on<fq_t>()) return;
     hipLaunchKernelGGL(g1_bases_to_form406_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c.stream, d, slots);
     HIP_TRY(hipGetLastError());
 }
+#ifndef SV_NO_G2
+static void bases_to_lazy_form(lane_t& c, aff_mem_t<fq2_t>* d, size_t slots) {
+    if (!slots || !msm_lazy_on<fq2_t>()) return;
+    hipLaunchKernelGGL(g2_bases_to_form406_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c.stream, d, slots);
+    HIP_TRY(hipGetLastError());
+}
+#endif
 
 // Precomputed base tables of a registered vector: table j = 2^(table_bits * j) * P_i, from table j - 1 (msm.hip.h).  Long
 // vectors give every thread a run of points that share one inversion; a run of 1 keeps small vectors parallel.
@@ -1257,7 +1293,8 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
         std::vector<size_t> mine;
         for (size_t i = (dev < 0 ? 0 : (size_t)dev); i < nchunks; i += (size_t)ndu) mine.push_back(i);
         lane_guard lg;
-        lg.acquire(dev, mine.size() > 2 ? 3 : (int)mine.size());
+        const int ring = tuning().ring_lanes < 2 ? 2 : (tuning().ring_lanes > device_t::LANES ? device_t::LANES : tuning().ring_lanes);
+        lg.acquire(dev, mine.size() > (size_t)ring ? ring : (int)mine.size());
         const int L = (int)lg.lanes.size();
         // Several chunks on this device: they share ONE set of buckets (16-bit windows whatever the chunk length) - every chunk
         // adds its per-bucket partial sums to a sink and the fold / bit-plane tail runs once, after the last chunk, instead of once
@@ -1587,6 +1624,8 @@ struct msm_ticket_t {
     int state = 0;  // 0 queued, 1 in flight, 2 done, 3 failed
     std::exception_ptr err;
 };
+// how the coalescer grouped its callers so far: {batches dispatched, tickets in them, largest batch, batches of one ticket}
+static std::atomic<uint64_t> g_co_stats[4];
 static bool msm_other_caller_recently() {
     static std::atomic<uint64_t> last_ns{0}, last_tid{0};
     timespec ts;
@@ -1637,6 +1676,11 @@ static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t 
             lk.unlock();
             std::exception_ptr err;
             if (!batch.empty()) {
+                g_co_stats[0].fetch_add(1, std::memory_order_relaxed);
+                g_co_stats[1].fetch_add(batch.size(), std::memory_order_relaxed);
+                if (batch.size() == 1) g_co_stats[3].fetch_add(1, std::memory_order_relaxed);
+                for (uint64_t cur = g_co_stats[2].load(); cur < batch.size() && !g_co_stats[2].compare_exchange_weak(cur, batch.size());) {
+                }
                 try {
                     std::vector<msm_req_t> req(batch.size());
                     for (size_t i = 0; i < batch.size(); i++) req[i] = batch[i]->req;

@@ -25,12 +25,14 @@
 //   fold_flat       1        flattened-list fold for every MSM (0: per-bucket lists for big ones)
 //   fuse_batch      1        small instances of a batch travel as fused multi-instance groups
 //   fuse_max_k      64       instances per fused group
+//   fuse_reduce     0        reduce rounds of a fused group before its fold (0: none)
 //   coalesce        1        concurrent callers of small registered MSMs are fused by an in-library dispatcher
 //   coalesce_us     40       how long a dispatcher waits for further callers when others are inside the library
 //   lanes           0        lanes a batch cycles through (0: 8 below 2^20 pairs, 3 above)
 //   msm_chunk_lg    21       pairs per upload / compute chunk of snarkvm_msm (host bases)
 //   scalar_chunk_lg 22       pairs per scalar chunk of a host-scalar MSM over registered bases
-//   taper           1        snarkvm_msm: the last chunks shrink so that little compute is exposed after the final upload
+//   taper           1        snarkvm_msm: the last chunk is cut again (1/2, 1/4, 1/4) and all chunks share one bucket sink and one tail
+//   ring_lanes      3        lanes (streams with their own staging buffers) the chunks of one snarkvm_msm call cycle through
 //   seg             0        accumulate segment length override (0: planner)
 //   seg2            0        reduce-round group size override
 //   fold_l          0        planner L override
@@ -38,7 +40,7 @@
 //   ntt_min_tiles   256      workgroups a small-transform pass is spread over
 //   ntt_full_tw     1        materialised closing-twiddle tables
 //   ntt_fold        1        2^261 [/ n] folded into the table of the pass before the last
-//   ntt_signed      1        NTT butterflies on signed limbs (0: the unsigned lazy butterflies of round 3)
+//   ntt_signed      0        1: NTT butterflies on the signed limbs of frs.hip.h (measured: 2.115 vs 2.062 ms of kernels at 2^24 - not faster)
 //   ntt_batch       1        snarkvm_hip_ntt_device_batch: one launch per pass for all vectors of a (direction, type) group
 #pragma once
 #include <stdio.h>
@@ -50,9 +52,9 @@ namespace sv {
 struct tuning_t {
     int lazy = 1, lazy2 = 1, fused = 1, hist = 2, prefetch = 2;
     long acc_lds = 96 * 1024;
-    int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, coalesce = 1, coalesce_us = 40, lanes = 0;
-    int msm_chunk_lg = 21, scalar_chunk_lg = 22, taper = 1, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
-    int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 1, ntt_batch = 1;
+    int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 0, coalesce = 1, coalesce_us = 40, lanes = 0;
+    int msm_chunk_lg = 21, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
+    int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -61,8 +63,8 @@ struct tuning_t {
         return true;                       \
     }
         SV_TUNE_KEY(lazy) SV_TUNE_KEY(lazy2) SV_TUNE_KEY(fused) SV_TUNE_KEY(hist) SV_TUNE_KEY(prefetch) SV_TUNE_KEY(acc_lds)
-        SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(coalesce)
-        SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
+        SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
+        SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
         SV_TUNE_KEY(ntt_batch)
 #undef SV_TUNE_KEY

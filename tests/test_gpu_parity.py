@@ -993,3 +993,23 @@ def test_bench_two_rank_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 2 * (1 << 16) / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_proofs64_two_rank_lockstep_on_one_gpu():
+    """bench.py --workload proofs64 with two ranks sharing this GPU over gloo: the proofs are sharded over the ranks (strong scaling),
+    every rank replays its share in lock step and by concurrent callers, the modes are compared, rank 0 checks one whole proof
+    against the oracle and prints the one JSON line with every rank's own time."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SNARKVM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+           os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--workload", "proofs64", "--proofs", "8", "--proof-group", "4", "--proof-workers", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=util.ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and len(d["rank_ms_per_proof"]) == 2
+    assert "one_proof_vs_oracle" in d["checks"] and "lockstep_vs_callers" in d["checks"]
+    assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6

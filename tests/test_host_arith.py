@@ -196,3 +196,23 @@ def test_lazy_accumulate_arithmetic_matches_exact():
     L = _lib.lib()
     for seed in (1, 2, 3, 0xDEADBEEF):
         assert L.snarkvm_hip_selftest_fq_lazy(ctypes.c_uint64(seed), ctypes.c_int(5000)) == 0, seed
+
+
+def test_signed_ntt_butterfly_arithmetic_matches_exact():
+    """csrc/frs.hip.h (signed limbs, R = 2^290, no canonical form inside a pass) compiled for the host against the exact Fr
+    arithmetic (which test_field_ops pins on the oracle): chains of up to nine butterfly stages, the closing product, the bare
+    reduction and the folded closing-table form, including operands with all-ones / all-zero limbs."""
+    L = _lib.lib()
+    for seed in (1, 0xFEED, 0x5EED5EED, 2**63 + 11):
+        assert L.snarkvm_hip_selftest_fr_signed(ctypes.c_uint64(seed), ctypes.c_int(400)) == 0, seed
+
+
+def test_lazy_g2_accumulate_arithmetic_matches_exact():
+    """csrc/ffl2.hip.h (lazy Fq2 on signed limbs: the factor 5 of the non-residue folded into a 14-limb operand, two-product
+    reductions, tight-range subtractions) compiled for the host against the exact Fq2 / XYZZ arithmetic: chains of G2 mixed additions
+    with doublings, cancellations and restarts, every coordinate after every step; products, squares and the raw partial-sum image."""
+    L = _lib.lib()
+    pts = synthetic.g2_points(48, distinct=48)
+    for seed in (1, 7, 0xC0FFEE):
+        rc = L.snarkvm_hip_selftest_fq2_lazy(ctypes.c_void_p(pts.ctypes.data), ctypes.c_size_t(pts.shape[0]), ctypes.c_uint64(seed), ctypes.c_int(1500))
+        assert rc == 0, (seed, rc)
