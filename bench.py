@@ -309,9 +309,11 @@ def main():
 
     if args.ntt_steps & 1:
         args.ntt_steps += 1  # forward / inverse pairs: the vector is back to the input afterwards
-    ntt_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps)
+    # `ntt_value` = one synchronous snarkvm_hip_ntt_device call per transform: the reference's call pattern (EvaluationDomain::fft_in_place
+    # -> snarkvm_ntt per vector), comparable with earlier rounds and with the CPU baseline; the same transforms as ONE batch call beside it
+    ntt_batch_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps)
+    ntt_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps, batched=False)
     ntt_elems_per_s = world * nn * args.ntt_steps / ntt_dt
-    ntt_sync_dt = time_ntt(d_x, args.lg_ntt, args.ntt_steps, batched=False)
     L.snarkvm_hip_set_profiling(1)
     ntt_dev(d_x, args.lg_ntt, 0)
     ntt_kernel_ms = L.snarkvm_hip_get_phase_ms(0)
@@ -368,9 +370,9 @@ def main():
             extra["msm_2p20"] = {"value": n20 * k20 / d20, "unit": "pairs/s", "ms_per_step_pipelined": d20 / k20 * 1e3, "ms_sync": s20 * 1e3, "base_tables": "16 x 16 bit"}
         if args.lg_ntt >= 20:
             nt = 20
-            d20 = time_ntt(d_x, 20, nt)
-            d20s = time_ntt(d_x, 20, nt, batched=False)
-            extra["ntt_2p20"] = {"value": (1 << 20) * nt / d20, "unit": "elements/s", "ms_per_transform": d20 / nt * 1e3, "ms_per_transform_sync_calls": d20s / nt * 1e3}
+            d20b = time_ntt(d_x, 20, nt)
+            d20 = time_ntt(d_x, 20, nt, batched=False)
+            extra["ntt_2p20"] = {"value": (1 << 20) * nt / d20, "unit": "elements/s", "ms_per_transform": d20 / nt * 1e3, "ms_per_transform_one_batch_call": d20b / nt * 1e3}
         # -- the reference's own FFI symbols over host buffers (PCIe-inclusive; never `value`)
         ffi = {}
         host_bases = bases_dev.cpu().numpy().view(G1_AFFINE)
@@ -490,7 +492,7 @@ def main():
     # runs; gfx950 x2 FETCH correction), and the wall-clock arithmetic ceilings of tools/ecbench.hip / tools/microbench.hip.
     # Only quoted for the configuration they were collected on; PMC collection cannot run inside this process.
     default_cfg = args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits
-    pmc = (load_profile_json("r03_pmc_traffic.json") or load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
+    pmc = (load_profile_json("r04_pmc_traffic.json") or load_profile_json("r03_pmc_traffic.json") or load_profile_json("r02_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
     ceil = load_profile_json("r03_alu_ceilings.json") or load_profile_json("r02_alu_ceilings.json")
 
     def traffic(kernel_prefix, fetch_key, times=1):
@@ -502,7 +504,7 @@ def main():
     if rank == 0:
         acc_ms = phase_ms.get("msm_accumulate", 0.0)
         dig_ms = phase_ms.get("msm_scalar_read", 0.0) or phase_ms.get("msm_digits", 0.0)
-        dig_kernel = "radix_hist1_fused_kernel (scalar read + level-1 histograms; no digit matrix)" if "msm_scalar_read" in phase_ms else "msm_digits_kernel"
+        dig_kernel = "radix_hist1_wide_kernel (scalar read + level-1 histograms; no digit matrix)" if "msm_scalar_read" in phase_ms else "msm_digits_kernel"
         cbits = args.window_bits or (args.table_bits if args.tables > 1 else 16)
         W = args.tables * (args.table_bits // cbits) if args.tables > 1 else (254 + cbits - 1) // cbits  # digit rows per scalar
         alg_bytes = n * 128.0 + 144.0  # whole MSM = n (32 + 96) + 144
@@ -560,8 +562,9 @@ def main():
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
             "ntt_ms_per_transform": ntt_dt / args.ntt_steps * 1e3,
-            "ntt_sync_call": {"value": world * nn * args.ntt_steps / ntt_sync_dt, "unit": "elements/s", "ms_per_transform": ntt_sync_dt / args.ntt_steps * 1e3,
-                              "what": "one synchronous snarkvm_hip_ntt_device call per transform (ntt_value: the same transforms as one snarkvm_hip_ntt_device_batch call)"},
+            "ntt_batched_call": {"value": world * nn * args.ntt_steps / ntt_batch_dt, "unit": "elements/s", "ms_per_transform": ntt_batch_dt / args.ntt_steps * 1e3,
+                                 "what": "the same transforms as ONE snarkvm_hip_ntt_device_batch call (one enqueue, one synchronisation); ntt_value: one synchronous "
+                                         "snarkvm_hip_ntt_device call per transform"},
             "ntt_kernel_ms": ntt_kernel_ms,
             "ntt_vs_cpu_baseline": (ntt_elems_per_s / cpu["ntt_value"]) if cpu else None,
             "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
@@ -576,7 +579,7 @@ def main():
                 "frac": (alg_bytes / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
                 "traffic": traffic("msm_accumulate_lazy_kernel", "fetch_bytes_raw") or traffic("msm_accumulate_seg_kernel", "fetch_bytes_raw"),
                 "algorithmic_bytes": alg_bytes,
-                "traffic_model": {"bytes": n * 100.0 * W, "what": "one gathered 96-B base + one 4-B sorted index per (pair, digit row)"},
+                "traffic_model": {"bytes": n * 132.0 * W, "what": "one gathered 128-B lazy base slot + one 4-B sorted index per (pair, digit row)"},
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see alu_roofline; roofline_scalar_read is the HBM-bound phase",
             },
             "alu_roofline": alu,
@@ -588,12 +591,12 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
-                "traffic": traffic("radix_hist1_fused_kernel", "fetch_bytes_x2") if "msm_scalar_read" in phase_ms else traffic("msm_digits_kernel", "fetch_bytes_x2"),
+                "traffic": (traffic("radix_hist1_wide_kernel", "fetch_bytes_x2") or traffic("radix_hist1_fused_kernel", "fetch_bytes_x2")) if "msm_scalar_read" in phase_ms else traffic("msm_digits_kernel", "fetch_bytes_x2"),
                 "algorithmic_bytes": 32.0 * n,
                 # the whole scalar-consuming phase: the level-1 scatter (radix_scatter1_fused_kernel + its counter scans) reads every
                 # scalar a second time and writes 72 B of (index | sign, remainder) entries per scalar; still priced on 32 n bytes
                 "whole_phase": ({
-                    "kernels": "radix_hist1_fused + fused_chunk_sums / scan / fused_tile_offsets + radix_scatter1_fused",
+                    "kernels": "radix_hist1_wide + fused_chunk_sums / scan / fused_tile_offsets + radix_scatter1_fused",
                     "ms": dig_ms + phase_ms["msm_sort_level1"],
                     "achieved": (32.0 * n) / ((dig_ms + phase_ms["msm_sort_level1"]) * 1e-3) / 1e9,
                     "frac": (32.0 * n) / ((dig_ms + phase_ms["msm_sort_level1"]) * 1e-3) / 1e9 / 8000.0,

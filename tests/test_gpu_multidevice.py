@@ -234,13 +234,21 @@ for i, (k, o) in enumerate(zip(sizes, offs)):
     assert util.affine_equal(oracle.g1_to_affine(res[i:i + 1]), closed(sc[:k], start=o + 1)), ("batch", i)
 rb.close()
 assert util.affine_equal(oracle.g1_to_affine(plugin.msm(bases[:300000], sc[:300000])), closed(sc[:300000])), "ffi"
+# G2 (the accumulate arithmetic, tuning lazy2): repeated bases (doublings), registered tables and the one-shot symbol
+g2p = synthetic.g2_points(700, distinct=40)
+g2s = synthetic.random_fr_integers(700, 777)
+want2 = oracle.g2_to_affine(oracle.g2_msm(g2p, g2s)).tobytes()
+assert oracle.g2_to_affine(msm.msm_g2(g2p, g2s)).tobytes() == want2, "g2 one-shot"
+rg = msm.RegisteredBasesG2(g2p, tables=17, window_bits=15)
+assert oracle.g2_to_affine(rg.msm(g2s)).tobytes() == want2, "g2 registered"
+rg.close()
 print("AB_OK")
 '''
 
 
 @pytest.mark.parametrize("tuning", [
     "ntt_min_tiles=1", "ntt_min_tiles=1024", "lazy=0", "prefetch=0", "acc_one_wg=1,acc_lds=83968", "fuse_batch=0", "fused=0", "seg=96", "reduce_rounds=0",
-    "hist=1", "ntt_signed=1", "ntt_batch=0", "ring_lanes=5", "coalesce=0", "taper=0", "fuse_max_k=2"])
+    "hist=1", "ntt_signed=1", "ntt_batch=0", "ring_lanes=5", "coalesce=0", "taper=0", "fuse_max_k=2", "fuse_reduce=0", "lazy2=0"])
 def test_ab_switches_are_bit_exact(tuning):
     """csrc/tuning.hip.h: one variable, parsed once per process; every key selects another kernel / launch shape for the same mathematics."""
     r = subprocess.run([sys.executable, "-c", AB_SCRIPT % util.ROOT], capture_output=True, text=True, env=dict(os.environ, SNARKVM_HIP_TUNING=tuning), timeout=900, cwd=util.ROOT)
