@@ -122,6 +122,9 @@ mod sys {
             window_bits: i32,
         ) -> Error;
         pub fn snarkvm_hip_free_bases(handle: *mut c_void);
+        pub fn snarkvm_hip_scope_begin(d_any: *const c_void) -> Error;
+        pub fn snarkvm_hip_scope_end() -> Error;
+        pub fn snarkvm_hip_coalescer_stats(out: *mut u64, reset: i32);
         pub fn snarkvm_hip_msm_registered_ex(
             out: *mut c_void,
             handle: *const c_void,
@@ -254,6 +257,8 @@ pub mod resident {
             self.len
         }
 
+        /// Concurrent callers (rayon workers, one commitment each: sonic_pc/mod.rs:186-245) of <= 2^18 pairs over windowed tables are fused
+        /// inside the library (runtime.hip.h::msm_coalesced): no change on this side.
         /// One KZG10 commitment (polycommit/kzg10/mod.rs:98-156): `coeffs[..n0]` against bases `[off0, off0 + n0)` plus
         /// `coeffs[n0..]` against `[off1, off1 + n1)` (the hiding MSM).  `coeffs` are `Fr` elements in Montgomery form when
         /// `montgomery` is set - `convert_to_bigints` (kzg10/mod.rs:469-474) is then fused into the device's scalar read.
@@ -299,6 +304,33 @@ pub mod resident {
             .into_result()?;
             Ok(outs)
         }
+    }
+
+    /// Deferred synchronisation for device-resident operands (include/snarkvm_hip.h: snarkvm_hip_scope_begin / _end): while the guard
+    /// lives, this thread's calls on device vectors are only enqueued; dropping it waits once.  One guard per thread at a time.
+    pub struct Scope(());
+    impl Scope {
+        pub fn begin(device_ptr: *const c_void) -> Result<Self, Error> {
+            unsafe { sys::snarkvm_hip_scope_begin(device_ptr) }.into_result()?;
+            Ok(Scope(()))
+        }
+        /// Ends the scope and reports an error of the queued work (dropping the guard ignores it).
+        pub fn end(self) -> Result<(), Error> {
+            core::mem::forget(self);
+            unsafe { sys::snarkvm_hip_scope_end() }.into_result()
+        }
+    }
+    impl Drop for Scope {
+        fn drop(&mut self) {
+            let _ = unsafe { sys::snarkvm_hip_scope_end() };
+        }
+    }
+
+    /// How the in-library coalescer grouped concurrent callers of proof-sized MSMs: (batches, instances, largest batch, single-instance batches).
+    pub fn coalescer_stats(reset: bool) -> (u64, u64, u64, u64) {
+        let mut v = [0u64; 4];
+        unsafe { sys::snarkvm_hip_coalescer_stats(v.as_mut_ptr(), reset as i32) };
+        (v[0], v[1], v[2], v[3])
     }
 
     impl<Affine> Drop for Bases<Affine> {
