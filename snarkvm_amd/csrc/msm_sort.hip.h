@@ -52,7 +52,17 @@ struct msm_radix_params_t {
     // arithmetic): digit row of table j, scalar i  ->  j * vstride + (i < vn0 ? vr0 + i : vr1 + (i - vn0)).  (vn0, vr0, vr1) come
     // from the instance table in a multi-instance run.
     uint32_t vstride = 0, vn0 = 0, vr0 = 0, vr1 = 0;
+    uint32_t xcd = 0;      // scatter kernels: tile = xcd_tile(blockIdx.x, tiles) instead of blockIdx.x
 };
+// Workgroup -> tile map of the scatter kernels (round 4).  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md
+// "Workgroup dispatch"; a speed assumption only), so with tile = b the runs that tiles t and t + 1 write side by side into the same
+// 128-byte lines (16 entries = 64 B of v1 per (row, bin) and tile at level 1) dirty those lines in two different L2s, neither of which
+// ever sees a whole line: profiles/r04_pmc_traffic.json counted 1.90 GB written for 1.21 GB of entries.  Here XCD x walks the
+// contiguous tile range [x T / 8, (x + 1) T / 8): neighbouring runs meet in one L2 and leave it as whole lines.  Bijective for any T.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t T) {
+    const uint32_t q = T >> 3, r = T & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 // One level-1 tile: digits [lo, hi) of one digit row feeding bucket window w; its counters live at cbase + bin * TPW + tw.
 struct l1_tile_t {
     uint32_t w, tw, TPW, j;
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter1_kernel(const DT* 
     __shared__ RT sl_[SORT_TILE];
     __shared__ uint8_t sbin_[SORT_TILE];
     const uint32_t B1 = 1u << p.HB;
-    const l1_tile_t tl = l1_decode_tile(p, blockIdx.x);
+    const l1_tile_t tl = l1_decode_tile(p, p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
     // this tile's histogram was computed by radix_hist1_kernel; its global run starts are off1[...]
     const size_t lo = tl.lo, hi = tl.hi;
     const int half = 1 << (p.c - 1);
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) radix_scatter1_fused_kernel(con
     const uint32_t B1 = 1u << p.HB;
     const uint32_t rows = (uint32_t)dp.W;
     const uint32_t keys = rows * B1;
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     const int half = 1 << (p.c - 1);
     const uint32_t lmask = (1u << p.LB) - 1;
     // ---- read the tile's scalars (coalesced through LDS) and keep their recoded words in registers
@@ -710,13 +720,14 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
                                                                       const uint32_t* __restrict__ counts2,
                                                                       const uint32_t* __restrict__ off2, const uint32_t* __restrict__ boff,
                                                                       uint32_t* __restrict__ sorted, ROUT* __restrict__ rem_out, uint32_t nbins,
-                                                                      int LB, int shift) {
+                                                                      int LB, int shift, uint32_t xcd) {
     __shared__ uint32_t lcount[128], lstart[128], cursor[128], gbase[128], wave_tot[4];
     __shared__ uint32_t sv_[SORT_TILE];
     __shared__ uint8_t slow_[SORT_TILE];
     __shared__ ROUT srem_[SORT_TILE];
-    const uint32_t t2 = blockIdx.x;
-    if (t2 >= tile2_start[nbins]) return;
+    const uint32_t ntiles2 = tile2_start[nbins];  // the grid is an upper bound computed on the host
+    if (blockIdx.x >= ntiles2) return;
+    const uint32_t t2 = xcd ? xcd_tile(blockIdx.x, ntiles2) : blockIdx.x;
     const uint32_t B2 = 1u << LB;
     const uint32_t q = find_bucket(tile2_start, nbins, t2);
     const uint32_t lt = t2 - tile2_start[q];

@@ -670,8 +670,11 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
         // (<= 512 workgroups at two waves per SIMD); many windows (table-less small MSMs: 20 windows x 128 outputs) or many
         // buckets are throughput-bound: one wave per output
         const unsigned fold_blocks = ((1u << g.fold_m) + (1u << g.fold_hb)) * (unsigned)nwin;
-        const unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
-        if (flat || fold_threads == 256u)
+        // (G2 kernels hold one wave per SIMD: 256-thread workgroups sit one per CU, so 384 of them take two turns on 256 CUs; 128-thread
+        // workgroups sit two per CU and lose one level of the tree besides - tuning fold_threads2)
+        unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
+        if (sizeof(F) > 64 && fold_threads == 256u && (tuning().fold_threads2 == 128 || tuning().fold_threads2 == 64)) fold_threads = (unsigned)tuning().fold_threads2;
+        if (flat || fold_threads != 64u)
             hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
                                c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb);
         else
@@ -819,6 +822,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         rp.LB = wide ? 14 : LBL;        // bits left below the level-1 key
         rp.HB = K - rp.LB;
         rp.nb = pl.nb;
+        rp.xcd = (uint32_t)tuning().xcd;
         rp.tiles_per_row = fused ? (uint32_t)((n + FUSED_TILE - 1) / FUSED_TILE) : (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
         rp.TPW = (uint32_t)pl.J * rp.tiles_per_row;
         const uint32_t B1 = 1u << rp.HB;
@@ -941,7 +945,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             exclusive_scan_u32(st, msize, mboff, (size_t)ngroups + 1, c.scan_tmp.as<uint32_t>());
             hipLaunchKernelGGL((radix_scatter2_kernel<uint16_t, uint8_t>), dim3((unsigned)tmax), dim3(SORT_THREADS), 0, st, v_in, c.rl1.as<uint16_t>(),
                                seg_start, c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), mboff, c.rv2.as<uint32_t>(),
-                               c.rl2.as<uint8_t>(), nseg, 7, 7);
+                               c.rl2.as<uint8_t>(), nseg, 7, 7, (uint32_t)tuning().xcd);
             phase_end();
             seg_start = mboff;
             nseg = ngroups;
@@ -957,7 +961,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         exclusive_scan_u32(st, bsize, boffp, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
         hipLaunchKernelGGL((radix_scatter2_kernel<uint8_t, uint8_t>), dim3((unsigned)tiles2_max), dim3(SORT_THREADS), 0, st, v_in, rem_last, seg_start,
                            c.rtstart.as<uint32_t>(), c.rcounts2.as<uint32_t>(), c.roff2.as<uint32_t>(), boffp, c.sorted.as<uint32_t>(),
-                           (uint8_t*)nullptr, nseg, LBL, 0);
+                           (uint8_t*)nullptr, nseg, LBL, 0, (uint32_t)tuning().xcd);
         phase_end();
         // A single-round MSM (<= 2^22 digit entries: at most 2^16 accumulate threads) leaves at most 2^16 + nbt partial sums
         // whatever the scalars are, and the tail kernels walk them position by position (msm.hip.h 7a/7b): no reduce round.
@@ -1653,7 +1657,7 @@ static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t 
     };
     bool waited = false;
     while (!mine_done()) {
-        if (h.co_leaders < 2 && !h.co_q.empty()) {
+        if (h.co_leaders < tuning().coalesce_slots && !h.co_q.empty()) {
             h.co_leaders++;
             if (!waited && (hint || h.co_leaders > 1) && tuning().coalesce_us > 0) {
                 waited = true;  // once per call: stragglers of the same fan-out

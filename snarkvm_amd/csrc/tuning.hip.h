@@ -43,6 +43,9 @@
 //   ntt_fold        1        2^261 [/ n] folded into the table of the pass before the last
 //   ntt_signed      0        1: NTT butterflies on the signed limbs of frs.hip.h (measured: 2.115 vs 2.062 ms of kernels at 2^24 - not faster)
 //   ntt_batch       1        snarkvm_hip_ntt_device_batch: one launch per pass for all vectors of a (direction, type) group
+//   xcd             1        scatter kernels of the radix partition: XCD x walks a contiguous tile range (msm_sort.hip.h::xcd_tile)
+//   fold_threads2   128      G2: threads per output of a small fold (its kernels run one wave per SIMD: 256-thread workgroups = one per CU)
+//   coalesce_slots  2        dispatchers of the coalescer that may be inside the library at once (per handle)
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,6 +59,7 @@ struct tuning_t {
     int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 21, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -67,7 +71,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots)
 #undef SV_TUNE_KEY
         return false;
     }
