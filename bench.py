@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--cpu-lg-ntt", type=int, default=24)
     ap.add_argument("--proofs", type=int, default=64)
     ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64, callers mode)")
+    ap.add_argument("--proof-geometry", default="17x15", help="base tables x window bits of the proofs' registered SRS (proofs64)")
     ap.add_argument("--proof-group", type=int, default=32, help="proofs replayed in lock step per group (proofs64, lockstep mode)")
     args = ap.parse_args()
 
@@ -639,7 +640,8 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
     from snarkvm_amd import _lib, proofs
 
     shape = proofs.ProofShape()
-    keys = proofs.ProverKeys(shape)
+    ptab, pbits = (int(v) for v in args.proof_geometry.split("x"))
+    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits)
     mine = list(range(rank, args.proofs, world))
     checks = {}
     # ---- lock step
@@ -719,7 +721,8 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
             "data": "synthetic",
             "config": {"workload": "64 x (14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM); "
                                    "device-resident random data, transfer_private domain sizes; lock-step batch (prove_batch shape)",
-                       "proofs": args.proofs, "lockstep_group": min(args.proof_group, max(1, len(mine))), "proofs_per_rank": len(mine)},
+                       "proofs": args.proofs, "lockstep_group": min(args.proof_group, max(1, len(mine))), "proofs_per_rank": len(mine),
+                       "registered_srs": f"{ptab} tables x {pbits}-bit windows"},
             "g1_pairs_per_s": args.proofs * shape.pairs() / dt_lock,
             "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt_lock,
             "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_lock.items()},

@@ -241,6 +241,26 @@ static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, s
     if (parts < 1) parts = 1;
     const size_t chunk = msm_scalar_chunk_pairs();
     if (n >= 2 * chunk && (n + chunk - 1) / chunk > parts) parts = (n + chunk - 1) / chunk;
+    // One device: GEOMETRIC chunks (tuning scalar_geo = g, default 4: sizes 1 : g [: g^2]).  Every chunk pays the bucket overhead of a
+    // whole MSM (partial sums, their conversion, reduce rounds and the merge over 2^21 buckets at 22-bit windows: equal quarters of a 2^24 call cost 9.6 ms
+    // each against 7.85 ms for a quarter of the unchunked MSM), so few chunks are better than many - and a chunk only has to keep
+    // the GPU busy for as long as the NEXT chunk's scalars take to arrive (0.6 ms per 2^20 over PCIe against ~2 ms of arithmetic).
+    std::vector<size_t> bound;
+    const int geo = tuning().scalar_geo;
+    if (nd == 1 && geo > 1 && tuning().taper != 0 && n >= ((size_t)1 << 22)) {
+        parts = n >= ((size_t)1 << 23) ? 3 : 2;
+        size_t wsum = 0, w = 1;
+        for (size_t i = 0; i < parts; i++, w *= (size_t)geo) wsum += w;
+        size_t acc_w = 0;
+        w = 1;
+        bound.push_back(0);
+        for (size_t i = 0; i < parts; i++, w *= (size_t)geo) {
+            acc_w += w;
+            bound.push_back(i + 1 == parts ? n : (size_t)((unsigned __int128)n * acc_w / wsum));
+        }
+    } else {
+        for (size_t i = 0; i <= parts; i++) bound.push_back(n * i / parts);
+    }
     const int ndu = (int)(parts < (size_t)nd ? parts : (size_t)nd);
     std::unique_ptr<msm_accum_t<fq_t>> acc(new msm_accum_t<fq_t>());
     std::mutex acc_mu;
@@ -257,34 +277,64 @@ static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, s
         lane_guard lg;
         lg.acquire(dev, mine.size() > 2 ? 3 : (int)mine.size());
         const size_t L = lg.lanes.size();
-        std::vector<msm_pending_t> pend(mine.size());
         size_t max_cnt = 0;
         for (size_t j = 0; j < mine.size(); j++) {
-            const size_t cnt = n * (mine[j] + 1) / parts - n * mine[j] / parts;
+            const size_t cnt = bound[mine[j] + 1] - bound[mine[j]];
             max_cnt = cnt > max_cnt ? cnt : max_cnt;
         }
+        // Several scalar chunks on this device share ONE set of buckets (the geometry of the largest chunk for all of them): every
+        // chunk adds its per-bucket partial sums to a sink - one slot per bucket, the merges chained by events across the lanes - and
+        // the reduce / fold / bit-plane tail runs once after the last chunk instead of once per chunk (2^24 pairs over 12 x 22-bit
+        // tables: four tails of ~2.5 ms over 2^21 buckets each).  tuning taper=0: every chunk runs its own tail (round 3).
+        const bool use_sink = tuning().taper != 0 && mine.size() >= 2;
+        std::vector<msm_pending_t> pend(use_sink ? 1 : mine.size());
+        int chunk_c = window_bits;
+        msm_bucket_sink_t sink;
+        std::vector<hipEvent_t> merged;
         for (size_t l = 0; l < L; l++) {
             lane_t& c = *lg.lanes[l];
             c.begin_call();
             c.scalars_tmp.ensure(max_cnt * 32 + 32);
-            c.pin.ensure(slot * ((mine.size() + L - 1) / L));
+            c.pin.ensure(slot * (use_sink ? 1 : (mine.size() + L - 1) / L));
+        }
+        if (use_sink) {
+            lane_t& c0 = *lg.lanes[0];
+            const msm_plan_t pl = msm_make_plan(max_cnt, window_bits, h->tables, h->table_bits);
+            chunk_c = pl.c;
+            sink.nbt = (uint32_t)pl.W * pl.nb;
+            sink.L = 1;
+            const size_t bytes = (size_t)sink.nbt * sizeof(g1_xyzz_mem_t);
+            c0.sink_acc.ensure(bytes);
+            sink.acc = c0.sink_acc.p;
+            HIP_TRY(hipMemsetAsync(sink.acc, 0, bytes, c0.stream));  // all-zero = the point at infinity
+            hipEvent_t ready = c0.new_event();
+            HIP_TRY(hipEventRecord(ready, c0.stream));
+            for (size_t l = 1; l < L; l++) HIP_TRY(hipStreamWaitEvent(lg.lanes[l]->stream, ready, 0));
+            for (size_t j = 0; j < mine.size(); j++) merged.push_back(lg.lanes[j % L]->new_event());
         }
         const g1_aff_mem_t* base = h->d[lg.lanes[0]->dev->logical];
         auto upload = [&](size_t j, hipStream_t st) {
             lane_t& c = *lg.lanes[j % L];
-            const size_t lo = n * mine[j] / parts, hi = n * (mine[j] + 1) / parts;
+            const size_t lo = bound[mine[j]], hi = bound[mine[j] + 1];
             if (hi > lo) HIP_TRY(hipMemcpyAsync(c.scalars_tmp.p, (const uint8_t*)scalars + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, st));
         };
         auto compute = [&](size_t j, bool prof) {
             lane_t& c = *lg.lanes[j % L];
             // slice [lo, hi) of the concatenation (range 0 | range 1)
-            const size_t lo = n * mine[j] / parts, hi = n * (mine[j] + 1) / parts;
+            const size_t lo = bound[mine[j]], hi = bound[mine[j] + 1];
             const size_t a0 = lo < n0 ? lo : n0, a1 = hi < n0 ? hi : n0;  // part inside range 0
             const size_t m0 = a1 - a0;
             const g1_aff_mem_t* b0 = base + off0 + a0;
             const g1_aff_mem_t* b1 = base + off1 + (lo > n0 ? lo - n0 : 0);
-            pend[j] = msm_run<fq_t>(c, m0 ? b0 : b1, c.scalars_tmp.as<uint4>(), hi - lo, c.pin.as<uint8_t>() + slot * (j / L), window_bits, b1,
-                                    m0 ? m0 : ~(size_t)0, scalars_montgomery, h->tables, h->n, prof, h->table_bits);
+            msm_bucket_sink_t mine_sink = sink;
+            if (use_sink) {
+                mine_sink.after = j ? merged[j - 1] : nullptr;
+                mine_sink.done = merged[j];
+            }
+            const msm_pending_t pd = msm_run<fq_t>(c, m0 ? b0 : b1, c.scalars_tmp.as<uint4>(), hi - lo, c.pin.as<uint8_t>() + (use_sink ? 0 : slot * (j / L)), chunk_c,
+                                                   b1, m0 ? m0 : ~(size_t)0, scalars_montgomery, h->tables, h->n, prof, h->table_bits, nullptr,
+                                                   use_sink ? &mine_sink : nullptr);
+            if (!use_sink) pend[j] = pd;
         };
         if (mine.size() == 1) {
             lane_t& c = *lg.lanes[0];
@@ -294,6 +344,11 @@ static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, s
             compute(0, parts == 1);
         } else {
             lane_ring_run(lg, mine.size(), upload, [&](size_t j) { compute(j, false); }, trace, t_begin);
+        }
+        if (use_sink) {  // the last merge (which waited for all earlier ones), then the one tail on lane 0
+            lane_t& c0 = *lg.lanes[0];
+            HIP_TRY(hipStreamWaitEvent(c0.stream, merged.back(), 0));
+            pend[0] = msm_tail_from_sink<fq_t>(c0, max_cnt, chunk_c, sink, c0.pin.p, h->tables, h->table_bits);
         }
         for (size_t l = 0; l < L; l++) {
             HIP_TRY(hipStreamSynchronize(lg.lanes[l]->alt));

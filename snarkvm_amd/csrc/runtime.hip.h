@@ -698,6 +698,9 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
 struct msm_bucket_sink_t {
     void* acc = nullptr;  // xyzz_mem_t<F>[nbt * L], zero-initialised (the point at infinity)
     uint32_t L = 1, slot = 0, nbt = 0;
+    // L == 1 with several lanes (2^21 buckets of a wide-window geometry: one slot per bucket, not one per lane): the merges are
+    // chained - a chunk's merge waits for `after` (the previous chunk's merge) and records `done`
+    hipEvent_t after = nullptr, done = nullptr;
 };
 // Device side of one MSM on lane `c`: d_bases = converted device bases; d_scalars = device scalars (32 B each).  Everything
 // is enqueued on the lane's stream, ending with the copy of the bit-plane sums into `host_planes` (pinned, >=
@@ -1059,8 +1062,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     if (sink) {
         // a chunk of a bigger MSM: its per-bucket partial sums join the sink; the tail runs once, after the last chunk (msm_tail_from_sink)
         phase_begin("msm_bucket_merge");
+        if (sink->after) HIP_TRY(hipStreamWaitEvent(st, sink->after, 0));
         hipLaunchKernelGGL((msm_bucket_merge_kernel<F>), dim3((nbt + 255) / 256), dim3(256), 0, st, (const xyzz_mem_t<F>*)pin, (const uint32_t*)start_in,
                            (const uint32_t*)cnt_in, (xyzz_mem_t<F>*)sink->acc, nbt, sink->L, sink->slot);
+        if (sink->done) HIP_TRY(hipEventRecord(sink->done, st));
         phase_end();
         HIP_TRY(hipGetLastError());
         pd.nplanes = 0;
@@ -1074,10 +1079,11 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
 }
 // The tail of a chunked MSM: fold + bit planes over the bucket sink (every bucket holds L partial sums, one per lane).
 template <class F>
-static msm_pending_t msm_tail_from_sink(lane_t& c, size_t chunk_n, int window_bits, const msm_bucket_sink_t& sink, void* host_planes) {
+static msm_pending_t msm_tail_from_sink(lane_t& c, size_t chunk_n, int window_bits, const msm_bucket_sink_t& sink, void* host_planes, int tables = 1,
+                                        int table_bits = 0) {
     msm_pending_t pd;
     pd.planes = host_planes;
-    const msm_plan_t pl = msm_make_plan(chunk_n, window_bits, 1, 0);
+    const msm_plan_t pl = msm_make_plan(chunk_n, window_bits, tables, table_bits);
     const uint32_t nwin = (uint32_t)pl.W, nbt = nwin * pl.nb;
     if (nbt != sink.nbt) throw hip_failure{hipErrorInvalidValue, "msm: bucket sink does not match the plan", __LINE__};
     const msm_tail_geom_t tg = msm_tail_geometry(pl, nwin, pd, 0);
@@ -1283,6 +1289,24 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
         bound.push_back(lo + len / 2 + len / 4);
         bound.push_back(npoints);
         nchunks += 2;
+    }
+    // ... and nothing can be computed before the FIRST chunk has arrived: at 2^24 the table-less arithmetic (16 digit rows per
+    // point, ~47 ms of GPU time) outlasts the 41 ms of upload, so the 5 ms the GPU idles through the first 2^21-pair upload are 5 ms
+    // of the call.  The first chunk is cut into 1/2^r, 1/2^r, 1/2^(r-1), ..., 1/2 (tuning ramp = r; pieces of >= 2^17 pairs).
+    int ramp = tuning().taper != 0 && nchunks >= 2 ? tuning().ramp : 0;
+    while (ramp > 0 && (bound[1] >> ramp) < ((size_t)1 << 17)) ramp--;
+    if (ramp > 0) {
+        const size_t len = bound[1];
+        std::vector<size_t> front;
+        size_t pos = len >> ramp;
+        front.push_back(pos);
+        for (int k = ramp; k >= 1; k--) {
+            pos += len >> k;
+            front.push_back(k == 1 ? len : pos);
+        }
+        bound.erase(bound.begin() + 1);
+        bound.insert(bound.begin() + 1, front.begin(), front.end());
+        nchunks += (size_t)ramp;
     }
     const int ndu = (int)(nchunks < (size_t)nd ? nchunks : (size_t)nd);
     std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());

@@ -30,9 +30,12 @@
 //   coalesce        1        concurrent callers of small registered MSMs are fused by an in-library dispatcher
 //   coalesce_us     40       how long a dispatcher waits for further callers when others are inside the library
 //   lanes           0        lanes a batch cycles through (0: 8 below 2^20 pairs, 3 above)
-//   msm_chunk_lg    21       pairs per upload / compute chunk of snarkvm_msm (host bases)
-//   scalar_chunk_lg 22       pairs per scalar chunk of a host-scalar MSM over registered bases
-//   taper           1        snarkvm_msm: the last chunk is cut again (1/2, 1/4, 1/4) and all chunks share one bucket sink and one tail
+//   msm_chunk_lg    20       pairs per upload / compute chunk of snarkvm_msm (host bases)
+//   scalar_chunk_lg 22       pairs per scalar chunk of a host-scalar MSM over registered bases (equal chunks: several devices, or scalar_geo=0)
+//   scalar_geo      4        one device, >= 2^22 pairs: two or three scalar chunks of sizes 1 : g [: g^2] instead of equal ones (0: off)
+//   taper           1        snarkvm_msm: the last chunk is cut again (1/2, 1/4, 1/4) and all chunks share one bucket sink and one tail; the scalar
+//                            chunks of a host-scalar MSM over registered bases share one sink as well
+//   ramp            3        snarkvm_msm: the FIRST chunk is cut into 1/2^r, 1/2^r, 1/2^(r-1), ..., 1/2 (0: off) so that the GPU starts after a short upload
 //   ring_lanes      3        lanes (streams with their own staging buffers) the chunks of one snarkvm_msm call cycle through
 //   seg             0        accumulate segment length override (0: planner)
 //   seg2            0        reduce-round group size override
@@ -57,9 +60,9 @@ struct tuning_t {
     int lazy = 1, lazy2 = 1, fused = 1, hist = 2, prefetch = 2;
     long acc_lds = 96 * 1024;
     int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
-    int msm_chunk_lg = 21, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
+    int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
-    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -71,7 +74,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo)
 #undef SV_TUNE_KEY
         return false;
     }

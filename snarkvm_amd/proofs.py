@@ -52,20 +52,21 @@ class ProofShape:
 
 class ProverKeys:
     """The static device-resident operands shared by every proof: registered G1 powers (+ the gamma powers behind them) with
-    17 precomputed tables of 15-bit windows, a registered G2 vector (same geometry), and a pool of random Fr data the proofs slice their "polynomials" from.
+    17 precomputed tables of 15-bit windows (the default; `tables` x `window_bits` must cover 254 bits), a registered G2 vector (same geometry), and a pool of random Fr data the proofs slice their "polynomials" from.
     Registration replicates the bases to every device the backend uses."""
 
-    def __init__(self, shape, seed=99):
+    def __init__(self, shape, seed=99, tables=17, window_bits=15):
         import torch
 
         self.shape = shape
+        self.geometry = (tables, window_bits)
         L = _lib.lib()
         n = shape.nmax + 8
         buf = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
         _lib.check(L.snarkvm_hip_g1_generate_bases_device(_p(buf), ctypes.c_uint64(1), ctypes.c_size_t(n)))
         self.h = ctypes.c_void_p()
-        _lib.check(L.snarkvm_hip_register_bases_windowed(ctypes.byref(self.h), _p(buf), ctypes.c_size_t(n), ctypes.c_size_t(G1_AFFINE.itemsize), 1, 17, 15))
+        _lib.check(L.snarkvm_hip_register_bases_windowed(ctypes.byref(self.h), _p(buf), ctypes.c_size_t(n), ctypes.c_size_t(G1_AFFINE.itemsize), 1, tables, window_bits))
         self.g1_host = buf.cpu().numpy().view(G1_AFFINE)
         del buf
         # G2: the generator's multiples would need Fq2 point generation on the host; a G2 vector of repeated (decoded) real
@@ -75,7 +76,7 @@ class ProverKeys:
         if shape.lg_g2:
             self.g2_host = synthetic.g2_points(1 << shape.lg_g2)
             _lib.check(L.snarkvm_hip_register_bases_g2(ctypes.byref(self.hg2), ctypes.c_void_p(self.g2_host.ctypes.data), ctypes.c_size_t(self.g2_host.shape[0]),
-                                                       ctypes.c_size_t(G2_AFFINE.itemsize), 17, 15))
+                                                       ctypes.c_size_t(G2_AFFINE.itemsize), tables, window_bits))
         self.pool_host = synthetic.random_fr_integers(shape.nmax + 4096, seed)  # any residue < r is a valid Montgomery image
         self.point = self.pool_host[7:8].copy()
 

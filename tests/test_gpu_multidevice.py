@@ -195,6 +195,51 @@ def test_chunk_ring_single_device():
     assert "RING_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+RAMP_SCRIPT = r'''
+import ctypes, sys
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+from oracle import cpu as oracle
+from snarkvm_amd import _lib, msm, plugin
+from snarkvm_amd.layout import G1_AFFINE
+from tests import util
+
+G = util.g1_generator_affine()
+nmax = (1 << 23) + 77
+buf = torch.empty(nmax * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
+_lib.check(_lib.lib().snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(nmax)))
+bases = buf.cpu().numpy().view(G1_AFFINE)
+sc = np.random.default_rng(31337).integers(0, 1 << 64, size=(nmax, 4), dtype=np.uint64)
+sc[:, 3] &= np.uint64((1 << 60) - 1)  # < 2^252 < r: canonical integers
+sc[3] = 0
+def closed(n):
+    return oracle.g1_to_affine(oracle.g1_mul(G, util.limbs(util.weighted_sum_mod_r(sc[:n], start=1), 4)))
+# snarkvm_msm, host bases + host scalars: 2 chunks (front ramp only), 2 chunks of 1.5 * 2^20, 5 chunks (ramp + taper)
+for n in ((1 << 20) + 12345, 3 * (1 << 20) + 5, 5 * (1 << 20) + 77):
+    assert util.affine_equal(oracle.g1_to_affine(plugin.msm(bases[:n], sc[:n])), closed(n)), n
+    print("ok", n)
+# registered bases (13 tables x 20-bit windows) + host scalars: one upload, two geometric scalar chunks, three - all into one bucket sink
+rb = msm.RegisteredBases(device_ptr=buf.data_ptr(), npoints=nmax, tables=13, window_bits=20)
+for n in ((1 << 21) + 3, 5 * (1 << 20) + 77, nmax):
+    assert util.affine_equal(oracle.g1_to_affine(rb.msm(sc[:n])), closed(n)), ("registered", n)
+    print("registered ok", n)
+rb.close()
+print("RAMP_OK")
+'''
+
+
+@pytest.mark.parametrize("tuning", ["ramp=3", "ramp=1,scalar_geo=2", "ramp=0,scalar_geo=0", "taper=0", "ramp=3,ring_lanes=2,scalar_chunk_lg=20,scalar_geo=0"])
+def test_chunk_ramp_and_taper_uncached(tuning):
+    """`snarkvm_msm` over host buffers with the default 2^21-pair chunks (no base cache: every call uploads): the first chunk is cut into a
+    ramp (tuning ramp), the last into 1/2, 1/4, 1/4 (taper), every chunk adds into the shared bucket sink - same group element whatever
+    the cut (runtime.hip.h::msm_host_chunked).  Then host scalars over registered bases: equal or geometric scalar chunks into one
+    sink with chained merges (api.hip::msm_registered_host_scalars)."""
+    env = dict(os.environ, SNARKVM_HIP_DEVICES="0", SNARKVM_HIP_TUNING=tuning, SNARKVM_HIP_BASE_CACHE="0")
+    r = subprocess.run([sys.executable, "-u", "-c", RAMP_SCRIPT % util.ROOT], capture_output=True, text=True, env=env, timeout=600, cwd=util.ROOT)
+    assert "RAMP_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # The A/B switches DESIGN.md quotes measurements for select other kernels / launch shapes for the same mathematics: every one of
 # them must return bit-identical results.  One subprocess per setting (the switches are read once per process).
