@@ -27,3 +27,8 @@ except Exception as e:
 PY
 timeout 1500 bash tools/profile_round.sh r04 > $O/profile_round.log 2>&1; echo "profile rc=$?"
 cp gpurun_out/r04prof/r04_* $O/ 2>/dev/null; ls $O
+# side tables of the round (profiles/r04_summary.md)
+timeout 200 python tools/reg_host_scalars.py 16 20 22 24 > $O/reg_host_scalars.md 2> $O/reg_host_scalars.err; cat $O/reg_host_scalars.md
+SNARKVM_HIP_BASE_CACHE=0 timeout 200 python tools/ffi_msm_sweep.py 16 20 22 24 > $O/ffi_msm.md 2> $O/ffi_msm.err; cat $O/ffi_msm.md
+timeout 150 python tools/bench_g2.py > $O/g2.md 2> $O/g2.err; cut -c1-60 $O/g2.md | tail -4
+g++ -std=c++17 -O2 -pthread -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bench_callers.cpp -o /tmp/bench_callers -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib && GPU_MAX_HW_QUEUES=8 timeout 120 /tmp/bench_callers 1 8 32 > $O/callers.md 2> $O/callers.err; cat $O/callers.md
