@@ -70,4 +70,58 @@ inline Projective msm(const Affine* points, size_t npoints_available, const Scal
     return ret;
 }
 
+// ---- extensions (part 2 of rust/snarkvm-algorithms-hip/src/lib.rs: `resident`) -------------------------------------------
+// Deferred-synchronisation scope (snarkvm_hip.h: snarkvm_hip_scope_begin / _end): device-resident calls of this thread between
+// construction and destruction are enqueued on one stream and waited for once.  Not copyable; end() reports errors, the
+// destructor swallows them (like the Rust guard's Drop).
+class Scope {
+public:
+    explicit Scope(const void* d_any = nullptr) { check(snarkvm_hip_scope_begin(d_any)); }
+    Scope(const Scope&) = delete;
+    Scope& operator=(const Scope&) = delete;
+    void end() {
+        if (open_) {
+            open_ = false;
+            check(snarkvm_hip_scope_end());
+        }
+    }
+    ~Scope() {
+        if (open_) {
+            RustError e = snarkvm_hip_scope_end();
+            if (e.message) std::free(e.message);
+        }
+    }
+
+private:
+    bool open_ = true;
+};
+
+// Registered bases (an SRS resident in HBM with precomputed window tables): register once, commit per call.  `tables` x
+// `window_bits` must cover 254 bits (17 x 15 for proof-sized MSMs, 12 x 22 at 2^24).  Concurrent commit() calls of proof size
+// are fused inside the library (runtime.hip.h::msm_coalesced).
+template <class Affine, class Projective>
+class RegisteredBases {
+public:
+    RegisteredBases(const Affine* bases, size_t n, bool on_device, int tables, int window_bits) : n_(n) {
+        check(snarkvm_hip_register_bases_windowed(&h_, bases, n, sizeof(Affine), on_device ? 1 : 0, tables, window_bits));
+    }
+    RegisteredBases(const RegisteredBases&) = delete;
+    RegisteredBases& operator=(const RegisteredBases&) = delete;
+    ~RegisteredBases() {
+        if (h_) snarkvm_hip_free_bases(h_);
+    }
+    size_t size() const { return n_; }
+    // sum_i scalars[i] * bases[offset + i]  (+ sum_j scalars[n + j] * bases[offset1 + j] when n1 > 0: KZG10's hiding term)
+    Projective commit(size_t offset, size_t n, const void* scalars, bool scalars_on_device, bool scalars_montgomery = false, size_t offset1 = 0,
+                      size_t n1 = 0) const {
+        Projective out;
+        check(snarkvm_hip_msm_registered_ex(&out, h_, offset, n, offset1, n1, scalars, scalars_on_device ? 1 : 0, scalars_montgomery ? 1 : 0, 0));
+        return out;
+    }
+
+private:
+    snarkvm_hip_bases_t* h_ = nullptr;
+    size_t n_;
+};
+
 }  // namespace snarkvm_hip
