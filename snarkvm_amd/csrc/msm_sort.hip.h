@@ -423,10 +423,12 @@ __device__ __forceinline__ uint32_t fused_group_index(uint32_t key, uint32_t B1,
 // chunk column sums: csum[(q * J + j) * nchunks + chunk] = sum over the chunk's tiles of cnt[t][key]
 static __global__ void __launch_bounds__(FUSED_THREADS) fused_chunk_sums_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ csum, uint32_t ntiles,
                                                                          uint32_t nchunks, uint32_t keys, uint32_t B1, uint32_t W, uint32_t J) {
+    // grid (chunks, key blocks): 128 chunks alone would leave half of the CUs without a workgroup (78 us for 50 MB of counters)
     const uint32_t ch = blockIdx.x;
     const uint32_t t0 = ch * FUSED_CHUNK, t1 = (t0 + FUSED_CHUNK < ntiles) ? t0 + FUSED_CHUNK : ntiles;
-    for (uint32_t key = threadIdx.x; key < keys; key += FUSED_THREADS) {
+    for (uint32_t key = blockIdx.y * FUSED_THREADS + threadIdx.x; key < keys; key += gridDim.y * FUSED_THREADS) {
         uint32_t s = 0;
+#pragma unroll 8
         for (uint32_t t = t0; t < t1; t++) s += cnt[(size_t)t * keys + key];
         csum[(size_t)fused_group_index(key, B1, W, J) * nchunks + ch] = s;
     }
@@ -438,10 +440,11 @@ static __global__ void __launch_bounds__(FUSED_THREADS) fused_tile_offsets_kerne
                                                                            uint32_t B1, uint32_t W, uint32_t J) {
     const uint32_t ch = blockIdx.x;
     const uint32_t t0 = ch * FUSED_CHUNK, t1 = (t0 + FUSED_CHUNK < ntiles) ? t0 + FUSED_CHUNK : ntiles;
-    for (uint32_t key = threadIdx.x; key < keys; key += FUSED_THREADS) {
+    for (uint32_t key = blockIdx.y * FUSED_THREADS + threadIdx.x; key < keys; key += gridDim.y * FUSED_THREADS) {
         const uint32_t g = fused_group_index(key, B1, W, J);
         uint32_t run = choff[(size_t)g * nchunks + ch];
         if (ch == 0 && g % J == 0) binstart[g / J] = run;
+#pragma unroll 8
         for (uint32_t t = t0; t < t1; t++) {
             const size_t idx = (size_t)t * keys + key;
             const uint32_t c = cnt[idx];
@@ -449,7 +452,7 @@ static __global__ void __launch_bounds__(FUSED_THREADS) fused_tile_offsets_kerne
             run += c;
         }
     }
-    if (ch == 0 && threadIdx.x == 0) {  // one past the last group: the total number of entries
+    if (ch == 0 && blockIdx.y == 0 && threadIdx.x == 0) {  // one past the last group: the total number of entries
         const size_t last = (size_t)W * B1 * J * nchunks - 1;
         binstart[W * B1] = choff[last] + csum[last];
     }
@@ -685,8 +688,10 @@ static __global__ void __launch_bounds__(1024) radix_colscan2_seg_kernel(const u
     if (a > t1) a = t1;
     if (b > t1) b = t1;
     uint32_t s = 0;
-    if (key < B2)
-        for (uint32_t t2 = a; t2 < b; t2++) s += counts2[(size_t)t2 * B2 + key];
+    if (key < B2) {
+#pragma unroll 8
+        for (uint32_t t2 = a; t2 < b; t2++) s += counts2[(size_t)t2 * B2 + key];  // independent loads: keep several in flight
+    }
     part[sl][key] = s;
     __syncthreads();
     uint32_t run = 0, total = 0;
@@ -696,6 +701,7 @@ static __global__ void __launch_bounds__(1024) radix_colscan2_seg_kernel(const u
         total += v;
     }
     if (key < B2) {
+#pragma unroll 8
         for (uint32_t t2 = a; t2 < b; t2++) {
             const size_t idx = (size_t)t2 * B2 + key;
             const uint32_t cnt = counts2[idx];

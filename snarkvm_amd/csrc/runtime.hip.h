@@ -880,10 +880,11 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
 #undef SV_FUSED_HIST
             phase_end();
             phase_begin("msm_sort_level1");
-            hipLaunchKernelGGL(fused_chunk_sums_kernel, dim3(nchunks), dim3(FUSED_THREADS), 0, st, (const uint32_t*)counts1, csum, ntiles, nchunks, keys, B1,
+            const unsigned key_blocks = (keys + FUSED_THREADS - 1) / FUSED_THREADS;
+            hipLaunchKernelGGL(fused_chunk_sums_kernel, dim3(nchunks, key_blocks), dim3(FUSED_THREADS), 0, st, (const uint32_t*)counts1, csum, ntiles, nchunks, keys, B1,
                                (uint32_t)pl.W, (uint32_t)pl.J);
             exclusive_scan_u32(st, csum, choff, ngroups, c.scan_tmp.as<uint32_t>());
-            hipLaunchKernelGGL(fused_tile_offsets_kernel, dim3(nchunks), dim3(FUSED_THREADS), 0, st, (const uint32_t*)counts1, (const uint32_t*)choff,
+            hipLaunchKernelGGL(fused_tile_offsets_kernel, dim3(nchunks, key_blocks), dim3(FUSED_THREADS), 0, st, (const uint32_t*)counts1, (const uint32_t*)choff,
                                (const uint32_t*)csum, off1, c.rbinstart.as<uint32_t>(), ntiles, nchunks, keys, B1, (uint32_t)pl.W, (uint32_t)pl.J);
 #define SV_FUSED_SCATTER(CB)                                                                                                                      \
     case CB:                                                                                                                                      \
