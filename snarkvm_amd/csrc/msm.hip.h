@@ -654,8 +654,10 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
     const uint32_t nlo = 1u << m, nhi = 1u << hb;
     const uint32_t w = blockIdx.y;
     const uint32_t kbase = w << (m + hb);
-    const bool column = blockIdx.x < nlo;
-    const uint32_t fixed = column ? blockIdx.x : blockIdx.x - nlo;
+    // rows first: a row spans 2^m buckets, a column 2^hb <= 2^m - with an odd number of index bits a row is twice the work of a column, and
+    // the workgroups that start last should be the short ones (2^24 x 22-bit windows: 3 072 workgroups for 2 048 resident waves)
+    const bool column = blockIdx.x >= nhi;
+    const uint32_t fixed = column ? blockIdx.x - nhi : blockIdx.x;
     if (!column && fixed == 0) return;
     if (!FLAT) {
         xyzz_t<F> acc = xyzz_t<F>::inf();

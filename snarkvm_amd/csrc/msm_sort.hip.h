@@ -549,6 +549,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) radix_scatter1_fused_kernel(con
         __syncthreads();
         const uint32_t last = FUSED_G * B1 - 1;
         const uint32_t total = lstart[last] + lcount[last];
+#pragma unroll 4
         for (uint32_t pos = threadIdx.x; pos < total; pos += FUSED_THREADS) {
             const uint32_t lk = skey_[pos];
             const size_t dst = (size_t)gbase[lk] + (pos - lstart[lk]);
@@ -630,20 +631,32 @@ template <class RIN>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist2_kernel(const RIN* __restrict__ l1, const uint32_t* __restrict__ binstart,
                                                                    const uint32_t* __restrict__ tile2_start, uint32_t* __restrict__ counts2,
                                                                    uint32_t nbins, int LB, int shift) {
-    __shared__ uint32_t hist[128];
+    // four private copies of the histogram (copy = lane & 3, interleaved): 64 lanes into <= 128 keys serialise on equal keys, as in the
+    // level-1 kernel (radix_hist1_wide_kernel); all of a thread's loads are issued before its first atomic
+    __shared__ uint32_t hist[128 * 4];
     const uint32_t t2 = blockIdx.x;
     if (t2 >= tile2_start[nbins]) return;
     const uint32_t B2 = 1u << LB;
     const uint32_t q = find_bucket(tile2_start, nbins, t2);
     const uint32_t lt = t2 - tile2_start[q];
-    for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 4 * B2; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const uint32_t lo = binstart[q] + lt * SORT_TILE;
     uint32_t hi = lo + SORT_TILE;
     if (hi > binstart[q + 1]) hi = binstart[q + 1];
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&hist[((uint32_t)l1[i] >> shift) & (B2 - 1)], 1u);
+    constexpr int PER = SORT_TILE / SORT_THREADS;
+    uint32_t ll[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = lo + threadIdx.x + (uint32_t)k * SORT_THREADS;
+        ll[k] = i < hi ? (uint32_t)l1[i] : 0xffffffffu;
+    }
+    const uint32_t copy = threadIdx.x & 3u;
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (ll[k] != 0xffffffffu) atomicAdd(&hist[(((ll[k] >> shift) & (B2 - 1)) << 2) | copy], 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) counts2[(size_t)t2 * B2 + i] = hist[i];
+    for (uint32_t i = threadIdx.x; i < B2; i += blockDim.x) counts2[(size_t)t2 * B2 + i] = hist[4 * i] + hist[4 * i + 1] + hist[4 * i + 2] + hist[4 * i + 3];
 }
 // ---- per bucket k = q * B2 + low: exclusive prefix of its counts over the tiles of bin q + bucket size
 static __global__ void radix_colscan2_kernel(const uint32_t* __restrict__ counts2, uint32_t* __restrict__ off2,
@@ -778,6 +791,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter2_kernel(const uint
     }
     __syncthreads();
     const uint32_t total = hi - lo;
+#pragma unroll 4
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
         const uint32_t key = slow_[pos];
         const size_t dst = (size_t)gbase[key] + (pos - lstart[key]);
