@@ -319,6 +319,8 @@ int snarkvm_hip_selftest_g1_finish(const void *planes_projective, const int32_t 
  * chained mixed additions (doublings, cancellations and restarts from infinity included) compared coordinate by coordinate,
  * then the field routines at the edges of their operand ranges.  0 = identical; > 0: first differing step; < 0: field case. */
 int snarkvm_hip_selftest_fq_lazy(uint64_t seed, int iters);
+/* host only: the tail arithmetic of a G1 MSM (ffl.hip.h::fqz_t under the generic addition / doubling laws) against the exact one */
+int snarkvm_hip_selftest_g1_lazy_tail(uint64_t seed, int iters);
 /* The lazy Fq2 arithmetic of the G2 accumulate kernel (csrc/ffl2.hip.h) against the exact arithmetic, on the host: `iters` chained
  * mixed additions of +- points[k] (npoints >= 2 Rust G2Affine records on the curve, 200-byte stride), doublings, cancellations
  * and restarts from infinity included, every coordinate compared after every step; products, squares and the raw partial-sum image

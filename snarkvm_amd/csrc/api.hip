@@ -303,7 +303,7 @@ static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, s
             chunk_c = pl.c;
             sink.nbt = (uint32_t)pl.W * pl.nb;
             sink.L = 1;
-            const size_t bytes = (size_t)sink.nbt * sizeof(g1_xyzz_mem_t);
+            const size_t bytes = (size_t)sink.nbt * msm_partial_bytes<fq_t>();
             c0.sink_acc.ensure(bytes);
             sink.acc = c0.sink_acc.p;
             HIP_TRY(hipMemsetAsync(sink.acc, 0, bytes, c0.stream));  // all-zero = the point at infinity
@@ -807,6 +807,77 @@ int snarkvm_hip_selftest_fq_lazy(uint64_t seed, int iters) {
         for (int i = 0; i < 13; i++)
             if (back.v[i] != wide.v[i]) return -(100000 + t);
     }
+    return 0;
+}
+// The lazy arithmetic behind field-like operators (ffl.hip.h::fqz_t: the tail of a G1 MSM under tuning lazy_tail) against the exact
+// one, on the host: two chains over the generic xyzz_t<F> - F = fq_t and F = fqz_t - fed the same GENERAL points (multiples of the
+// generator with random zz / zzz scalings, so that the full addition law runs, not the mixed one), with repeated points (the doubling
+// inside the addition), negatives (infinity), restarts and explicit doublings; every coordinate of the lazy accumulator is converted and
+// compared after every step.  Returns 0, or the (1-based) step of the first mismatch.
+int snarkvm_hip_selftest_g1_lazy_tail(uint64_t seed, int iters) {
+    uint32_t xw[12], yw[12];
+    memcpy(xw, G1_GEN_X, 48);
+    memcpy(yw, G1_GEN_Y, 48);
+    const g1_aff_t g{fq_t::unpack(xw).from_mem_mont(), fq_t::unpack(yw).from_mem_mont()};
+    std::vector<g1_xyzz_t> pool;
+    g1_xyzz_t run = g1_xyzz_t::inf();
+    for (int k = 0; k < 48; k++) {
+        run.add_affine(g);
+        pool.push_back(run);
+    }
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto to_lazy = [](const g1_xyzz_t& p) {
+        xyzz_t<fqz_t> r = xyzz_t<fqz_t>::inf();
+        if (!p.is_inf()) r = {{fql_t::from_exact(p.x)}, {fql_t::from_exact(p.y)}, {fql_t::from_exact(p.zz)}, {fql_t::from_exact(p.zzz)}};
+        return r;
+    };
+    g1_xyzz_t exact = g1_xyzz_t::inf();
+    xyzz_t<fqz_t> lazy = xyzz_t<fqz_t>::inf();
+    g1_xyzz_t prev = g1_xyzz_t::inf();
+    for (int it = 0; it < iters; it++) {
+        const uint64_t r = next();
+        g1_xyzz_t p = pool[r % 48];
+        // another representative of the same point: (l^2 X, l^3 Y, l^2 ZZ, l^3 ZZZ)
+        fq_t l = fq_t::zero();
+        for (int i = 0; i < 12; i++) l.v[i] = (uint32_t)(next() & LIMB_MASK);
+        l.v[0] |= 1;
+        const fq_t l2 = l.sqr(), l3 = l2 * l;
+        p = {p.x * l2, p.y * l3, p.zz * l2, p.zzz * l3};
+        if ((r >> 8) & 1) p.y = p.y.neg();
+        const int mode = (int)((r >> 16) % 16);
+        if (mode == 0) p = prev;                                  // the same representative again
+        if (mode == 1) p = {prev.x, prev.y.neg(), prev.zz, prev.zzz};  // its negative
+        if (mode == 2) {                                         // restart: acc = P, then (next step, mode 0 or 3) P again -> doubling
+            exact = g1_xyzz_t::inf();
+            lazy = xyzz_t<fqz_t>::inf();
+        }
+        if (mode == 3) p = exact;                                // acc + acc: the doubling inside the addition
+        if (mode == 4) {                                         // explicit doubling
+            exact = exact.dbl();
+            lazy = lazy.dbl();
+        } else {
+            prev = p;
+            exact.add(p);
+            lazy.add(to_lazy(p));
+        }
+        if (lazy.is_inf() != exact.is_inf()) return it + 1;
+        if (!exact.is_inf() && (lazy.x.to_exact() != exact.x || lazy.y.to_exact() != exact.y || lazy.zz.to_exact() != exact.zz || lazy.zzz.to_exact() != exact.zzz))
+            return it + 1;
+        // the memory image the tail kernels exchange
+        xyzz_mem_t<fqz_t> m;
+        store_xyzz<fqz_t>(&m, lazy);
+        lazy = load_xyzz<fqz_t>(&m);
+    }
+    // a representative of zero other than 0 is still the point at infinity / an equal coordinate: q and -q as limbs
+    fqz_t zq;
+    for (int i = 0; i < 13; i++) zq.a.v[i] = FqL::MOD[i];
+    if (!zq.is_zero() || !zq.neg().is_zero() || !(zq + zq).is_zero() || (zq + fqz_t::one()).is_zero()) return -1;
     return 0;
 }
 // The host-side finish of an MSM (runtime.hip.h msm_accum_t) on its own, no device needed: out (144 B) = sum_i 2^pos[i] *

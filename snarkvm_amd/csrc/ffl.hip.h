@@ -437,4 +437,58 @@ struct xyzz_lazy_t {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same arithmetic behind field-like operators, for the TAIL of a G1 MSM (round 4; tuning lazy_tail): the reduce rounds, the
+// bucket merge, the fold and the bit-plane kernels are ec.hip.h's generic xyzz_t<F> (add-2008-s, dbl-2008-s-1) and msm.hip.h's
+// quad-cooperative addition instantiated with F = fqz_t, reading the raw partial sums of the accumulate kernel as they are (no
+// conversion pass) and leaving raw bit planes that the host converts (<= ~270 points).
+//   * every operator returns a NORMALISED value (sums and differences propagate their carries: 13 steps, no conditional
+//     subtraction), so every product is normalised x normalised;
+//   * ranges (multiples of q; the int32 top limb holds up to 4.7 q, q / 2^348 = 0.84 * 2^29): products in (-1.002, 0.002);
+//     P = U2 - U1, R = S2 - S1 in (-1.004, 1.004); X3 = R^2 - PPP - 2 Q in (-1.01, 3.01); Q - X3 in (-4.02, 1.02);
+//     Y3 (one two-product reduction) in (-0.002, 1.002), as the difference of two products (quad_add) in (-1.004, 1.004);
+//     doubling: 3 X^2 in (-3.006, 0.006), S - X3 in (-3.01, 1.01) - all inside what xyzz_lazy_t::madd feeds the same routines;
+//   * x == 0 (mod q) is decided on the low limb first (q = 1 mod 2^29: k q = k mod 2^29, |k| <= 8 here) and exactly only when that
+//     filter passes (17 * 2^-29 of the random cases); the point at infinity is zz = 0 as 13 zero limbs (how the accumulate kernel
+//     writes an empty partial sum, how a zeroed sink starts) or any other representative of 0.
+// ------------------------------------------------------------------------------------------------------------------------
+struct fqz_t {
+    fql_t a;
+    struct mem_t {
+        uint32_t w[13];
+    };
+    static constexpr int N = 13;
+
+    SV_HD static fqz_t zero() { return {fql_t::zero()}; }
+    SV_HD static fqz_t one() { return {xyzz_lazy_t::one()}; }
+    SV_HD static fqz_t load(const mem_t* p) {
+        fqz_t r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.a.v[i] = (int32_t)p->w[i];
+        return r;
+    }
+    SV_HD void store(mem_t* p) const {
+#pragma unroll
+        for (int i = 0; i < N; i++) p->w[i] = (uint32_t)a.v[i];
+    }
+    SV_HD fqz_t operator*(const fqz_t& b) const { return {fql_t::mul(a, b.a)}; }
+    SV_HD fqz_t sqr() const { return {fql_t::sqr(a)}; }
+    SV_HD fqz_t operator+(const fqz_t& b) const { return {(a + b.a).normalized()}; }
+    SV_HD fqz_t operator-(const fqz_t& b) const { return {(a - b.a).normalized()}; }
+    SV_HD fqz_t dbl() const { return {(a + a).normalized()}; }
+    SV_HD fqz_t neg() const { return {(fql_t::zero() - a).normalized()}; }
+    SV_HD static fqz_t diff_of_products(const fqz_t& x, const fqz_t& y, const fqz_t& z, const fqz_t& w) {
+        return {fql_t::diff_of_products(x.a, y.a, z.a, w.a)};
+    }
+    SV_HD fq_t to_exact() const { return a.to_exact(); }
+    SV_HD bool is_zero() const {
+        int32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) any |= a.v[i];
+        if (any == 0) return true;
+        if ((((uint32_t)a.v[0] + 8u) & fql_t::MASK) > 16u) return false;
+        return a.to_exact().is_zero();
+    }
+};
+
 }  // namespace sv

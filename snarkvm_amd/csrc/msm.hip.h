@@ -452,6 +452,13 @@ __device__ __forceinline__ fq_t shfl_xor_field(const fq_t& a, int mask) {
     return r;
 }
 __device__ __forceinline__ fq2_t shfl_xor_field(const fq2_t& a, int mask) { return {shfl_xor_field(a.c0, mask), shfl_xor_field(a.c1, mask)}; }
+__device__ __forceinline__ fqz_t shfl_xor_field(const fqz_t& a, int mask) {
+    fqz_t r;
+#pragma unroll
+    for (int i = 0; i < fqz_t::N; i++) r.a.v[i] = __shfl_xor(a.a.v[i], mask);
+    SV_OPAQUE_13(r.a.v);  // see quad_perm_field below
+    return r;
+}
 template <class F>
 __device__ __forceinline__ xyzz_t<F> shfl_xor_point(const xyzz_t<F>& a, int mask) {
     return {shfl_xor_field(a.x, mask), shfl_xor_field(a.y, mask), shfl_xor_field(a.zz, mask), shfl_xor_field(a.zzz, mask)};
@@ -469,6 +476,19 @@ template <int CTRL>
 __device__ __forceinline__ fq2_t quad_perm_field(const fq2_t& a) {
     return {quad_perm_field<CTRL>(a.c0), quad_perm_field<CTRL>(a.c1)};
 }
+// The permuted limbs pass through empty asm statements (ffl.hip.h: SV_OPAQUE_13) before anything consumes them.  Without that the
+// compiler folds the DPP move into the consuming instruction (v_subrev_u32_dpp ... quad_perm:[3,3,3,3] in Y3 = bcast<2>(m4) -
+// bcast<3>(m4) of quad_add), and on gfx950 / ROCm 7.2 that folded form computed with the lane's OWN limb when its other operand had
+// just been written by a DPP move: Y3 = m4[2] - m4[own lane] on three lanes of every quad (tools/exp/lazytail_dev.hip prints it).
+// The exact arithmetic never hits the pattern: its subtractions are borrow chains, not single limb operations.
+template <int CTRL>
+__device__ __forceinline__ fqz_t quad_perm_field(const fqz_t& a) {
+    fqz_t r;
+#pragma unroll
+    for (int i = 0; i < fqz_t::N; i++) r.a.v[i] = __builtin_amdgcn_mov_dpp(a.a.v[i], CTRL, 0xf, 0xf, true);
+    SV_OPAQUE_13(r.a.v);
+    return r;
+}
 template <int L, class F>
 __device__ __forceinline__ F quad_bcast(const F& a) {
     return quad_perm_field<L * 0x55>(a);
@@ -481,6 +501,12 @@ __device__ __forceinline__ fq_t select_field(bool c, const fq_t& a, const fq_t& 
 }
 __device__ __forceinline__ fq2_t select_field(bool c, const fq2_t& a, const fq2_t& b) {
     return {select_field(c, a.c0, b.c0), select_field(c, a.c1, b.c1)};
+}
+__device__ __forceinline__ fqz_t select_field(bool c, const fqz_t& a, const fqz_t& b) {
+    fqz_t r;
+#pragma unroll
+    for (int i = 0; i < fqz_t::N; i++) r.a.v[i] = c ? a.a.v[i] : b.a.v[i];
+    return r;
 }
 template <class F>
 __device__ __forceinline__ xyzz_t<F> select_point(bool c, const xyzz_t<F>& a, const xyzz_t<F>& b) {

@@ -594,23 +594,39 @@ struct msm_pending_t {
     int c = 0, m = 0;
     bool folded = false;
     int ninst = 0;  // fused multi-instance run: window w IS instance w (every instance has ONE bucket window at bit position 0)
+    bool lazy = false;  // G1: the planes are raw lazy points (xyzz_mem_t<fqz_t>, 208 B each; tuning lazy_tail) - msm_collect converts them
     int pos(int idx) const {
         const int tw = idx / nbits, j = idx % nbits;
         if (ninst) return (tw & 1) * m + j;
         return folded ? c * (tw >> 1) + (tw & 1) * m + j : c * tw + j;
     }
 };
+// bytes of one bit plane / partial sum in the staging areas: the larger of the exact and the raw lazy image (G1: 192 / 208 B)
+template <class F>
+static constexpr size_t msm_point_bytes() {
+    return sizeof(F) == sizeof(fq_t) && sizeof(xyzz_mem_t<fqz_t>) > sizeof(xyzz_mem_t<F>) ? sizeof(xyzz_mem_t<fqz_t>) : sizeof(xyzz_mem_t<F>);
+}
+// plane i of a pending run as an exact point (a raw lazy plane: four products by 2^377 on the host)
+template <class F>
+static xyzz_t<F> msm_plane(const msm_pending_t& pd, int i) {
+    if constexpr (sizeof(F) == sizeof(fq_t)) {
+        if (pd.lazy) {
+            const xyzz_t<fqz_t> z = load_xyzz<fqz_t>(&((const xyzz_mem_t<fqz_t>*)pd.planes)[i]);
+            if (z.is_inf()) return xyzz_t<F>::inf();
+            return {z.x.to_exact(), z.y.to_exact(), z.zz.to_exact(), z.zzz.to_exact()};
+        }
+    }
+    return load_xyzz<F>(&((const xyzz_mem_t<F>*)pd.planes)[i]);
+}
 template <class F>
 static void msm_collect(msm_accum_t<F>& acc, const msm_pending_t& pd) {
-    const xyzz_mem_t<F>* pl = (const xyzz_mem_t<F>*)pd.planes;
-    for (int i = 0; i < pd.nplanes; i++) acc.add(pd.pos(i), load_xyzz<F>(&pl[i]));
+    for (int i = 0; i < pd.nplanes; i++) acc.add(pd.pos(i), msm_plane<F>(pd, i));
 }
 // the planes of instance `inst` of a fused multi-instance run (2 * nbits consecutive planes)
 template <class F>
 static void msm_collect_inst(msm_accum_t<F>& acc, const msm_pending_t& pd, int inst) {
-    const xyzz_mem_t<F>* pl = (const xyzz_mem_t<F>*)pd.planes;
     const int per = 2 * pd.nbits;
-    for (int i = inst * per; i < (inst + 1) * per; i++) acc.add(pd.pos(i), load_xyzz<F>(&pl[i]));
+    for (int i = inst * per; i < (inst + 1) * per; i++) acc.add(pd.pos(i), msm_plane<F>(pd, i));
 }
 // host description of a fused multi-instance run (msm_sort.hip.h: msm_inst_t)
 struct msm_multi_t {
@@ -630,6 +646,17 @@ static size_t msm_acc_lds() {
 }
 template <class F>
 static bool msm_lazy_on();
+// G1: the tail (reduce rounds, bucket merge, fold, bit planes) runs on the lazy arithmetic too (ffl.hip.h::fqz_t) and reads the accumulate
+// kernel's raw partial sums as they are
+template <class F>
+static bool msm_lazy_tail_on() {
+    return sizeof(F) == sizeof(fq_t) && msm_lazy_on<F>() && tuning().lazy_tail != 0;
+}
+// bytes of one partial sum / sink slot / plane on the device for the arithmetic the tail of an MSM over F runs on
+template <class F>
+static size_t msm_partial_bytes() {
+    return msm_lazy_tail_on<F>() ? sizeof(xyzz_mem_t<fqz_t>) : sizeof(xyzz_mem_t<F>);
+}
 // Tail geometry of an MSM with `nwin` bucket windows of 2^(c - 1) buckets: windows of >= 2^11 buckets are first folded into two tail
 // windows of 2^fold_m / 2^fold_hb - 1 entries; so are smaller windows when there are too few (window, bit) pairs to spread an
 // unfolded tail over the chip (registered tables below 4 096 points: 2 windows x 8 bits would be 16 workgroups walking every
@@ -702,12 +729,53 @@ struct msm_bucket_sink_t {
     // chained - a chunk's merge waits for `after` (the previous chunk's merge) and records `done`
     hipEvent_t after = nullptr, done = nullptr;
 };
+// Steps 6.-9. of msm_run on the tail arithmetic T (F itself, or fqz_t for a G1 MSM whose accumulate kernel left raw lazy partial sums):
+// reduce rounds (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ..., then either the merge into a bucket sink (a chunk of a
+// bigger MSM; pd.nplanes = 0) or fold -> bit planes -> copy to `host_planes`.
+template <class T, class PB, class PE>
+static void msm_reduce_and_tail(lane_t& c, const msm_plan_t& pl, const msm_tail_geom_t& tg, uint32_t nwin, uint32_t nbt, int rounds, size_t T0_max, size_t T1_max,
+                                const msm_bucket_sink_t* sink, msm_pending_t& pd, void* host_planes, bool flat, PB&& phase_begin, PE&& phase_end) {
+    hipStream_t st = c.stream;
+    phase_begin("msm_reduce_partials");
+    uint32_t *cnt_in = c.cnt_a.as<uint32_t>(), *cnt_out = c.cnt_b.as<uint32_t>();
+    uint32_t *start_in = c.start_a.as<uint32_t>(), *start_out = c.start_b.as<uint32_t>();
+    xyzz_mem_t<T> *pin = c.part_a.as<xyzz_mem_t<T>>(), *pout = c.part_b.as<xyzz_mem_t<T>>();
+    size_t T_in_max = T0_max;
+    for (int r = 0; r < rounds; r++) {
+        size_t T_out_max = T_in_max / pl.S2 + nbt + 1;
+        if (T_out_max > T1_max) T_out_max = T1_max;  // both ping-pong buffers hold >= T1_max partials
+        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, cnt_in, cnt_out, nbt, pl.S2);
+        exclusive_scan_u32(st, cnt_out, start_out, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
+        hipLaunchKernelGGL((msm_reduce_kernel<T>), dim3((unsigned)((T_out_max + 255) / 256)), dim3(256), 0, st, pin, start_in, cnt_in, start_out, pout, nbt,
+                           pl.S2);
+        std::swap(cnt_in, cnt_out);
+        std::swap(start_in, start_out);
+        std::swap(pin, pout);
+        T_in_max = T_out_max;
+    }
+    phase_end();
+    if (sink) {
+        // a chunk of a bigger MSM: its per-bucket partial sums join the sink; the tail runs once, after the last chunk (msm_tail_from_sink)
+        phase_begin("msm_bucket_merge");
+        if (sink->after) HIP_TRY(hipStreamWaitEvent(st, sink->after, 0));
+        hipLaunchKernelGGL((msm_bucket_merge_kernel<T>), dim3((nbt + 255) / 256), dim3(256), 0, st, (const xyzz_mem_t<T>*)pin, (const uint32_t*)start_in,
+                           (const uint32_t*)cnt_in, (xyzz_mem_t<T>*)sink->acc, nbt, sink->L, sink->slot);
+        if (sink->done) HIP_TRY(hipEventRecord(sink->done, st));
+        phase_end();
+        HIP_TRY(hipGetLastError());
+        pd.nplanes = 0;
+        return;
+    }
+    phase_begin("msm_bucket_reduce");
+    msm_tail_launch<T>(c, pl, tg, nwin, nbt, pin, start_in, cnt_in, flat, pd, host_planes);
+    phase_end();
+}
 // Device side of one MSM on lane `c`: d_bases = converted device bases; d_scalars = device scalars (32 B each).  Everything
 // is enqueued on the lane's stream, ending with the copy of the bit-plane sums into `host_planes` (pinned, >=
 // msm_plane_bytes<F>(...)); the caller synchronises the stream and runs msm_collect / msm_accum_t::finish.
 template <class F>
 static size_t msm_plane_bytes() {
-    return (size_t)MSM_MAX_POS * sizeof(xyzz_mem_t<F>);  // upper bound on tail windows * bits
+    return (size_t)MSM_MAX_POS * msm_point_bytes<F>();  // upper bound on tail windows * bits
 }
 template <class F>
 static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* host_planes, int window_bits,
@@ -765,13 +833,15 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
     const size_t slack = (size_t)nbt / 32 + 64;
     const size_t T0_max = E_max / pl.S + nbt + 1 + slack;
     const size_t T1_max = T0_max / pl.S2 + nbt + 1 + slack;
-    c.part_a.ensure(T0_max * sizeof(xyzz_mem_t<F>));
-    c.part_b.ensure(T1_max * sizeof(xyzz_mem_t<F>));
+    const bool ltail = msm_lazy_tail_on<F>();
+    pd.lazy = ltail;
+    c.part_a.ensure(T0_max * msm_partial_bytes<F>());
+    c.part_b.ensure(T1_max * msm_partial_bytes<F>());
     const int K = pl.c - 1;  // bucket-index bits
     const msm_tail_geom_t tg = msm_tail_geometry(pl, nwin, pd, mu ? (int)mu->K : 0);
     if (mu && (size_t)pd.nplanes > mu->plane_capacity) throw hip_failure{hipErrorInvalidValue, "msm: plane staging of the fused group too small", __LINE__};
     if (sink && (mu || sink->nbt != nbt)) throw hip_failure{hipErrorInvalidValue, "msm: bucket sink does not match the plan", __LINE__};
-    c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
+    c.planes.ensure((size_t)pd.nplanes * msm_partial_bytes<F>());
 
     // 1. scalar read.  Wide windows: fused with the level-1 partition below (the digits never exist in memory); otherwise the
     // stand-alone digit kernel writes the [rows][n] digit matrix.
@@ -999,7 +1069,10 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                 if (msm_lazy_on<F>()) {
                     // raw partial sums (208 B each) go to their own buffer; the dense conversion pass fills part_a for the tail
                     const size_t tmax = nthreads + nbt + 1;  // every thread leaves >= 1 partial sum, one more per bucket boundary inside its segment
-                    c.part_raw.ensure(tmax * sizeof(g1_lazy_partial_t));
+                    // lazy tail: the raw partial sums ARE the tail's input (part_a holds T0_max >= tmax of them); else they go to their own
+                    // buffer and the dense conversion pass fills part_a
+                    if (!ltail) c.part_raw.ensure(tmax * sizeof(g1_lazy_partial_t));
+                    g1_lazy_partial_t* raw_out = ltail ? c.part_a.as<g1_lazy_partial_t>() : c.part_raw.as<g1_lazy_partial_t>();
                     // One workgroup per CU (a dynamic LDS request no second workgroup fits beside) = one accumulate wave per SIMD with half
                     // of the register file and ~64 KB of LDS left free: single-round grids always; multi-round grids when
                     // tuning acc_one_wg is set - the sort and tail kernels of the NEXT instance of a pipelined batch (another
@@ -1008,13 +1081,13 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                     if ((single_round && prefetch_ok && prefetch_env) || prefetch_env >= 2)
                         hipLaunchKernelGGL((msm_accumulate_lazy_kernel<true>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256),
                                            (single_round && prefetch_ok) || one_wg_env ? msm_acc_lds() : 0, st, vbase, c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(),
-                                           c.part_raw.as<g1_lazy_partial_t>(), nbt, pl.S, dbg_mask);
+                                           raw_out, nbt, pl.S, dbg_mask);
                     else
                         hipLaunchKernelGGL((msm_accumulate_lazy_kernel<false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, vbase,
-                                           c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), c.part_raw.as<g1_lazy_partial_t>(), nbt, pl.S, dbg_mask);
-                    hipLaunchKernelGGL(g1_partials_to_exact_kernel, dim3((unsigned)((tmax + 255) / 256)), dim3(256), 0, st,
-                                       (const g1_lazy_partial_t*)c.part_raw.as<g1_lazy_partial_t>(), c.part_a.as<g1_xyzz_mem_t>(),
-                                       (const uint32_t*)c.start_a.as<uint32_t>(), nbt);
+                                           c.sorted.as<uint32_t>(), boffp, c.start_a.as<uint32_t>(), raw_out, nbt, pl.S, dbg_mask);
+                    if (!ltail)
+                        hipLaunchKernelGGL(g1_partials_to_exact_kernel, dim3((unsigned)((tmax + 255) / 256)), dim3(256), 0, st,
+                                           (const g1_lazy_partial_t*)raw_out, c.part_a.as<g1_xyzz_mem_t>(), (const uint32_t*)c.start_a.as<uint32_t>(), nbt);
                     goto accumulated;
                 }
             } else {
@@ -1041,41 +1114,16 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         }
         phase_end();
     }
-    // 6. reduce rounds: (cnt_a, start_a, part_a) -> (cnt_b, start_b, part_b) -> ...
-    phase_begin("msm_reduce_partials");
-    uint32_t *cnt_in = c.cnt_a.as<uint32_t>(), *cnt_out = c.cnt_b.as<uint32_t>();
-    uint32_t *start_in = c.start_a.as<uint32_t>(), *start_out = c.start_b.as<uint32_t>();
-    xyzz_mem_t<F> *pin = c.part_a.as<xyzz_mem_t<F>>(), *pout = c.part_b.as<xyzz_mem_t<F>>();
-    size_t T_in_max = T0_max;
-    for (int r = 0; r < rounds; r++) {
-        size_t T_out_max = T_in_max / pl.S2 + nbt + 1;
-        if (T_out_max > T1_max) T_out_max = T1_max;  // both ping-pong buffers hold >= T1_max partials
-        hipLaunchKernelGGL(msm_alloc_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, cnt_in, cnt_out, nbt, pl.S2);
-        exclusive_scan_u32(st, cnt_out, start_out, (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
-        hipLaunchKernelGGL((msm_reduce_kernel<F>), dim3((unsigned)((T_out_max + 255) / 256)), dim3(256), 0, st, pin, start_in, cnt_in, start_out, pout,
-                           nbt, pl.S2);
-        std::swap(cnt_in, cnt_out);
-        std::swap(start_in, start_out);
-        std::swap(pin, pout);
-        T_in_max = T_out_max;
+    // 6.-9. reduce rounds, then the bucket merge (a chunk of a bigger MSM) or fold -> bit-plane sums -> (host) Horner: on the lazy arithmetic
+    // when the accumulate kernel left raw partial sums (G1, tuning lazy_tail), else on F's exact arithmetic
+    const bool flat = single_round || tuning().fold_flat != 0;
+    if constexpr (sizeof(F) == sizeof(fq_t)) {
+        if (ltail) {
+            msm_reduce_and_tail<fqz_t>(c, pl, tg, nwin, nbt, rounds, T0_max, T1_max, sink, pd, host_planes, flat, phase_begin, phase_end);
+            return pd;
+        }
     }
-    phase_end();
-    if (sink) {
-        // a chunk of a bigger MSM: its per-bucket partial sums join the sink; the tail runs once, after the last chunk (msm_tail_from_sink)
-        phase_begin("msm_bucket_merge");
-        if (sink->after) HIP_TRY(hipStreamWaitEvent(st, sink->after, 0));
-        hipLaunchKernelGGL((msm_bucket_merge_kernel<F>), dim3((nbt + 255) / 256), dim3(256), 0, st, (const xyzz_mem_t<F>*)pin, (const uint32_t*)start_in,
-                           (const uint32_t*)cnt_in, (xyzz_mem_t<F>*)sink->acc, nbt, sink->L, sink->slot);
-        if (sink->done) HIP_TRY(hipEventRecord(sink->done, st));
-        phase_end();
-        HIP_TRY(hipGetLastError());
-        pd.nplanes = 0;
-        return pd;
-    }
-    // 7.-9. fold -> bit-plane sums -> (host) Horner
-    phase_begin("msm_bucket_reduce");
-    msm_tail_launch<F>(c, pl, tg, nwin, nbt, pin, start_in, cnt_in, single_round || tuning().fold_flat != 0, pd, host_planes);
-    phase_end();
+    msm_reduce_and_tail<F>(c, pl, tg, nwin, nbt, rounds, T0_max, T1_max, sink, pd, host_planes, flat, phase_begin, phase_end);
     return pd;
 }
 // The tail of a chunked MSM: fold + bit planes over the bucket sink (every bucket holds L partial sums, one per lane).
@@ -1091,7 +1139,15 @@ static msm_pending_t msm_tail_from_sink(lane_t& c, size_t chunk_n, int window_bi
     c.start_a.ensure(((size_t)nbt + 1) * 4);
     c.cnt_a.ensure(((size_t)nbt + 1) * 4);
     hipLaunchKernelGGL(msm_sink_lists_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, c.stream, c.start_a.as<uint32_t>(), c.cnt_a.as<uint32_t>(), nbt, sink.L);
+    pd.lazy = msm_lazy_tail_on<F>();  // the sink holds what the chunks' merges left: raw lazy points then
     c.phase_begin("msm_bucket_reduce");
+    if constexpr (sizeof(F) == sizeof(fq_t)) {
+        if (pd.lazy) {
+            msm_tail_launch<fqz_t>(c, pl, tg, nwin, nbt, (const xyzz_mem_t<fqz_t>*)sink.acc, c.start_a.as<uint32_t>(), c.cnt_a.as<uint32_t>(), true, pd, host_planes);
+            c.phase_end();
+            return pd;
+        }
+    }
     msm_tail_launch<F>(c, pl, tg, nwin, nbt, (const xyzz_mem_t<F>*)sink.acc, c.start_a.as<uint32_t>(), c.cnt_a.as<uint32_t>(), true, pd, host_planes);
     c.phase_end();
     return pd;
@@ -1351,7 +1407,7 @@ static void msm_host_chunked(void* out, const void* points, size_t npoints, cons
             const msm_plan_t pl = msm_make_plan(max_cnt, chunk_c, 1, 0);
             sink.nbt = (uint32_t)pl.W * pl.nb;
             sink.L = (uint32_t)L;
-            const size_t bytes = (size_t)sink.nbt * L * sizeof(xyzz_mem_t<F>);
+            const size_t bytes = (size_t)sink.nbt * L * msm_partial_bytes<F>();
             c0.sink_acc.ensure(bytes);
             sink.acc = c0.sink_acc.p;
             HIP_TRY(hipMemsetAsync(sink.acc, 0, bytes, c0.stream));  // all-zero = the point at infinity
@@ -1537,7 +1593,7 @@ static void msm_batch_run(const bases_handle_t<F>& h, const msm_req_t* req, size
         for (size_t i = 0; i < jobs.size(); i++) {
             const size_t K = jobs[i].size();
             plane_off[i] = lane_bytes[i % L];
-            lane_bytes[i % L] += K > 1 ? K * fuse_planes * sizeof(xyzz_mem_t<F>) : slot;
+            lane_bytes[i % L] += K > 1 ? K * fuse_planes * msm_point_bytes<F>() : slot;
             table_off[i] = lane_bytes[i % L];
             lane_bytes[i % L] += K > 1 ? ((K + 1) * sizeof(msm_inst_t) + 255) / 256 * 256 : 0;
         }

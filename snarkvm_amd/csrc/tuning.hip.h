@@ -14,6 +14,11 @@
 //
 //   key             default  meaning
 //   lazy            1        G1 accumulation on the signed-limb arithmetic of ffl.hip.h (0: exact kernel)
+//   lazy_tail       0        1: G1 reduce rounds, bucket merge, fold and bit planes on the lazy arithmetic too (ffl.hip.h::fqz_t), no conversion pass.
+//                            Measured at 2^24: the conversion pass goes (-0.52 ms) but the tail kernels do not get faster (reduce 0.89 vs 0.87 ms,
+//                            fold + bit planes 1.54 vs 1.46 ms: every sum / difference is a 13-step carry chain in a latency-bound kernel, and the
+//                            fold / bit-plane kernels spill 808 B at 256 registers): 30.71 vs 30.88 ms per step, 197.4 vs 196.6 proofs/s - kept as
+//                            a bit-exact switch, off by default
 //   lazy2           1        G2 accumulation on the signed-limb Fq2 arithmetic (0: exact kernel)
 //   fused           1        wide windows: scalar read fused with the level-1 partition (0: stand-alone digit matrix)
 //   hist            2        scalar-read kernel variant (1: 512 threads x 4 scalars, one LDS histogram - round 3; 2: 1 024 threads x 2
@@ -62,7 +67,7 @@ struct tuning_t {
     int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
-    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 0;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -74,7 +79,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail)
 #undef SV_TUNE_KEY
         return false;
     }

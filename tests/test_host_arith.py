@@ -198,6 +198,15 @@ def test_lazy_accumulate_arithmetic_matches_exact():
         assert L.snarkvm_hip_selftest_fq_lazy(ctypes.c_uint64(seed), ctypes.c_int(5000)) == 0, seed
 
 
+def test_lazy_tail_arithmetic_matches_exact():
+    """csrc/ffl.hip.h::fqz_t (the lazy arithmetic behind field-like operators: the reduce rounds, fold and bit planes of a G1 MSM under
+    tuning lazy_tail) against the exact arithmetic under the same generic addition and doubling laws, compiled for the host: general
+    representatives, repeated points, negatives, restarts from infinity, explicit doublings, the 208-byte memory image after every step."""
+    L = _lib.lib()
+    for seed in (1, 2, 3, 0xDEADBEEF):
+        assert L.snarkvm_hip_selftest_g1_lazy_tail(ctypes.c_uint64(seed), ctypes.c_int(4000)) == 0, seed
+
+
 def test_signed_ntt_butterfly_arithmetic_matches_exact():
     """csrc/frs.hip.h (signed limbs, R = 2^290, no canonical form inside a pass) compiled for the host against the exact Fr
     arithmetic (which test_field_ops pins on the oracle): chains of up to nine butterfly stages, the closing product, the bare
