@@ -129,7 +129,7 @@ static inline msm_plan_t msm_make_plan(size_t n, int c_override = 0, int tables 
         p.S = (uint32_t)(sfill < 4 ? 4 : sfill);
     }
     if (env_S > 0) p.S = env_S;
-    p.S2 = env_S2 > 1 ? env_S2 : 8;
+    p.S2 = env_S2 > 1 ? env_S2 : 16;
     p.L = env_L > 0 ? (uint32_t)env_L : 8;
     if (p.L > p.nb) p.L = p.nb;
     while (p.nb % p.L) p.L--;

@@ -1039,7 +1039,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         phase_end();
         // A single-round MSM (<= 2^22 digit entries: at most 2^16 accumulate threads) leaves at most 2^16 + nbt partial sums
         // whatever the scalars are, and the tail kernels walk them position by position (msm.hip.h 7a/7b): no reduce round.
-        // Bigger MSMs run a FIXED number of reduce rounds (2: each shrinks a bucket's partial sums 8x) before the fold reads
+        // Bigger MSMs run a FIXED number of reduce rounds (round 4: ONE round that shrinks a bucket's partial sums 16x; rounds 2-3: two of 8x) before the fold reads
         // them twice - what uniform scalars need anyway (the top digit row of a 253-bit scalar fills only 2^(253 mod c) buckets,
         // thousands of entries each) - and the flattened-list fold takes whatever is left of a heavier bucket (all scalars
         // equal at 2^24: 2 048 partial sums in one bucket, 32 additions per lane of its row and column).  Nothing is read back:

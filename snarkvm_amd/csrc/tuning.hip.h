@@ -26,7 +26,10 @@
 //   prefetch        2        base gather software pipeline: 0 never, 1 single-round grids, 2 always
 //   acc_lds         98304    dynamic LDS request that keeps a second accumulate workgroup off a CU (single-round grids); 0: off
 //   acc_one_wg      0        1: one accumulate workgroup per CU for multi-round grids too
-//   reduce_rounds   2        fixed reduce rounds of a multi-round MSM (0 .. 8)
+//   reduce_rounds   1        fixed reduce rounds of a multi-round MSM (0 .. 8), each shrinking a bucket's partial sums by the group size (seg2, 16).
+//                            Round 4: one round of 16 instead of two of 8 - for uniform scalars the second round only copied (0.84 -> 0.57 ms of
+//                            reduce time at 2^24, 29.84 -> 29.51 ms per step; one round of 64: 0.99 ms); what an all-equal scalar vector leaves in
+//                            one bucket (2^24: 16 384 partial sums instead of 4 096) goes to the flattened-list fold: ~3 ms more on that input
 //   fold_flat       1        flattened-list fold for every MSM (0: per-bucket lists for big ones)
 //   fuse_batch      1        small instances of a batch travel as fused multi-instance groups
 //   fuse_max_k      64       instances per fused group
@@ -43,7 +46,7 @@
 //   ramp            3        snarkvm_msm: the FIRST chunk is cut into 1/2^r, 1/2^r, 1/2^(r-1), ..., 1/2 (0: off) so that the GPU starts after a short upload
 //   ring_lanes      3        lanes (streams with their own staging buffers) the chunks of one snarkvm_msm call cycle through
 //   seg             0        accumulate segment length override (0: planner)
-//   seg2            0        reduce-round group size override
+//   seg2            0        reduce-round group size override (0: 16)
 //   fold_l          0        planner L override
 //   scan1           1        single-launch scan for mid-size counter arrays
 //   ntt_min_tiles   256      workgroups a small-transform pass is spread over
@@ -64,7 +67,7 @@ namespace sv {
 struct tuning_t {
     int lazy = 1, lazy2 = 1, fused = 1, hist = 2, prefetch = 2;
     long acc_lds = 96 * 1024;
-    int acc_one_wg = 0, reduce_rounds = 2, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
+    int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
     int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 0;
