@@ -12,6 +12,11 @@ SURVEY.md 8(d) (algorithmic bytes n * 128 + 144 for the whole MSM, 32 n for the 
 `alu_roofline` against the wall-clock-calibrated arithmetic ceilings of tools/ecbench.hip, and a `cpu_baseline` (the C++
 restatement of the reference's rayon path, oracle/, timed on this box's host cores on a bounded sample).
 
+`--workload proof1`: BASELINE.json configs[3] - ONE Varuna-proof-shaped call list at a time from one caller thread (the reference
+proves one transaction at a time, proving_key/mod.rs:37): `value` = proofs/s of 32 proofs proved one after the other,
+`ms_per_step` = the latency of one proof; every result of every timed proof is compared with the serial replay and all 15 results
+of two proofs with the CPU oracle.  The default workload carries compact `proof1`, `proofs64` and `concurrent_callers` legs too.
+
 `--workload proofs64`: BASELINE.json configs[4] - 64 Varuna-proof-shaped call lists (14 G1 commitments / openings of
 2^16-2^17, ~45 NTTs, the polynomial passes, one 2^16 G2 MSM each; snarkvm_amd/proofs.py), 64 / N proofs per rank, replayed in
 lock step (`value`, proofs/s over all ranks, strong scaling) and by concurrent caller threads (`concurrent_callers`); one whole
@@ -118,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["msm", "proofs64"], default="msm")
+    ap.add_argument("--workload", choices=["msm", "proofs64", "proof1"], default="msm")
     ap.add_argument("--lg-msm", type=int, default=24)
     ap.add_argument("--lg-ntt", type=int, default=24)
     ap.add_argument("--ntt-steps", type=int, default=10)
@@ -136,6 +141,8 @@ def main():
     ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64, callers mode)")
     ap.add_argument("--proof-geometry", default="17x15", help="base tables x window bits of the proofs' registered SRS (proofs64)")
     ap.add_argument("--proof-group", type=int, default=32, help="proofs replayed in lock step per group (proofs64, lockstep mode)")
+    ap.add_argument("--proof1-sync-msm", action="store_true", help="proof1: synchronous commitments (the A/B of SNARKVM_HIP_SCOPE_ASYNC_MSM)")
+    ap.add_argument("--no-proof-legs", action="store_true", help="default workload: skip the proof1 / proofs64 / concurrent_callers legs")
     args = ap.parse_args()
 
     import torch
@@ -151,12 +158,38 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
         backend = os.environ.get("SNARKVM_BENCH_BACKEND", "nccl")  # "gloo": smoke-testing the N > 1 path on a 1-GPU box
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+        # A rank that cannot bring up RCCL (no xGMI peer access, IPC mode, a dead GPU) must END the job with a message, not leave the
+        # other ranks waiting in their first collective: bounded initialisation, then one probe all-reduce under the same bound.
+        import datetime
+
+        limit = datetime.timedelta(seconds=int(os.environ.get("SNARKVM_BENCH_INIT_TIMEOUT_S", "180")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
+            else:
+                dist.init_process_group(backend, timeout=limit)
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"probe all-reduce returned {probe.item()} instead of {world}")
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}] FATAL: cannot initialise the {backend} process group on cuda:{dev_index} within {limit.seconds} s: {e!r}", file=sys.stderr, flush=True)
+            os._exit(3)  # no destructors: a half-initialised communicator may block in its own teardown
     else:
         torch.cuda.set_device(0)
+
+    def device_identity():
+        """what this rank runs on: lets a scaling run be checked for two ranks sharing one GPU"""
+        pr = torch.cuda.get_device_properties(dev_index)
+        return {"rank": rank, "cuda_index": dev_index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")), "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+
+    def gather_objects(obj):
+        if world > 1:
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        return [obj]
 
     from snarkvm_amd import _lib, plugin, synthetic
     from snarkvm_amd.layout import G1_AFFINE, G1_PROJECTIVE
@@ -188,8 +221,11 @@ def main():
             return [float(x.item()) for x in out]
         return [dt]
 
+    rank_devices = gather_objects(device_identity())
     if args.workload == "proofs64":
-        return proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks)
+        return proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks, rank_devices)
+    if args.workload == "proof1":
+        return proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks, rank_devices)
 
     gen = np.zeros(1, dtype=G1_AFFINE)
     gen["x"] = G1_GEN_X
@@ -339,14 +375,21 @@ def main():
         extra["registration_ms"] = registration_ms
         extra["table_bytes"] = table_bytes
         # -- the same MSM without precomputed tables (registered bases only: 16 windows of 16 bits, Horner chain on the host)
+        # (16 digit rows per scalar instead of 12: every lane the batch cycles through must GROW its workspace first.  Round 4 warmed one
+        # lane with a synchronous call and timed a 2-instance batch: lane 1 outgrew its buffers inside the timed region, behind lane 0's
+        # running MSM - 93.6 ms per step on the driver's box.  The warm-up now is a batch of the same shape over every lane, and the
+        # library no longer frees an outgrown buffer in the middle of a call; `tables1_workspace_growth` must read zero allocations.)
         rb1 = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=1)
-        rb1.msm(device_ptr=d_scalars.data_ptr(), npoints=n)
-        barrier()
-        t0 = time.perf_counter()
         k1 = 2
+        lanes1 = max(k1, L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n)))
+        rb1.msm_batch(device_ptrs=[d_scalars.data_ptr()] * lanes1, npoints=[n] * lanes1)
+        barrier()
+        alloc_stats(L, reset=True)
+        t0 = time.perf_counter()
         r1 = rb1.msm_batch(device_ptrs=[d_scalars.data_ptr()] * k1, npoints=[n] * k1)
         barrier()
         d1 = time.perf_counter() - t0
+        extra["tables1_workspace_growth"] = alloc_stats(L)
         rb1.close()
         if to_affine(r1)[0:1].tobytes() != want_affine.tobytes():
             raise SystemExit("bench.py: RESULT MISMATCH in the tables = 1 leg")
@@ -447,6 +490,9 @@ def main():
         checks["ffi"] = "snarkvm_msm (stateless) and registered-bases calls == closed form at every size; snarkvm_ntt round trips"
         del host_bases
     del bases_dev
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.no_proof_legs:
+        torch.cuda.empty_cache()
+        extra.update(proof_legs(dev_index, with_oracle=not args.no_cpu_baseline))
 
     # ------------------------------------------------------------------ CPU baseline + oracle checks (rank 0, N = 1 only)
     cpu = None
@@ -500,7 +546,12 @@ def main():
     # runs; gfx950 x2 FETCH correction), and the wall-clock arithmetic ceilings of tools/ecbench.hip / tools/microbench.hip.
     # Only quoted for the configuration they were collected on; PMC collection cannot run inside this process.
     default_cfg = args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits
-    pmc = (load_profile_json("r04_pmc_traffic.json") or load_profile_json("r03_pmc_traffic.json") or load_profile_json("r02_pmc_traffic.json")).get("kernels", {}) if default_cfg else {}
+    pmc, pmc_source = {}, None
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        if default_cfg and load_profile_json(name):
+            pmc = load_profile_json(name).get("kernels", {})
+            pmc_source = f"look-up, not measured in this run: profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration on the builder's box)"
+            break
     ceil = load_profile_json("r03_alu_ceilings.json") or load_profile_json("r02_alu_ceilings.json")
 
     def traffic(kernel_prefix, fetch_key, times=1):
@@ -528,7 +579,7 @@ def main():
                 "mads_per_launch": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)),
                 "peak_mads_per_s": ceil.get("v_mad_u64_u32_per_s"),
                 "mad_frac": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)) / (acc_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"] if ceil.get("v_mad_u64_u32_per_s") else None,
-                "source": "profiles/r03_alu_ceilings.json (tools/ecbench.hip k_lazy at the kernel's occupancy, tools/microbench.hip: wall-clock, whole chip)",
+                "source": "look-up, not measured in this run: profiles/r03_alu_ceilings.json (tools/ecbench.hip k_lazy at the kernel's occupancy, tools/microbench.hip: wall-clock, whole chip, on the builder's box)",
                 # the shader clock sampled by a host thread during the timed MSM steps (amdgpu hwmon): the ceilings above assume the 2.4 GHz
                 # peak clock, so mad_frac against what the chip could issue at the clock it actually sustained is mad_frac * 2400 / mean_mhz
                 "sclk_during_timed_steps": sclk.summary(),
@@ -556,6 +607,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "rank_ms_per_step": [d / args.steps * 1e3 for d in rank_dts],
+            "rank_devices": rank_devices,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,  # the reference publishes no number for this metric
@@ -586,6 +638,7 @@ def main():
                 "unit": "GB/s",
                 "frac": (alg_bytes / (acc_ms * 1e-3) / 1e9 / 8000.0) if acc_ms else None,
                 "traffic": traffic("msm_accumulate_lazy_kernel", "fetch_bytes_raw") or traffic("msm_accumulate_seg_kernel", "fetch_bytes_raw"),
+                "traffic_source": pmc_source,
                 "algorithmic_bytes": alg_bytes,
                 "traffic_model": {"bytes": n * 132.0 * W, "what": "one gathered 128-B lazy base slot + one 4-B sorted index per (pair, digit row)"},
                 "note": "whole-MSM is integer-ALU bound (SURVEY.md 8d): see alu_roofline; roofline_scalar_read is the HBM-bound phase",
@@ -600,6 +653,7 @@ def main():
                 "unit": "GB/s",
                 "frac": ((32.0 * n) / (dig_ms * 1e-3) / 1e9 / 8000.0) if dig_ms else None,
                 "traffic": (traffic("radix_hist1_wide_kernel", "fetch_bytes_x2") or traffic("radix_hist1_fused_kernel", "fetch_bytes_x2")) if "msm_scalar_read" in phase_ms else traffic("msm_digits_kernel", "fetch_bytes_x2"),
+                "traffic_source": pmc_source,
                 "algorithmic_bytes": 32.0 * n,
                 # the whole scalar-consuming phase: the level-1 scatter (radix_scatter1_fused_kernel + its counter scans) reads every
                 # scalar a second time and writes 72 B of (index | sign, remainder) entries per scalar; still priced on 32 n bytes
@@ -620,6 +674,7 @@ def main():
                 "unit": "GB/s",
                 "frac": ((64.0 * nn) / (ntt_kernel_ms * 1e-3) / 1e9 / 8000.0) if ntt_kernel_ms else None,
                 "traffic": traffic("ntt_pass_kernel_v2", "fetch_bytes_x2", times=3),
+                "traffic_source": pmc_source,
                 "algorithmic_bytes": 64.0 * nn,
                 "alu_roofline": alu_ntt,
             },
@@ -632,7 +687,250 @@ def main():
         dist.destroy_process_group()
 
 
-def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks):
+def oracle_check_proof(keys, shape, got, p):
+    """All 15 results of proof `p` (`got`: 14 G1Projective records + the G2Projective record, as bytes) against oracle/proof_replay.py;
+    raises SystemExit on a mismatch, returns the oracle's seconds.  Test infrastructure: only ever called outside timed regions."""
+    from oracle import cpu as oracle
+    from oracle import proof_replay
+    from snarkvm_amd import kzg10
+    from snarkvm_amd.layout import G1_PROJECTIVE, G2_PROJECTIVE
+
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.perf_counter()
+    want = proof_replay.expected_results(keys.pool_host, keys.g1_host, keys.g2_host, keys.point, shape.lg_r, shape.lg_k, shape.lg_g2, shape.nmax, p)
+    oracle_s = time.perf_counter() - t0
+    for j in range(14):
+        ga = kzg10.to_affine(np.frombuffer(got[j], dtype=G1_PROJECTIVE))
+        wa = want[j]
+        if not (np.array_equal(ga["x"], wa["x"]) and np.array_equal(ga["y"], wa["y"]) and np.array_equal(ga["infinity"], wa["infinity"])):
+            raise SystemExit(f"bench.py: proof {p}, commitment {j}: the device result differs from the CPU oracle")
+    if want[14] is not None:
+        g2a = oracle.g2_to_affine(np.frombuffer(got[14], dtype=G2_PROJECTIVE))
+        if g2a.tobytes() != want[14].tobytes():
+            raise SystemExit(f"bench.py: proof {p}: the G2 MSM result differs from the CPU oracle")
+    return oracle_s
+
+
+def alloc_stats(L, reset=False):
+    v = (ctypes.c_uint64 * 5)()
+    L.snarkvm_hip_alloc_stats(v, 1 if reset else 0)
+    return {"device_allocations": int(v[0]), "device_bytes": int(v[1]), "pinned_allocations": int(v[2]), "pinned_bytes": int(v[3]), "ms": v[4] / 1e3}
+
+
+def proof1_run(keys, dev_index, salts, warm=4, async_msm=True):
+    """`salts`: the proofs, proved ONE AT A TIME by this thread (snarkvm_amd/proofs.py::replay_single).  Returns (seconds of the whole
+    run, per-proof latencies, per-proof result lists, call-time split, workspace growth inside the timed region)."""
+    from snarkvm_amd import _lib, proofs
+
+    L = _lib.lib()
+    ws = proofs.SingleProofWorkspace(keys, dev_index)
+    for sidx in salts[:warm]:
+        proofs.replay_single(ws, sidx, None, async_msm)
+    ws.times = {k: 0.0 for k in ws.times}
+    _lib.check(L.snarkvm_hip_synchronize())
+    alloc_stats(L, reset=True)
+    lat, results = [], []
+    t_begin = time.perf_counter()
+    for sidx in salts:
+        got = []
+        t0 = time.perf_counter()
+        proofs.replay_single(ws, sidx, got, async_msm)
+        lat.append(time.perf_counter() - t0)
+        results.append(got)
+    dt = time.perf_counter() - t_begin
+    return dt, lat, results, dict(ws.times), alloc_stats(L)
+
+
+def proof1_summary(dt, lat, times, grown, count):
+    ls = sorted(lat)
+    return {"proofs": count, "ms_per_proof": dt / count * 1e3, "median_ms": ls[len(ls) // 2] * 1e3, "min_ms": ls[0] * 1e3, "max_ms": ls[-1] * 1e3,
+            "host_enqueue_ms_per_proof": times["enqueue"] / count * 1e3, "host_wait_ms_per_proof": times["wait"] / count * 1e3,
+            "workspace_growth_in_timed_region": grown}
+
+
+def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks, rank_devices):
+    """BASELINE.json configs[3]: one Varuna-proof-shaped call list at a time from ONE caller thread, 32 timed proofs per rank (the
+    reference proves one transaction at a time: synthesizer/snark/src/proving_key/mod.rs:37 -> varuna.rs:336).  `ms_per_step` is the
+    latency of one proof.  Every timed result is compared with the serial replay (one synchronous call per step: `proofs.replay`), two
+    whole proofs with the CPU oracle; the same proofs are timed again with synchronous commitments (the A/B of the overlap)."""
+    import torch.distributed as dist
+
+    from snarkvm_amd import proofs
+
+    shape = proofs.ProofShape()
+    ptab, pbits = (int(v) for v in args.proof_geometry.split("x"))
+    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits)
+    count = 32
+    mine = list(range(rank, count * world, world))
+    checks = {}
+    barrier()
+    t0 = time.perf_counter()
+    dt_rank, lat, got, times, grown = proof1_run(keys, dev_index, mine, async_msm=not args.proof1_sync_msm)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    # proof1_run's warm-up sits inside [t0, now): the per-proof figures come from its own clock, the whole-job rate from the slowest rank's
+    dt_job = max_over_ranks(dt_rank)
+    rank_dts = gather_over_ranks(dt_rank)
+    _, lat_b, got_b, times_b, _ = proof1_run(keys, dev_index, mine, async_msm=bool(args.proof1_sync_msm))
+    # ---- checks (outside the timed regions)
+    ref_ws = proofs.ProofWorkspace(keys, dev_index)
+    for i, p in enumerate(mine):
+        ref = []
+        proofs.replay(ref_ws, p, ref)
+        if proofs.normalize_results(ref) != proofs.normalize_results(got[i]) or proofs.normalize_results(ref) != proofs.normalize_results(got_b[i]):
+            raise SystemExit(f"bench.py: proof {p}: the one-scope replay differs from the serial replay")
+    checks["every_proof_vs_serial_replay"] = f"all {len(mine)} timed proofs x 15 results (asynchronous and synchronous commitments) == one synchronous call per step"
+    if rank == 0 and not args.no_cpu_baseline:
+        secs = [oracle_check_proof(keys, shape, got[mine.index(p)], p) for p in (mine[0], mine[-1])]
+        checks["proofs_vs_oracle"] = (f"proofs {mine[0]} and {mine[-1]}: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py "
+                                      f"({secs[0]:.1f} + {secs[1]:.1f} s on the host)")
+    if rank == 0:
+        a = proof1_summary(dt_rank, lat, times, grown, len(mine))
+        b = proof1_summary(sum(lat_b), lat_b, times_b, None, len(mine))
+        print(json.dumps({
+            "metric": "Varuna-proof-shaped hot-path replays per second, ONE proof at a time from one caller thread (BASELINE.json configs[3])",
+            "value": world * len(mine) / dt_job,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": len(mine),
+            "warmup": 4,
+            "ms_per_step": dt_job / len(mine) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": DTYPE,
+            "data": "synthetic",
+            "config": {"workload": "one proof at a time: 14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM; "
+                                   "device-resident random data, transfer_private domain sizes; one deferred-synchronisation scope per proof",
+                       "proofs_per_rank": len(mine), "registered_srs": f"{ptab} tables x {pbits}-bit windows",
+                       "commitments": "synchronous" if args.proof1_sync_msm else "SNARKVM_HIP_SCOPE_ASYNC_MSM"},
+            "latency": a,
+            "other_commitment_mode": dict(b, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM" if args.proof1_sync_msm else "synchronous"),
+            "g1_pairs_per_s": world * len(mine) * shape.pairs() / dt_job,
+            "rank_ms_per_proof": [d / len(mine) * 1e3 for d in rank_dts],
+            "rank_devices": rank_devices,
+            "wall_ms_including_warmup": dt * 1e3,
+            "checks": checks,
+        }))
+    keys.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def proof_legs(dev_index, with_oracle):
+    """Compact prover-shaped legs of the default line (rank 0, N = 1, outside the timed region, ~10 s): configs[3] (`proof1`), configs[4]
+    on one GPU with 32 proofs in lock step (`proofs64`), and 8 caller threads issuing one proof-sized MSM per call (`concurrent_callers`:
+    the reference's rayon fan-out, sonic_pc/mod.rs:186-245, met by the in-library coalescer).  Every leg carries its own `checks`."""
+    import threading
+
+    import torch
+
+    from snarkvm_amd import _lib, proofs
+    from snarkvm_amd.layout import G1_PROJECTIVE
+
+    L = _lib.lib()
+    shape = proofs.ProofShape()
+    keys = proofs.ProverKeys(shape, tables=17, window_bits=15)
+    out = {}
+    P = 32
+    salts = list(range(P))
+    # ---- proof1
+    dt, lat, got1, times, grown = proof1_run(keys, dev_index, salts)
+    leg = dict(proof1_summary(dt, lat, times, grown, P), value=P / dt, unit="proofs/s",
+               what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof (bench.py --workload proof1)")
+    out["proof1"] = leg
+    # ---- proofs64 shape, 32 proofs in lock step
+    lock = proofs.LockstepBatch(keys, group=P, devices=[dev_index])
+    lock.run(salts)
+    for ws in lock.workspaces:
+        ws.times = {k: 0.0 for k in ws.times}
+    _lib.check(L.snarkvm_hip_synchronize())
+    t0 = time.perf_counter()
+    _, got_lock = lock.run(salts, collect=True)
+    _lib.check(L.snarkvm_hip_synchronize())
+    dt_lock = time.perf_counter() - t0
+    t_lock = dict(lock.workspaces[0].times)
+    del lock
+    torch.cuda.empty_cache()
+    norm1 = [proofs.normalize_results(r) for r in got1]
+    norm_lock = [proofs.normalize_results(r) for r in got_lock]
+    if norm1 != norm_lock:
+        raise SystemExit("bench.py: proof legs: the one-at-a-time replay and the lock-step replay differ")
+    out["proofs64"] = {"value": P / dt_lock, "unit": "proofs/s", "proofs": P, "ms_per_proof": dt_lock / P * 1e3,
+                       "g1_pairs_per_s_inside_msm_calls": P * shape.pairs() / t_lock["msm"] if t_lock.get("msm") else None,
+                       "g2_pairs_per_s_inside_msm_calls": P * (1 << shape.lg_g2) / t_lock["g2"] if t_lock.get("g2") else None,
+                       "call_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_lock.items()},
+                       "what": "BASELINE.json configs[4] on one GPU with 32 proofs in lock step (bench.py --workload proofs64 runs 64, and the concurrent-caller mode)",
+                       "checks": {"lockstep_vs_proof1": f"all {P} proofs x 15 results identical in both replays"}}
+    leg["checks"] = {"proof1_vs_lockstep": f"all {P} proofs x 15 results identical in both replays"}
+    # ---- checks (outside the timed regions)
+    if with_oracle:
+        p = salts[-1]
+        secs = oracle_check_proof(keys, shape, got1[p], p)
+        oracle_check_proof(keys, shape, got_lock[p], p)
+        msg = f"proof {p}: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py ({secs:.1f} s on the host)"
+        leg["checks"]["one_proof_vs_oracle"] = msg
+        out["proofs64"]["checks"]["one_proof_vs_oracle"] = msg
+    # ---- concurrent callers: 8 threads, one MSM of 2^16 pairs per call, device-resident Montgomery scalars
+    T, calls, n = 8, 24, 1 << shape.lg_r
+    pool = torch.from_numpy(keys.pool_host.view(np.int64).reshape(-1)).cuda()
+    torch.cuda.synchronize()
+
+    def one_call(t, k, dst):
+        ptr = ctypes.c_void_p(pool.data_ptr() + 32 * (97 * t + 13 * k))
+        _lib.check(L.snarkvm_hip_msm_registered_ex(ctypes.c_void_p(dst.ctypes.data), keys.h, 0, n, 0, 0, ptr, 1, 1, 0))
+
+    alone = np.zeros((T, calls), dtype=G1_PROJECTIVE)
+    for t in range(T):
+        for k in range(calls):
+            one_call(t, k, alone[t, k : k + 1])
+    t0 = time.perf_counter()
+    for k in range(calls):
+        one_call(0, k, alone[0, k : k + 1])
+    dt_alone = time.perf_counter() - t0
+    together = np.zeros((T, calls), dtype=G1_PROJECTIVE)
+    L.snarkvm_hip_coalescer_stats(None, 1)
+    start = threading.Barrier(T + 1)
+    errors = []
+
+    def worker(t):
+        try:
+            start.wait()
+            for k in range(calls):
+                one_call(t, k, together[t, k : k + 1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    dt_thr = time.perf_counter() - t0
+    if errors:
+        raise SystemExit(f"bench.py: concurrent callers failed: {errors[:3]}")
+    co = (ctypes.c_uint64 * 4)()
+    L.snarkvm_hip_coalescer_stats(co, 0)
+    from snarkvm_amd import kzg10
+    if kzg10.to_affine(together.reshape(-1)).tobytes() != kzg10.to_affine(alone.reshape(-1)).tobytes():
+        raise SystemExit("bench.py: concurrent callers: a coalesced result differs from the call issued alone")
+    out["concurrent_callers"] = {"value": T * calls * n / dt_thr, "unit": "pairs/s", "caller_threads": T, "calls": T * calls, "pairs_per_call": n,
+                                 "ms_per_call": dt_thr / calls * 1e3, "calls_per_s": T * calls / dt_thr,
+                                 "one_thread_alone": {"value": calls * n / dt_alone, "unit": "pairs/s", "ms_per_call": dt_alone / calls * 1e3},
+                                 "coalescer": {"batches": int(co[0]), "msm_instances": int(co[1]), "largest_batch": int(co[2]), "single_instance_batches": int(co[3]),
+                                               "instances_per_batch": (co[1] / co[0]) if co[0] else None},
+                                 "what": "8 caller threads, each issuing synchronous snarkvm_hip_msm_registered_ex calls of 2^16 pairs (one commitment per call, the reference's "
+                                         "rayon fan-out); calls that meet inside the library travel as fused groups",
+                                 "checks": {"coalesced_vs_alone": f"all {T * calls} results identical (after to_affine) to the same call issued alone"}}
+    del pool
+    keys.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks, rank_devices):
     """BASELINE.json configs[4]: a batch of Varuna-proof-shaped call lists, sharded over the ranks (64 / N proofs each).  Inside a
     rank two ways of issuing them are timed, one after the other, on the same proofs:
       lockstep   `VarunaSNARK::prove_batch` is a batch by construction (varuna.rs:336): round k of all proofs of a group is ONE
@@ -743,6 +1041,7 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
                                    "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_thr.items()},
                                    "what": "one proof per caller thread at a time (the reference's rayon fan-out); proof-sized MSMs of concurrent callers fused by the in-library coalescer"},
             "rank_ms_per_proof": [d / max(1, len(mine)) * 1e3 for d in rank_dts],
+            "rank_devices": rank_devices,
             "checks": checks,
         }))
     keys.close()

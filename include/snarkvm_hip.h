@@ -81,8 +81,8 @@ RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoint
 /* Number of visible HIP devices (0 if none).  Never fails. */
 int snarkvm_hip_device_count(void);
 /* Number of HIP streams (each with its own workspace) snarkvm_hip_msm_registered_batch cycles through for instances of
- * up to `npoints` pairs: 8 below 2^20, 3 above (SNARKVM_HIP_LANES overrides).  A caller that wants allocation-free timed
- * regions warms up that many instances first. */
+ * up to `npoints` pairs: 8 below 2^20, 3 above (SNARKVM_HIP_TUNING=lanes=N overrides).  A caller that wants allocation-free timed
+ * regions warms up that many instances first (snarkvm_hip_alloc_stats tells whether anything grew). */
 int snarkvm_hip_batch_lanes(size_t npoints);
 /* Devices used by this process (the reference loops over `ngpus()`, snarkvm.cu:123-151).  Default: every visible device, or
  * the comma-separated list in SNARKVM_HIP_DEVICES.  snarkvm_hip_set_devices selects them explicitly; it must be called before
@@ -109,11 +109,26 @@ RustError snarkvm_hip_ntt_device_batch(void *const *d_inouts, size_t count, uint
  * to use, or NULL for any GPU) and snarkvm_hip_scope_end, calls of THIS thread whose operands and results live in device memory
  * - snarkvm_hip_ntt_device, _ntt_device_batch, _fr_mul_device, _fr_convert_device and the snarkvm_hip_fr_* vector kernels with
  * on_device = 1 - are enqueued on one stream, in call order, and return without waiting; snarkvm_hip_scope_end waits once.  The
- * 32-byte host `remainder` of snarkvm_hip_fr_divide_by_linear is delivered by scope_end.  Every other call (MSMs, host buffers, a
- * pointer on another GPU) first waits for the scope's queued work, so results are the same as without a scope.  Scopes do not
- * nest; a scope must be ended by the thread that began it. */
+ * 32-byte host `remainder` of snarkvm_hip_fr_divide_by_linear with on_device = 1 is delivered by scope_end.  Every other call (MSMs,
+ * host buffers, a pointer on another GPU) first waits for the scope's queued work, so results are the same as without a scope - and
+ * then runs on the scope's own stream: a thread inside a scope never waits for a free stream.  Scopes do not nest; a scope must be
+ * ended by the thread that began it. */
 RustError snarkvm_hip_scope_begin(const void *d_any);
 RustError snarkvm_hip_scope_end(void);
+/* The same with options.  SNARKVM_HIP_SCOPE_ASYNC_MSM: snarkvm_hip_msm_registered[_ex / _batch / _batch_ex] and
+ * snarkvm_hip_msm_g2_registered[_batch] calls of this thread whose scalars live in the scope's GPU memory are ENQUEUED too (on further
+ * streams of the scope, behind everything the scope has been given so far) and return at once: their `out` buffers are written by
+ * snarkvm_hip_scope_end - or by any call that has to wait for the scope - and must stay valid until then; the scalar vectors may be
+ * overwritten by later calls of the scope (those wait on the GPU until the MSM has read them).  How one prover thread keeps the GPU
+ * busy across the rounds of a proof: the commitments of round k run beside the transforms of round k + 1 and their host finishes run
+ * while the GPU works (the reference's rayon workers overlap the same way on the CPU, polycommit/sonic_pc/mod.rs:186-245).
+ * A thread holds at most 1 + 3 streams per scope and a GPU lends at most 6 of its 8 streams to scopes: the seventh scope_begin waits.
+ * snarkvm_hip_scope_stream: the hipStream_t the scope's device-resident calls are enqueued on (NULL outside a scope) - a caller that
+ * produces operands with its own kernels or copies (hipMemcpyAsync, torch.cuda.ExternalStream) orders them with the scope's calls by
+ * using this stream. */
+enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1 };
+RustError snarkvm_hip_scope_begin_ex(const void *d_any, uint32_t flags);
+void *snarkvm_hip_scope_stream(void);
 
 /* Register a base vector once (SRS powers are static per proving key; the reference re-uploads
  * 104 B/point on every call, snarkvm.cu:262-275).  `points` is a Rust `[G1Affine]` with the given
@@ -291,6 +306,12 @@ double snarkvm_hip_get_phase_ms(int i);
 /* How the in-library coalescer grouped concurrent callers of proof-sized G1 MSMs so far: out[4] = {batches dispatched, tickets
  * (MSM instances) in them, largest batch, batches of a single ticket}; reset != 0 clears the counters. */
 void snarkvm_hip_coalescer_stats(uint64_t *out, int reset);
+
+/* Workspace growth of the library since the last reset: out[5] = {device allocations, device bytes, pinned-host allocations,
+ * pinned bytes, microseconds spent inside them}.  Every lane grows its buffers on demand (hipFree / hipMalloc: the one thing here that
+ * synchronises the whole device behind the caller's back); a caller that wants an allocation-free timed region warms the same call
+ * shape first and can check with this that nothing grew. */
+void snarkvm_hip_alloc_stats(uint64_t *out, int reset);
 
 /* Block until all queued work of every device in use has finished. */
 RustError snarkvm_hip_synchronize(void);

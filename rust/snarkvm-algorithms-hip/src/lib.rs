@@ -123,7 +123,10 @@ mod sys {
         ) -> Error;
         pub fn snarkvm_hip_free_bases(handle: *mut c_void);
         pub fn snarkvm_hip_scope_begin(d_any: *const c_void) -> Error;
+        pub fn snarkvm_hip_scope_begin_ex(d_any: *const c_void, flags: u32) -> Error;
         pub fn snarkvm_hip_scope_end() -> Error;
+        pub fn snarkvm_hip_scope_stream() -> *mut c_void;
+        pub fn snarkvm_hip_alloc_stats(out: *mut u64, reset: i32);
         pub fn snarkvm_hip_coalescer_stats(out: *mut u64, reset: i32);
         pub fn snarkvm_hip_msm_registered_ex(
             out: *mut c_void,
@@ -308,11 +311,24 @@ pub mod resident {
 
     /// Deferred synchronisation for device-resident operands (include/snarkvm_hip.h: snarkvm_hip_scope_begin / _end): while the guard
     /// lives, this thread's calls on device vectors are only enqueued; dropping it waits once.  One guard per thread at a time.
-    pub struct Scope(());
+    /// The C scope belongs to the thread that began it (`snarkvm_hip_scope_end` on another thread is a no-op there and would leave the
+    /// first thread's stream bound forever): the guard is neither `Send` nor `Sync`.
+    pub struct Scope(core::marker::PhantomData<*mut ()>);
+    /// `Scope::begin_with`: MSMs over registered bases with device-resident scalars are enqueued too; their outputs are written when the
+    /// scope ends (include/snarkvm_hip.h: SNARKVM_HIP_SCOPE_ASYNC_MSM).  The output buffers must outlive the guard.
+    pub const SCOPE_ASYNC_MSM: u32 = 1;
     impl Scope {
         pub fn begin(device_ptr: *const c_void) -> Result<Self, Error> {
             unsafe { sys::snarkvm_hip_scope_begin(device_ptr) }.into_result()?;
-            Ok(Scope(()))
+            Ok(Scope(core::marker::PhantomData))
+        }
+        pub fn begin_with(device_ptr: *const c_void, flags: u32) -> Result<Self, Error> {
+            unsafe { sys::snarkvm_hip_scope_begin_ex(device_ptr, flags) }.into_result()?;
+            Ok(Scope(core::marker::PhantomData))
+        }
+        /// The `hipStream_t` the scope's calls are enqueued on (for the caller's own copies / kernels that feed them).
+        pub fn stream(&self) -> *mut c_void {
+            unsafe { sys::snarkvm_hip_scope_stream() }
         }
         /// Ends the scope and reports an error of the queued work (dropping the guard ignores it).
         pub fn end(self) -> Result<(), Error> {
@@ -324,6 +340,13 @@ pub mod resident {
         fn drop(&mut self) {
             let _ = unsafe { sys::snarkvm_hip_scope_end() };
         }
+    }
+
+    /// Workspace growth since the last reset: (device allocations, device bytes, pinned allocations, pinned bytes, microseconds inside them).
+    pub fn alloc_stats(reset: bool) -> (u64, u64, u64, u64, u64) {
+        let mut v = [0u64; 5];
+        unsafe { sys::snarkvm_hip_alloc_stats(v.as_mut_ptr(), reset as i32) };
+        (v[0], v[1], v[2], v[3], v[4])
     }
 
     /// How the in-library coalescer grouped concurrent callers of proof-sized MSMs: (batches, instances, largest batch, single-instance batches).

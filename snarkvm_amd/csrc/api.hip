@@ -10,6 +10,31 @@
 #include "ffl.hip.h"
 
 runtime_t g_rt;
+static std::atomic<uint64_t> g_alloc_stats[5];  // {device allocations, device bytes, pinned allocations, pinned bytes, microseconds}
+void sv_alloc_note(int slot, size_t bytes, double ms) {
+    g_alloc_stats[slot].fetch_add(1, std::memory_order_relaxed);
+    g_alloc_stats[slot + 1].fetch_add(bytes, std::memory_order_relaxed);
+    g_alloc_stats[4].fetch_add((uint64_t)(ms * 1e3), std::memory_order_relaxed);
+}
+
+static std::mutex g_free_mu;
+static std::vector<void*> g_free_list;
+static std::atomic<size_t> g_free_pending{0};
+void sv_defer_free(void* p) {
+    std::lock_guard<std::mutex> lk(g_free_mu);
+    g_free_list.push_back(p);
+    g_free_pending.store(g_free_list.size(), std::memory_order_relaxed);
+}
+void sv_drain_frees() {
+    if (!g_free_pending.load(std::memory_order_relaxed)) return;  // the common case: one relaxed load per call
+    std::vector<void*> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_free_mu);
+        mine.swap(g_free_list);
+        g_free_pending.store(0, std::memory_order_relaxed);
+    }
+    for (void* p : mine) (void)hipFree(p);  // hipFree takes a pointer of any device
+}
 
 extern "C" {
 
@@ -67,6 +92,12 @@ void snarkvm_hip_coalescer_stats(uint64_t* out, int reset) {
         if (reset) g_co_stats[i].store(0);
     }
 }
+void snarkvm_hip_alloc_stats(uint64_t* out, int reset) {
+    for (int i = 0; i < 5; i++) {
+        if (out) out[i] = g_alloc_stats[i].load();
+        if (reset) g_alloc_stats[i].store(0);
+    }
+}
 RustError snarkvm_hip_synchronize(void) {
     API_TRY
     g_rt.configure();
@@ -90,20 +121,42 @@ RustError snarkvm_hip_synchronize(void) {
 // small host results (the remainder of fr_divide_by_linear) are delivered by _end.  How a prover that keeps its polynomials in HBM
 // issues a whole round - or the same round of many proofs in lock step - without a stream synchronisation per call (~40 us each
 // on this stack: 45 transforms per proof).  Calls that leave the scope's lane (MSMs, host buffers) wait for the scope first.
-RustError snarkvm_hip_scope_begin(const void* d_any) {
+RustError snarkvm_hip_scope_begin_ex(const void* d_any, uint32_t flags) {
     API_TRY
     thread_scope_t& sc = tl_scope();
     if (sc.lane) throw hip_failure{hipErrorInvalidValue, "scope_begin: the calling thread already has an open scope", __LINE__};
-    lane_guard lg;
-    lg.acquire(device_for(d_any, d_any ? 1 : 0), 1);
-    lane_t* l = lg.lanes[0];
-    sc.prev_device = lg.prev_device;
-    lg.lanes.clear();       // ownership of the lane (and of the device selection) moves to the scope
-    lg.prev_device = -1;
+    if (flags & ~(uint32_t)SNARKVM_HIP_SCOPE_ASYNC_MSM) throw hip_failure{hipErrorInvalidValue, "scope_begin: unknown flag", __LINE__};
+    g_rt.configure();
+    const int nd = (int)g_rt.devs.size();
+    int dev = device_for(d_any, d_any ? 1 : 0);
+    if (dev < 0) dev = (int)(g_rt.rr.fetch_add(1) % (uint32_t)nd);
+    device_t* d = g_rt.devs[dev].get();
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = 0;
+    lane_t* l = d->take_for_scope(true);  // waits while the GPU's scopes hold SCOPE_LANES_MAX lanes
+    try {
+        HIP_TRY(hipSetDevice(d->physical));
+        d->init();
+        tu_kernel_attributes(d->logical);
+    } catch (...) {
+        d->give(l, true);
+        (void)hipSetDevice(prev);
+        throw;
+    }
     l->begin_call();
     l->in_scope = true;
+    l->pin_used = 0;
+    l->scope_events_used = 0;
+    sc = thread_scope_t();
     sc.lane = l;
+    sc.prev_device = prev;
+    sc.flags = flags;
     API_CATCH
+}
+RustError snarkvm_hip_scope_begin(const void* d_any) { return snarkvm_hip_scope_begin_ex(d_any, 0); }
+void* snarkvm_hip_scope_stream(void) {
+    lane_t* l = tl_scope().lane;
+    return l ? (void*)l->stream : nullptr;
 }
 RustError snarkvm_hip_scope_end(void) {
     thread_scope_t& sc = tl_scope();
@@ -111,19 +164,25 @@ RustError snarkvm_hip_scope_end(void) {
     if (!l) return ok();
     RustError r = ok();
     try {
-        l->flush_scope();
+        scope_flush();
     } catch (const hip_failure& f) {
         r = from_failure(f);
+    } catch (const std::exception& e) {
+        r = fail(1, std::string("snarkvm_hip: scope_end: ") + e.what());
     } catch (...) {
         r = fail(1, "snarkvm_hip: scope_end failed");
     }
     l->in_scope = false;
     l->deferred.clear();
     l->deferred_bytes = 0;
-    sc.lane = nullptr;
-    l->dev->give(l);
-    if (sc.prev_device >= 0) (void)hipSetDevice(sc.prev_device);
-    sc.prev_device = -1;
+    for (int i = 0; i < sc.naux; i++) {
+        (void)hipStreamSynchronize(sc.aux[i]->stream);  // (already idle unless the flush failed half-way)
+        sc.aux[i]->dev->give(sc.aux[i], true);
+    }
+    const int prev = sc.prev_device;
+    sc = thread_scope_t();
+    l->dev->give(l, true);
+    if (prev >= 0) (void)hipSetDevice(prev);
     return r;
 }
 
@@ -138,6 +197,7 @@ static void register_bases_impl(snarkvm_hip_bases_t** handle, const void* points
     if (npoints && !points) throw hip_failure{hipErrorInvalidValue, "register_bases: null points", __LINE__};
     if (ffi_affine_sz < 104 || (ffi_affine_sz & 7)) throw hip_failure{hipErrorInvalidValue, "register_bases: bad stride", __LINE__};
     check_tables(tables, table_bits, "register_bases");
+    scope_flush();  // device-resident points may come out of the caller's open scope; the per-device workers below are other threads
     const int nd = g_rt.ndev();
     std::unique_ptr<snarkvm_hip_bases> h(new snarkvm_hip_bases());
     h->n = npoints;
@@ -231,6 +291,7 @@ static void check_window_bits(int window_bits, const char* who) {
 static void msm_registered_host_scalars(void* out, const snarkvm_hip_bases* h, size_t off0, size_t n0, size_t off1, size_t n1, const void* scalars,
                                         int scalars_montgomery, int window_bits) {
     const size_t n = n0 + n1;
+    scope_flush();
     const int nd = g_rt.ndev();
     static const int trace = getenv("SNARKVM_HIP_TRACE") ? atoi(getenv("SNARKVM_HIP_TRACE")) : 0;
     const double t_begin = host_now_ms();
@@ -381,7 +442,10 @@ RustError snarkvm_hip_msm_registered(void* out, const snarkvm_hip_bases_t* h, si
     if (!h || offset + npoints > h->n) throw hip_failure{hipErrorInvalidValue, "msm_registered: range exceeds the registered bases", __LINE__};
     check_window_bits(window_bits, "msm_registered");
     if (!out || (npoints && !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered: null argument", __LINE__};
-    if (msm_coalescible(*h, npoints, window_bits)) {
+    msm_req_t one;
+    one.off0 = offset, one.n0 = npoints, one.scalars = scalars, one.out = out;
+    if (msm_scope_enqueue<fq_t>(*h, &one, 1, scalars_on_device, 0, window_bits)) {
+    } else if (msm_coalescible(*h, npoints, window_bits)) {
         msm_single_coalesced(out, h, offset, npoints, 0, 0, scalars, scalars_on_device, 0, window_bits);
     } else if (!scalars_on_device) {
         msm_registered_host_scalars(out, h, offset, npoints, 0, 0, scalars, 0, window_bits);
@@ -402,7 +466,10 @@ RustError snarkvm_hip_msm_registered_ex(void* out, const snarkvm_hip_bases_t* h,
     check_window_bits(window_bits, "msm_registered_ex");
     const size_t n = n0 + n1;
     if (!out || (n && !scalars)) throw hip_failure{hipErrorInvalidValue, "msm_registered_ex: null argument", __LINE__};
-    if (msm_coalescible(*h, n, window_bits)) {
+    msm_req_t one;
+    one.off0 = off0, one.n0 = n0, one.off1 = n1 ? off1 : 0, one.n1 = n1, one.scalars = scalars, one.out = out;
+    if (msm_scope_enqueue<fq_t>(*h, &one, 1, scalars_on_device, scalars_montgomery, window_bits)) {
+    } else if (msm_coalescible(*h, n, window_bits)) {
         msm_single_coalesced(out, h, off0, n0, off1, n1, scalars, scalars_on_device, scalars_montgomery, window_bits);
     } else if (!scalars_on_device) {
         msm_registered_host_scalars(out, h, off0, n0, off1, n1, scalars, scalars_montgomery, window_bits);

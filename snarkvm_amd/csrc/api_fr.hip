@@ -332,7 +332,8 @@ static RustError fr_divide_by_linear_impl(void* quotient, void* remainder, const
         fr_mem_t* drem = c.poly[2].as<fr_mem_t>();
         fr_suffix_horner(c, din, n, z, dq, 1, drem, count, stride, stride);
         if (dq) fr_finish_out(c, dq, quotient, n - 1, on_device);
-        if (remainder) c.host_result(remainder, drem, sizeof(fr_mem_t) * count);  // inside a scope: delivered by snarkvm_hip_scope_end
+        // device operands inside a scope: delivered by snarkvm_hip_scope_end; host operands: the call waits below, the value is there on return
+        if (remainder) c.host_result(remainder, drem, sizeof(fr_mem_t) * count, on_device != 0);
         fr_call_done(c, on_device);
     }
     API_END

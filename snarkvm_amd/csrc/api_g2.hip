@@ -84,13 +84,26 @@ static RustError msm_g2_single_coalesced(void* out, const snarkvm_hip_bases_g2_t
     msm_coalesced<fq2_t>(*h, &t, 1);
     API_CATCH
 }
+// the same call from a thread inside an SNARKVM_HIP_SCOPE_ASYNC_MSM scope: only enqueued (runtime.hip.h::msm_scope_enqueue)
+static RustError msm_g2_scope_enqueue(void* out, const snarkvm_hip_bases_g2_t* h, size_t offset, size_t npoints, const void* scalars, int window_bits, bool* queued) {
+    API_TRY
+    msm_req_t one;
+    one.off0 = offset, one.n0 = npoints, one.scalars = scalars, one.out = out;
+    *queued = msm_scope_enqueue<fq2_t>(*h, &one, 1, 1, 0, window_bits);
+    API_CATCH
+}
 #endif
 RustError snarkvm_hip_msm_g2_registered(void* out, const snarkvm_hip_bases_g2_t* h, size_t offset, size_t npoints, const void* scalars,
                                         int scalars_on_device, int window_bits) {
 #ifndef SV_NO_G2
-    if (h && out && scalars && offset + npoints <= h->n && (!window_bits || (window_bits >= 2 && window_bits <= MSM_C_MAX)) && g_rt.configured &&
-        msm_coalescible(*h, npoints, window_bits))
-        return msm_g2_single_coalesced(out, h, offset, npoints, scalars, scalars_on_device, window_bits);
+    if (h && out && scalars && offset + npoints <= h->n && (!window_bits || (window_bits >= 2 && window_bits <= MSM_C_MAX)) && g_rt.configured) {
+        if (tl_scope().lane && (tl_scope().flags & SNARKVM_HIP_SCOPE_ASYNC_MSM) && scalars_on_device && npoints) {
+            bool queued = false;
+            const RustError e = msm_g2_scope_enqueue(out, h, offset, npoints, scalars, window_bits, &queued);
+            if (e.code || queued) return e;
+        }
+        if (msm_coalescible(*h, npoints, window_bits)) return msm_g2_single_coalesced(out, h, offset, npoints, scalars, scalars_on_device, window_bits);
+    }
 #endif
     API_BEGIN_DEV(device_for(scalars, (scalars_on_device && npoints) ? 1 : 0))
 #ifdef SV_NO_G2

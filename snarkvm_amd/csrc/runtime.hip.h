@@ -73,16 +73,39 @@ static double host_now_ms() {
 // ------------------------------------------------------------------------------------------------
 // runtime: devices, lanes (the reference's (dev, stream) resource tokens), staging buffers
 // ------------------------------------------------------------------------------------------------
+// Workspace growth is the one thing in the library that synchronises the whole device behind the caller's back (hipFree waits for
+// every stream): counted, so that a caller - or a test - can see that a timed region allocated nothing
+// (snarkvm_hip_alloc_stats: {device allocations, device bytes, pinned allocations, pinned bytes, microseconds inside them}).
+void sv_alloc_note(int slot, size_t bytes, double ms);  // api.hip: the process-wide counters (this header is compiled into four units)
+// A buffer that is outgrown in the middle of a call is not freed on the spot: hipFree waits for EVERY stream of the device, i.e. the
+// second instance of a pipelined batch would only be enqueued after the first one had finished (the "tables1" leg of round 4's bench:
+// 93.6 instead of 37 ms per step when lane 1 grew its workspace behind lane 0's running MSM).  The old block goes to a process-wide
+// list and is released by sv_drain_frees() when a call ends (lane_t::end_call, scope flush), or at once when an allocation fails.
+void sv_defer_free(void* p);
+void sv_drain_frees();
+struct alloc_timer_t {
+    double t0;
+    int slot;
+    size_t bytes;
+    alloc_timer_t(int s, size_t b) : t0(host_now_ms()), slot(s), bytes(b) {}
+    ~alloc_timer_t() { sv_alloc_note(slot, bytes, host_now_ms() - t0); }
+};
 struct dev_buf {
     void* p = nullptr;
     size_t cap = 0;
     void ensure(size_t bytes) {  // on the CURRENT device (a lane guard has selected it)
         if (bytes <= cap) return;
-        if (p) HIP_TRY(hipFree(p));
+        size_t want = bytes + bytes / 8 + 256;
+        alloc_timer_t timer(0, want);
+        if (p) sv_defer_free(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        HIP_TRY(hipMalloc(&p, want));
+        if (hipMalloc(&p, want) != hipSuccess) {  // out of memory with outgrown blocks still parked: release them and try once more
+            (void)hipGetLastError();
+            p = nullptr;
+            sv_drain_frees();
+            HIP_TRY(hipMalloc(&p, want));
+        }
         cap = want;
     }
     template <class T>
@@ -95,10 +118,11 @@ struct pinned_buf {  // page-locked host staging (the reference's per-GPU pinned
     size_t cap = 0;
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
+        size_t want = bytes + bytes / 8 + 4096;
+        alloc_timer_t timer(2, want);
         if (p) HIP_TRY(hipHostFree(p));
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 8 + 4096;
         HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
         cap = want;
     }
@@ -146,6 +170,19 @@ struct lane_t {
     };
     std::vector<deferred_out_t> deferred;  // host results parked in pin2 until the scope ends
     size_t deferred_bytes = 0;
+    // a lane owned by a scope (its main lane or one of its MSM lanes): `pin` is handed out piecewise to the MSMs the scope has enqueued
+    // (bit planes + instance tables stay where they are until the scope's flush has collected them), events that must outlive a call
+    size_t pin_used = 0;
+    std::vector<hipEvent_t> scope_events;
+    size_t scope_events_used = 0;
+    hipEvent_t scope_event() {
+        if (scope_events_used == scope_events.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            scope_events.push_back(e);
+        }
+        return scope_events[scope_events_used++];
+    }
     // profiling
     std::vector<phase_rec> phases;
     std::vector<hipEvent_t> event_pool;
@@ -171,8 +208,9 @@ struct lane_t {
     }
     // a small host result (<= a few KB) of a call that may run inside a scope: copied now and waited for, or parked in pinned
     // memory and delivered by snarkvm_hip_scope_end
-    void host_result(void* dst, const void* d_src, size_t bytes) {
-        if (!in_scope) {
+    // may_defer = false: the call itself waits for the stream (host operands), so the value must be in `dst` when it returns
+    void host_result(void* dst, const void* d_src, size_t bytes, bool may_defer = true) {
+        if (!in_scope || !may_defer) {
             HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
             return;
         }
@@ -200,6 +238,12 @@ struct device_t {
     std::mutex mu;
     std::condition_variable cv;
     uint32_t busy = 0;
+    // lanes held by deferred-synchronisation scopes (for as long as the scope is open).  At most SCOPE_LANES_MAX of them: two lanes of
+    // every device always belong to calls that return their lane when they return, so a thread that waits for a lane - the ninth
+    // scope_begin, a call on another device from inside a scope, the per-device worker threads of a multi-GPU call - waits for
+    // something that ends (round-4 review: eight scopes that each issued an MSM held all eight lanes and waited for a ninth).
+    static constexpr int SCOPE_LANES_MAX = LANES - 2;
+    int scope_held = 0;
 
     void init() {  // the calling thread has this device current
         std::lock_guard<std::mutex> lk(init_mu);
@@ -259,12 +303,41 @@ struct device_t {
             }
         return false;
     }
-    void give(lane_t* l) {
+    // n lanes (<= want) without waiting; 0 when none is free
+    int try_take_n(lane_t** out, int want) {
+        std::lock_guard<std::mutex> lk(mu);
+        int got = 0;
+        for (int l = 0; l < LANES && got < want; l++)
+            if (!(busy & (1u << l))) {
+                busy |= 1u << l;
+                out[got++] = &lane[l];
+            }
+        return got;
+    }
+    // a lane for a scope: block = the scope's main lane (waits for a free lane AND for room under the cap); else an extra MSM lane, only if
+    // one is free right now
+    lane_t* take_for_scope(bool block) {
+        std::unique_lock<std::mutex> lk(mu);
+        auto room = [&] { return busy != (1u << LANES) - 1 && scope_held < SCOPE_LANES_MAX; };
+        if (block)
+            cv.wait(lk, room);
+        else if (!room())
+            return nullptr;
+        for (int l = 0; l < LANES; l++)
+            if (!(busy & (1u << l))) {
+                busy |= 1u << l;
+                scope_held++;
+                return &lane[l];
+            }
+        return nullptr;
+    }
+    void give(lane_t* l, bool from_scope = false) {
         {
             std::lock_guard<std::mutex> lk(mu);
             busy &= ~(1u << l->index);
+            if (from_scope) scope_held--;
         }
-        cv.notify_one();
+        cv.notify_all();  // waiters wait on different conditions (a free lane / room under the scope cap)
     }
 };
 
@@ -357,23 +430,62 @@ static void tu_kernel_attributes(int logical) {
 // RAII ownership of lanes.  Selecting a lane makes its device current on the calling thread (the HIP current device is per
 // host thread - rayon workers!) and restores the previous one on release.
 // Deferred-synchronisation scope of the calling thread (snarkvm_hip_scope_begin / _end): one lane stays bound to the thread; its
-// device-resident calls borrow that lane and return after the enqueue.  Anything that takes OTHER lanes (MSMs, host-buffer calls,
-// another device) first waits for the scope's stream - what it reads may have been produced inside the scope.
+// device-resident calls borrow that lane and return after the enqueue.  Anything that takes OTHER lanes (host-buffer MSMs, another
+// device) first waits for the scope's work - what it reads may have been produced inside the scope - and then runs on the scope's own
+// lane (plus whatever further lanes are free right now): a thread inside a scope never waits for a lane.
+// SNARKVM_HIP_SCOPE_ASYNC_MSM: MSMs over registered bases with device-resident scalars are enqueued as well - on up to SCOPE_AUX_MAX
+// further lanes of the scope, in turn, each behind an event of the scope's stream - and their host finishes (the Horner chain over the
+// bit planes) run when the scope is flushed.
+static constexpr int SCOPE_AUX_MAX = 3;
+struct scope_pending_t {
+    hipEvent_t done;               // everything the finish reads has arrived in pinned memory
+    std::function<void()> finish;  // host Horner chains -> the callers' `out` buffers
+};
 struct thread_scope_t {
     lane_t* lane = nullptr;
     int prev_device = -1;
+    unsigned flags = 0;
+    lane_t* aux[SCOPE_AUX_MAX] = {};
+    int naux = 0;
+    unsigned aux_rr = 0;
+    bool aux_exhausted = false;  // a try for a further lane failed: not tried again in this scope
+    std::vector<scope_pending_t> pending;
 };
 static thread_scope_t& tl_scope() {
     static thread_local thread_scope_t s;
     return s;
 }
+// wait for everything the calling thread's scope has enqueued; deliver the results it owes (MSM outputs, parked host values)
 static void scope_flush() {
-    if (lane_t* l = tl_scope().lane) l->flush_scope();
+    thread_scope_t& sc = tl_scope();
+    if (!sc.lane) return;
+    std::exception_ptr err;
+    // in enqueue order: the host finishes of the early MSMs run while the GPU still works on the later ones
+    for (scope_pending_t& p : sc.pending) {
+        try {
+            HIP_TRY(hipEventSynchronize(p.done));
+            p.finish();
+        } catch (...) {
+            if (!err) err = std::current_exception();
+        }
+    }
+    sc.pending.clear();
+    try {
+        sc.lane->flush_scope();
+        for (int i = 0; i < sc.naux; i++) HIP_TRY(hipStreamSynchronize(sc.aux[i]->stream));
+    } catch (...) {
+        if (!err) err = std::current_exception();
+    }
+    sc.lane->pin_used = 0;
+    sc.lane->scope_events_used = 0;
+    for (int i = 0; i < sc.naux; i++) sc.aux[i]->pin_used = 0, sc.aux[i]->scope_events_used = 0;
+    if (err) std::rethrow_exception(err);
 }
 struct lane_guard {
     std::vector<lane_t*> lanes;
     int prev_device = -1;
-    bool borrowed = false;
+    bool borrowed = false;        // every lane belongs to the thread's scope (nothing to give back)
+    bool first_borrowed = false;  // lanes[0] is the scope's lane, the others are ours
     lane_guard() {}
     lane_guard(const lane_guard&) = delete;
     // one lane on logical device `dev`, or on the least busy device when dev < 0
@@ -382,6 +494,7 @@ struct lane_guard {
         if (sl && (dev < 0 || (dev < (int)g_rt.devs.size() && g_rt.devs[dev]->physical == sl->dev->physical))) {  // inside the thread's scope: its lane, its device is already current
             borrowed = true;
             lanes.push_back(sl);
+            tu_kernel_attributes(sl->dev->logical);  // this unit's kernels may not have run on the device yet (the scope was opened by api.hip)
             return;
         }
         acquire(dev, 1);
@@ -389,13 +502,25 @@ struct lane_guard {
     void acquire(int dev, int want) {
         scope_flush();
         g_rt.configure();
-        if (prev_device < 0 && hipGetDevice(&prev_device) != hipSuccess) prev_device = 0;
         const int nd = (int)g_rt.devs.size();
+        if (dev >= nd) throw hip_failure{hipErrorInvalidDevice, "logical device index out of range", __LINE__};
+        if (lane_t* sl = tl_scope().lane) {
+            if (dev < 0 || g_rt.devs[dev]->physical == sl->dev->physical) {
+                // the scope's own lane (idle now) serves as the first lane of this call; more only if they are free right now
+                lanes.push_back(sl);
+                first_borrowed = true;
+                tu_kernel_attributes(sl->dev->logical);
+                lane_t* more[device_t::LANES];
+                const int n = want > 1 ? sl->dev->try_take_n(more, want - 1) : 0;
+                for (int i = 0; i < n; i++) lanes.push_back(more[i]);
+                return;
+            }
+        }
+        if (prev_device < 0 && hipGetDevice(&prev_device) != hipSuccess) prev_device = 0;
         device_t* d = nullptr;
         lane_t* got[device_t::LANES];
         int n = 0;
         if (dev >= 0) {
-            if (dev >= nd) throw hip_failure{hipErrorInvalidDevice, "logical device index out of range", __LINE__};
             d = g_rt.devs[dev].get();
         } else {
             const uint32_t s = g_rt.rr.fetch_add(1);
@@ -427,7 +552,7 @@ struct lane_guard {
     lane_t& c() { return *lanes[0]; }
     ~lane_guard() {
         if (borrowed) return;
-        for (lane_t* l : lanes) l->dev->give(l);
+        for (size_t i = first_borrowed ? 1 : 0; i < lanes.size(); i++) lanes[i]->dev->give(lanes[i]);
         if (prev_device >= 0) (void)hipSetDevice(prev_device);
     }
 };
@@ -458,9 +583,11 @@ inline void lane_t::flush_scope() {  // wait for everything the scope has enqueu
     deferred.clear();
     deferred_bytes = 0;
     if (!tw_leases.empty()) ntt_tw_release(dev, tw_leases);
+    sv_drain_frees();
 }
 inline void lane_t::end_call() {
     if (in_scope) return;  // nothing is waited for; leases are held until the scope ends
+    sv_drain_frees();
     if (!tw_leases.empty()) {
         HIP_TRY(hipStreamSynchronize(stream));
         ntt_tw_release(dev, tw_leases);
@@ -781,7 +908,9 @@ template <class F>
 static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* host_planes, int window_bits,
                              const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
                              size_t table_stride = 0, bool profile = true, int table_bits = 0, const msm_multi_t* mu = nullptr,
-                             const msm_bucket_sink_t* sink = nullptr) {
+                             const msm_bucket_sink_t* sink = nullptr, hipEvent_t scalars_read = nullptr) {
+    // scalars_read: recorded on the lane's stream behind the last kernel that reads the scalar vectors (the digit kernel; wide windows:
+    // the fused level-1 scatter) - from there on the caller may overwrite them while the MSM is still running
     // mu != nullptr: fused multi-instance run (msm_sort.hip.h): n = mu->npad padded positions, d_bases = the handle's table array,
     // d_scalars unused (the instance table carries the pointers), one bucket window per instance; host_planes holds
     // mu->K * 2 * (fold_m + 1) planes.
@@ -867,6 +996,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         else
             hipLaunchKernelGGL((msm_digits_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st, d_scalars, c.digits.as<uint16_t>(), dp);
         phase_end();
+        if (scalars_read) HIP_TRY(hipEventRecord(scalars_read, st));
     }
     int rounds = 0;
     // see step 5; a fused multi-instance run never reads back either: its instances are small (<= 2^18 points each), so the
@@ -963,6 +1093,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
         break;
             switch (pl.c) { SV_FUSED_SCATTER(17) SV_FUSED_SCATTER(18) SV_FUSED_SCATTER(19) SV_FUSED_SCATTER(20) SV_FUSED_SCATTER(21) SV_FUSED_SCATTER(22) }
 #undef SV_FUSED_SCATTER
+            if (scalars_read) HIP_TRY(hipEventRecord(scalars_read, st));
         } else if (wide) {
             phase_begin("msm_sort_level1");
             hipLaunchKernelGGL((radix_hist1_kernel<uint32_t>), dim3((unsigned)tiles1), dim3(SORT_THREADS), 0, st, c.digits.as<uint32_t>(), counts1, rp);
@@ -1329,6 +1460,7 @@ template <class F>
 static void msm_host_chunked(void* out, const void* points, size_t npoints, const void* scalars, size_t stride) {
     const size_t min_stride = 2 * sizeof(typename F::mem_t) + 8;
     if (stride < min_stride || (stride & 7)) throw hip_failure{hipErrorInvalidValue, "msm: bad ffi_affine_sz for this curve", __LINE__};
+    scope_flush();  // (the per-device workers of a multi-GPU call are other threads)
     const int nd = g_rt.ndev();
     static const int trace = getenv("SNARKVM_HIP_TRACE") ? atoi(getenv("SNARKVM_HIP_TRACE")) : 0;
     const double t_begin = host_now_ms();
@@ -1530,17 +1662,132 @@ static bool msm_handle_fusable(const bases_handle_t<F>& h, int window_bits) {
     const msm_plan_t pl = msm_make_plan(SORT_TILE, h.table_bits, h.tables, h.table_bits);  // what msm_run will ask of a fused group
     return pl.W == 1 && pl.c == h.table_bits;
 }
+// planes a fused instance leaves: two tail windows (row sums, column sums) of fold_m + 1 bits, fold_m = table_bits / 2 (msm_run)
+template <class F>
+static size_t msm_fuse_planes(const bases_handle_t<F>& h) {
+    return 2 * ((size_t)h.table_bits / 2 + 1);
+}
+static size_t msm_padded(size_t n) { return (n + SORT_TILE - 1) / SORT_TILE * SORT_TILE; }
+// the jobs the instances `mine` (indices into req) make on one device: fused groups of small instances (in order of appearance), single
+// instances otherwise
+template <class F>
+static std::vector<std::vector<size_t>> msm_make_jobs(const bases_handle_t<F>& h, const msm_req_t* req, const std::vector<size_t>& mine, bool fusable_handle) {
+    std::vector<std::vector<size_t>> jobs;
+    std::vector<size_t> group;
+    size_t group_entries = 0;
+    auto flush = [&] {
+        if (!group.empty()) jobs.push_back(group);  // a lone instance takes the single-MSM path (its own planner)
+        group.clear();
+        group_entries = 0;
+    };
+    for (size_t k : mine) {
+        const size_t tot = req[k].n0 + req[k].n1;
+        const bool small = fusable_handle && tot > 0 && tot <= MSM_FUSE_MAX_PAIRS;
+        if (!small) {
+            jobs.push_back({k});
+            continue;
+        }
+        const size_t e = msm_padded(tot) * (size_t)h.tables;
+        if (!group.empty() && (group.size() >= msm_fuse_max_k() || group_entries + e > MSM_FUSE_MAX_ENTRIES)) flush();
+        group.push_back(k);
+        group_entries += e;
+    }
+    flush();
+    return jobs;
+}
+// pinned bytes job `job` needs: its bit planes, then (fused groups) its instance table
+template <class F>
+static void msm_job_staging(const bases_handle_t<F>& h, const std::vector<size_t>& job, size_t& plane_bytes, size_t& table_bytes) {
+    const size_t K = job.size();
+    plane_bytes = K > 1 ? K * msm_fuse_planes(h) * msm_point_bytes<F>() : msm_plane_bytes<F>();
+    table_bytes = K > 1 ? ((K + 1) * sizeof(msm_inst_t) + 255) / 256 * 256 : 0;
+}
+// Enqueue job `job` on lane c (device `dev`): host_planes / tab = its pinned staging (valid until the planes have been collected).
+template <class F>
+static msm_pending_t msm_enqueue_job(lane_t& c, const bases_handle_t<F>& h, int dev, const msm_req_t* req, const std::vector<size_t>& job, uint8_t* host_planes,
+                                     msm_inst_t* tab, int scalars_on_device, int scalars_montgomery, int window_bits, hipEvent_t scalars_read = nullptr) {
+    if (job.size() == 1) {
+        const msm_req_t& r = req[job[0]];
+        const size_t n = r.n0 + r.n1;
+        const uint4* d_sc = (const uint4*)r.scalars;
+        if (!scalars_on_device && n) {
+            // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
+            c.scalars.ensure(n * 32);
+            HIP_TRY(hipMemcpyAsync(c.scalars.p, r.scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+            d_sc = c.scalars.template as<uint4>();
+        }
+        return msm_run<F>(c, h.d[dev] + r.off0, d_sc, n, host_planes, window_bits, r.n1 ? h.d[dev] + r.off1 : nullptr, r.n1 ? r.n0 : ~(size_t)0, scalars_montgomery,
+                          h.tables, h.n, false, h.table_bits, nullptr, nullptr, scalars_read);
+    }
+    // fused group: instance table (pinned -> device), scalars of host callers packed into the lane's scalar buffer
+    const size_t K = job.size();
+    size_t npad = 0, sc_bytes = 0;
+    for (size_t q = 0; q < K; q++) sc_bytes += (req[job[q]].n0 + req[job[q]].n1) * 32;
+    if (!scalars_on_device) c.scalars.ensure(sc_bytes);
+    size_t sc_off = 0;
+    for (size_t q = 0; q < K; q++) {
+        const msm_req_t& r = req[job[q]];
+        const size_t n = r.n0 + r.n1;
+        msm_inst_t& in = tab[q];
+        in.n = (uint32_t)n;
+        in.n0 = r.n1 ? (uint32_t)r.n0 : in.n;
+        in.off0 = (uint32_t)r.off0;
+        in.off1 = r.n1 ? (uint32_t)r.off1 : 0u;
+        in.pstart = (uint32_t)npad;
+        in.ptiles = (uint32_t)(msm_padded(n) / SORT_TILE);
+        npad += msm_padded(n);
+        if (scalars_on_device) {
+            in.scalars = (const uint4*)r.scalars;
+        } else {
+            uint8_t* dst = c.scalars.template as<uint8_t>() + sc_off;
+            HIP_TRY(hipMemcpyAsync(dst, r.scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+            in.scalars = (const uint4*)dst;
+            sc_off += n * 32;
+        }
+    }
+    tab[K] = msm_inst_t{nullptr, 0, 0, 0, 0, (uint32_t)npad, 0};  // sentinel
+    c.poly[4].ensure((K + 1) * sizeof(msm_inst_t));
+    HIP_TRY(hipMemcpyAsync(c.poly[4].p, tab, (K + 1) * sizeof(msm_inst_t), hipMemcpyHostToDevice, c.stream));
+    msm_multi_t mu;
+    mu.d_inst = c.poly[4].template as<msm_inst_t>();
+    mu.K = (uint32_t)K;
+    mu.npad = npad;
+    mu.hn = h.n;
+    mu.plane_capacity = K * msm_fuse_planes(h);  // checked by msm_run BEFORE it enqueues the copy into the staging area
+    return msm_run<F>(c, h.d[dev], nullptr, npad, host_planes, 0, nullptr, ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits, &mu, nullptr, scalars_read);
+}
+// the host finish of job `job` (its planes have arrived): one Horner chain per instance, the instances of a fused group on several threads
+template <class F>
+static void msm_finish_job(const msm_req_t* req, const std::vector<size_t>& job, const msm_pending_t& pd, int max_threads = 8) {
+    if (job.size() == 1) {
+        std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
+        msm_collect<F>(*acc, pd);
+        acc->finish(req[job[0]].out);
+        return;
+    }
+    host_parallel_for(job.size(), max_threads, [&](size_t q) {
+        std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
+        msm_collect_inst<F>(*acc, pd, (int)q);
+        acc->finish(req[job[q]].out);
+    });
+}
+static void msm_check_requests(size_t hn, const msm_req_t* req, size_t count) {
+    for (size_t k = 0; k < count; k++) {
+        if (req[k].off0 + req[k].n0 > hn || (req[k].n1 && req[k].off1 + req[k].n1 > hn))
+            throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
+        if ((req[k].n0 + req[k].n1) && !req[k].scalars) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null scalar vector", __LINE__};
+        if (!req[k].out) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null output", __LINE__};
+    }
+}
 template <class F>
 static void msm_batch_run(const bases_handle_t<F>& h, const msm_req_t* req, size_t count, int scalars_on_device, int scalars_montgomery, int window_bits) {
     auto total = [&](size_t k) { return req[k].n0 + req[k].n1; };
+    scope_flush();  // the per-device workers below are other threads: what they read must be complete (and they cannot flush this thread's scope)
     const int nd = g_rt.ndev();
     std::vector<std::vector<size_t>> per_dev(nd);
     size_t largest = 0;
+    msm_check_requests(h.n, req, count);
     for (size_t k = 0; k < count; k++) {
-        if (req[k].off0 + req[k].n0 > h.n || (req[k].n1 && req[k].off1 + req[k].n1 > h.n))
-            throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};
-        if (total(k) && !req[k].scalars) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null scalar vector", __LINE__};
-        if (!req[k].out) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: null output", __LINE__};
         largest = total(k) > largest ? total(k) : largest;
         int dev = (int)(k % (size_t)nd);
         if (scalars_on_device && total(k)) {
@@ -1553,36 +1800,9 @@ static void msm_batch_run(const bases_handle_t<F>& h, const msm_req_t* req, size
     std::vector<int> devs;
     for (int d = 0; d < nd; d++)
         if (!per_dev[d].empty()) devs.push_back(d);
-    const size_t slot = msm_plane_bytes<F>();
     const bool fusable_handle = msm_handle_fusable(h, window_bits);
-    // planes a fused instance leaves: two tail windows (row sums, column sums) of fold_m + 1 bits, fold_m = table_bits / 2 (msm_run)
-    const size_t fuse_planes = 2 * ((size_t)h.table_bits / 2 + 1);
-    auto padded = [](size_t n) { return (n + SORT_TILE - 1) / SORT_TILE * SORT_TILE; };
     for_each_device(devs, [&](int dev) {
-        const std::vector<size_t>& mine = per_dev[dev];
-        // jobs of this device: fused groups of small instances (in order of appearance), single instances otherwise
-        std::vector<std::vector<size_t>> jobs;
-        {
-            std::vector<size_t> group;
-            size_t group_entries = 0;
-            auto flush = [&] {
-                if (!group.empty()) jobs.push_back(group);  // a lone instance takes the single-MSM path (its own planner)
-                group.clear();
-                group_entries = 0;
-            };
-            for (size_t k : mine) {
-                const bool small = fusable_handle && total(k) > 0 && total(k) <= MSM_FUSE_MAX_PAIRS;
-                if (!small) {
-                    jobs.push_back({k});
-                    continue;
-                }
-                const size_t e = padded(total(k)) * (size_t)h.tables;
-                if (!group.empty() && (group.size() >= msm_fuse_max_k() || group_entries + e > MSM_FUSE_MAX_ENTRIES)) flush();
-                group.push_back(k);
-                group_entries += e;
-            }
-            flush();
-        }
+        const std::vector<std::vector<size_t>> jobs = msm_make_jobs(h, req, per_dev[dev], fusable_handle);
         lane_guard lg;
         lg.acquire(dev, nlanes < (int)jobs.size() ? nlanes : (int)jobs.size());
         const int L = (int)lg.lanes.size();
@@ -1591,11 +1811,11 @@ static void msm_batch_run(const bases_handle_t<F>& h, const msm_req_t* req, size
         // pinned staging per lane: the bit planes of its jobs, then the instance tables of its fused jobs
         std::vector<size_t> plane_off(jobs.size()), table_off(jobs.size()), lane_bytes(L, 0);
         for (size_t i = 0; i < jobs.size(); i++) {
-            const size_t K = jobs[i].size();
+            size_t pb, tb;
+            msm_job_staging(h, jobs[i], pb, tb);
             plane_off[i] = lane_bytes[i % L];
-            lane_bytes[i % L] += K > 1 ? K * fuse_planes * msm_point_bytes<F>() : slot;
-            table_off[i] = lane_bytes[i % L];
-            lane_bytes[i % L] += K > 1 ? ((K + 1) * sizeof(msm_inst_t) + 255) / 256 * 256 : 0;
+            table_off[i] = plane_off[i] + pb;
+            lane_bytes[i % L] += pb + tb;
         }
         for (int l = 0; l < L; l++) {
             lg.lanes[l]->begin_call();
@@ -1603,78 +1823,83 @@ static void msm_batch_run(const bases_handle_t<F>& h, const msm_req_t* req, size
         }
         for (size_t i = 0; i < jobs.size(); i++) {
             lane_t& c = *lg.lanes[i % L];
-            uint8_t* host_planes = c.pin.template as<uint8_t>() + plane_off[i];
-            if (jobs[i].size() == 1) {
-                const msm_req_t& r = req[jobs[i][0]];
-                const size_t n = r.n0 + r.n1;
-                const uint4* d_sc = (const uint4*)r.scalars;
-                if (!scalars_on_device && n) {
-                    // the lane's previous instance may still be reading its scalar buffer: stream order serialises the copy behind it
-                    c.scalars.ensure(n * 32);
-                    HIP_TRY(hipMemcpyAsync(c.scalars.p, r.scalars, n * 32, hipMemcpyHostToDevice, c.stream));
-                    d_sc = c.scalars.template as<uint4>();
-                }
-                pend[i] = msm_run<F>(c, h.d[dev] + r.off0, d_sc, n, host_planes, window_bits, r.n1 ? h.d[dev] + r.off1 : nullptr, r.n1 ? r.n0 : ~(size_t)0,
-                                     scalars_montgomery, h.tables, h.n, false, h.table_bits);
-            } else {
-                // fused group: instance table (pinned -> device), scalars of host callers packed into the lane's scalar buffer
-                const size_t K = jobs[i].size();
-                msm_inst_t* tab = (msm_inst_t*)(c.pin.template as<uint8_t>() + table_off[i]);
-                size_t npad = 0, sc_bytes = 0;
-                for (size_t q = 0; q < K; q++) sc_bytes += total(jobs[i][q]) * 32;
-                if (!scalars_on_device) c.scalars.ensure(sc_bytes);
-                size_t sc_off = 0;
-                for (size_t q = 0; q < K; q++) {
-                    const msm_req_t& r = req[jobs[i][q]];
-                    const size_t n = r.n0 + r.n1;
-                    msm_inst_t& in = tab[q];
-                    in.n = (uint32_t)n;
-                    in.n0 = r.n1 ? (uint32_t)r.n0 : in.n;
-                    in.off0 = (uint32_t)r.off0;
-                    in.off1 = r.n1 ? (uint32_t)r.off1 : 0u;
-                    in.pstart = (uint32_t)npad;
-                    in.ptiles = (uint32_t)(padded(n) / SORT_TILE);
-                    npad += padded(n);
-                    if (scalars_on_device) {
-                        in.scalars = (const uint4*)r.scalars;
-                    } else {
-                        uint8_t* dst = c.scalars.template as<uint8_t>() + sc_off;
-                        HIP_TRY(hipMemcpyAsync(dst, r.scalars, n * 32, hipMemcpyHostToDevice, c.stream));
-                        in.scalars = (const uint4*)dst;
-                        sc_off += n * 32;
-                    }
-                }
-                tab[K] = msm_inst_t{nullptr, 0, 0, 0, 0, (uint32_t)npad, 0};  // sentinel
-                c.poly[4].ensure((K + 1) * sizeof(msm_inst_t));
-                HIP_TRY(hipMemcpyAsync(c.poly[4].p, tab, (K + 1) * sizeof(msm_inst_t), hipMemcpyHostToDevice, c.stream));
-                msm_multi_t mu;
-                mu.d_inst = c.poly[4].template as<msm_inst_t>();
-                mu.K = (uint32_t)K;
-                mu.npad = npad;
-                mu.hn = h.n;
-                mu.plane_capacity = K * fuse_planes;  // checked by msm_run BEFORE it enqueues the copy into the staging area
-                pend[i] = msm_run<F>(c, h.d[dev], nullptr, npad, host_planes, 0, nullptr, ~(size_t)0, scalars_montgomery, h.tables, h.n, false, h.table_bits, &mu);
-            }
+            pend[i] = msm_enqueue_job<F>(c, h, dev, req, jobs[i], c.pin.template as<uint8_t>() + plane_off[i], (msm_inst_t*)(c.pin.template as<uint8_t>() + table_off[i]),
+                                         scalars_on_device, scalars_montgomery, window_bits);
             done[i] = c.new_event();
             HIP_TRY(hipEventRecord(done[i], c.stream));
         }
         // the host finishes job i while the GPU works on the later ones; the instances of a fused group on several host threads
         for (size_t i = 0; i < jobs.size(); i++) {
             HIP_TRY(hipEventSynchronize(done[i]));
-            if (jobs[i].size() == 1) {
-                std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
-                msm_collect<F>(*acc, pend[i]);
-                acc->finish(req[jobs[i][0]].out);
-            } else {
-                host_parallel_for(jobs[i].size(), 8, [&](size_t q) {
-                    std::unique_ptr<msm_accum_t<F>> acc(new msm_accum_t<F>());
-                    msm_collect_inst<F>(*acc, pend[i], (int)q);
-                    acc->finish(req[jobs[i][q]].out);
-                });
-            }
+            msm_finish_job<F>(req, jobs[i], pend[i]);
         }
         for (int l = 0; l < L; l++) lg.lanes[l]->end_call();
     });
+}
+// An MSM call of a thread inside an SNARKVM_HIP_SCOPE_ASYNC_MSM scope, scalars in the scope device's memory: the instances are only ENQUEUED -
+// on the next of the scope's MSM lanes, behind everything the scope's stream has been given so far - and the scope's stream in turn waits
+// until the MSM has read its scalars (the caller may reuse those buffers in its next calls).  The outputs are written by the scope's flush
+// (snarkvm_hip_scope_end, or any call that has to wait for the scope).  Returns false when the call does not qualify (the caller then
+// takes the synchronous path).
+template <class F>
+static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, size_t count, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    thread_scope_t& sc = tl_scope();
+    if (!sc.lane || !(sc.flags & SNARKVM_HIP_SCOPE_ASYNC_MSM) || !scalars_on_device || !count || g_rt.profiling.load(std::memory_order_relaxed)) return false;
+    msm_check_requests(h.n, req, count);
+    device_t* d = sc.lane->dev;
+    for (size_t k = 0; k < count; k++) {
+        if (!(req[k].n0 + req[k].n1)) continue;
+        const int dk = g_rt.device_of(req[k].scalars);
+        if (dk < 0) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: scalars are not on a device in use", __LINE__};
+        if (g_rt.devs[dk]->physical != d->physical) return false;  // another GPU: the synchronous path sorts that out
+    }
+    if ((size_t)d->logical >= h.d.size() || !h.d[d->logical]) return false;
+    // the lane: the scope's MSM lanes in turn; a further one is added while fewer than SCOPE_AUX_MAX are held and one is free
+    if (sc.naux < SCOPE_AUX_MAX && !sc.aux_exhausted && (sc.naux == 0 || sc.aux_rr >= (unsigned)sc.naux)) {
+        if (lane_t* l = d->take_for_scope(false)) {
+            l->begin_call();
+            l->pin_used = 0;
+            l->scope_events_used = 0;
+            sc.aux[sc.naux++] = l;
+        } else {
+            sc.aux_exhausted = true;
+        }
+    }
+    lane_t& c = sc.naux ? *sc.aux[sc.aux_rr++ % (unsigned)sc.naux] : *sc.lane;
+    std::vector<size_t> all(count);
+    for (size_t k = 0; k < count; k++) all[k] = k;
+    const std::vector<std::vector<size_t>> jobs = msm_make_jobs(h, req, all, msm_handle_fusable(h, window_bits));
+    size_t need = 0;
+    for (const auto& j : jobs) {
+        size_t pb, tb;
+        msm_job_staging(h, j, pb, tb);
+        need += pb + tb;
+    }
+    if (c.pin_used + need > c.pin.cap) {  // staging full (or first use): collect what is pending, then start over with a bigger area
+        scope_flush();
+        c.pin.ensure(need > ((size_t)1 << 20) ? need : (size_t)1 << 20);
+    }
+    // shared by the finish closures: the requests (outputs) of this call
+    std::shared_ptr<std::vector<msm_req_t>> rq(new std::vector<msm_req_t>(req, req + count));
+    if (&c != sc.lane) {
+        hipEvent_t ready = sc.lane->scope_event();
+        HIP_TRY(hipEventRecord(ready, sc.lane->stream));
+        HIP_TRY(hipStreamWaitEvent(c.stream, ready, 0));
+    }
+    for (const auto& j : jobs) {
+        size_t pb, tb;
+        msm_job_staging(h, j, pb, tb);
+        uint8_t* planes = c.pin.template as<uint8_t>() + c.pin_used;
+        msm_inst_t* tab = (msm_inst_t*)(planes + pb);
+        c.pin_used += pb + tb;
+        hipEvent_t read = (&c != sc.lane) ? c.scope_event() : nullptr;
+        const msm_pending_t pd = msm_enqueue_job<F>(c, h, d->logical, rq->data(), j, planes, tab, 1, scalars_montgomery, window_bits, read);
+        if (read) HIP_TRY(hipStreamWaitEvent(sc.lane->stream, read, 0));
+        hipEvent_t done = c.scope_event();
+        HIP_TRY(hipEventRecord(done, c.stream));
+        sc.pending.push_back(scope_pending_t{done, [rq, j, pd] { msm_finish_job<F>(rq->data(), j, pd, 4); }});
+    }
+    return true;
 }
 // contiguous outputs (outs + k * sizeof(Jacobian)): the batch entry points of the C ABI
 template <class F>
@@ -1702,7 +1927,10 @@ static std::vector<msm_req_t> msm_requests(void* outs, size_t count, const size_
 // itself; a dispatcher additionally waits `coalesce_us` for stragglers when another thread called within the last 300 us (a
 // rayon fan-out arrives within tens of microseconds).  A lone caller (one thread, sequential calls) never waits and runs exactly
 // the launch sequence of the direct path.  Results are bit-identical to the per-instance path: the same kernels on the same
-// operands, only grouped (tests/test_gpu_coalesce.py).  tuning coalesce=0 switches it off.
+// operands, only grouped (tests/test_gpu_proofs.py::test_coalesced_*).  tuning coalesce=0 switches it off.
+// Errors stay with the caller that caused them: every ticket is validated before it is queued, and when a fused batch fails as a whole
+// its tickets are run again one by one, so that one caller's bad request (or a failure only the group provokes) cannot make the other
+// callers fall back to their CPU paths.
 struct msm_ticket_t {
     msm_req_t req;
     int on_device = 0, montgomery = 0, window_bits = 0;
@@ -1728,6 +1956,11 @@ template <class F>
 static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t count) {
     if (!count) return;
     scope_flush();  // another thread may run these tickets: what they read must be complete
+    for (size_t i = 0; i < count; i++) {  // a request that cannot run never reaches the queue (it would fail the group it lands in)
+        msm_check_requests(h.n, &tix[i].req, 1);
+        if (tix[i].on_device && (tix[i].req.n0 + tix[i].req.n1) && g_rt.device_of(tix[i].req.scalars) < 0)
+            throw hip_failure{hipErrorInvalidValue, "msm_registered: scalars are not on a device in use", __LINE__};
+    }
     const bool hint = msm_other_caller_recently();
     std::unique_lock<std::mutex> lk(h.co_mu);
     for (size_t i = 0; i < count; i++) h.co_q.push_back(&tix[i]);
@@ -1760,6 +1993,7 @@ static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t 
             }
             lk.unlock();
             std::exception_ptr err;
+            std::vector<std::exception_ptr> errs;  // per ticket, after a failed group was re-run singly
             if (!batch.empty()) {
                 g_co_stats[0].fetch_add(1, std::memory_order_relaxed);
                 g_co_stats[1].fetch_add(batch.size(), std::memory_order_relaxed);
@@ -1773,11 +2007,22 @@ static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t 
                 } catch (...) {
                     err = std::current_exception();
                 }
+                if (err && batch.size() > 1) {
+                    errs.assign(batch.size(), nullptr);
+                    for (size_t i = 0; i < batch.size(); i++) {
+                        try {
+                            msm_batch_run<F>(h, &batch[i]->req, 1, batch[i]->on_device, batch[i]->montgomery, batch[i]->window_bits);
+                        } catch (...) {
+                            errs[i] = std::current_exception();
+                        }
+                    }
+                }
             }
             lk.lock();
-            for (msm_ticket_t* t : batch) {
-                t->err = err;
-                t->state = err ? 3 : 2;
+            for (size_t i = 0; i < batch.size(); i++) {
+                msm_ticket_t* t = batch[i];
+                t->err = errs.empty() ? err : errs[i];
+                t->state = t->err ? 3 : 2;
             }
             h.co_leaders--;
             h.co_cv.notify_all();
@@ -1792,6 +2037,7 @@ static void msm_coalesced(const bases_handle_t<F>& h, msm_ticket_t* tix, size_t 
 // a batch of requests through the coalescer when every one of them qualifies, else straight to msm_batch_run
 template <class F>
 static void msm_batch_dispatch(const bases_handle_t<F>& h, std::vector<msm_req_t>& req, int scalars_on_device, int scalars_montgomery, int window_bits) {
+    if (msm_scope_enqueue<F>(h, req.data(), req.size(), scalars_on_device, scalars_montgomery, window_bits)) return;
     bool all_small = !req.empty();
     for (const msm_req_t& r : req) {
         if (r.off0 + r.n0 > h.n || (r.n1 && r.off1 + r.n1 > h.n)) throw hip_failure{hipErrorInvalidValue, "msm_registered_batch: range exceeds the registered bases", __LINE__};

@@ -105,12 +105,41 @@ struct tuning_t {
             s = end;
         }
     }
+    // values a typo must not turn into a hang or a crash (coalesce_slots = 0: every coalescible MSM would wait for a dispatcher forever)
+    void clamp() {
+        auto fix = [](const char* key, auto& v, long lo, long hi) {
+            if ((long)v < lo || (long)v > hi) {
+                const long was = (long)v;
+                v = (decltype(v + 0))((long)v < lo ? lo : hi);
+                fprintf(stderr, "[snarkvm_hip] SNARKVM_HIP_TUNING: %s=%ld is out of range [%ld, %ld]; using %ld\n", key, was, lo, hi, (long)v);
+            }
+        };
+        fix("coalesce_slots", coalesce_slots, 1, 8);
+        fix("coalesce_us", coalesce_us, 0, 100000);
+        fix("fuse_max_k", fuse_max_k, 2, 256);
+        fix("fuse_reduce", fuse_reduce, 0, 4);
+        fix("reduce_rounds", reduce_rounds, 0, 8);
+        fix("lanes", lanes, 0, 8);
+        fix("ring_lanes", ring_lanes, 2, 8);
+        fix("ntt_min_tiles", ntt_min_tiles, 1, 1 << 20);
+        fix("hist", hist, 1, 2);
+        fix("prefetch", prefetch, 0, 2);
+        fix("acc_lds", acc_lds, 0, 160 * 1024);
+        fix("msm_chunk_lg", msm_chunk_lg, 16, 30);
+        fix("scalar_chunk_lg", scalar_chunk_lg, 18, 30);
+        fix("ramp", ramp, 0, 6);
+        fix("scalar_geo", scalar_geo, 0, 16);
+        fix("seg", seg, 0, 4096);
+        fix("seg2", seg2, 0, 256);
+        fix("fold_l", fold_l, 0, 64);
+    }
 };
 // parsed on first use, once per process (the variable is not consulted again)
 inline const tuning_t& tuning() {
     static const tuning_t t = [] {
         tuning_t v;
         v.parse(getenv("SNARKVM_HIP_TUNING"));
+        v.clamp();
         return v;
     }();
     return t;

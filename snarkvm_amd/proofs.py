@@ -228,6 +228,158 @@ def normalize_results(results):
     return out
 
 
+class SingleProofWorkspace:
+    """Device buffers of ONE proof proved at a time by one caller thread (BASELINE.json configs[3]): every vector of the proof has
+    its own row, so that the independent transforms of a round can travel as one batch and nothing has to wait for a buffer."""
+
+    ROWS = 26
+
+    def __init__(self, keys, device_index=0):
+        import torch
+
+        self.keys = keys
+        self.device = torch.device("cuda", device_index)
+        with torch.cuda.device(self.device):
+            self.pool = torch.from_numpy(keys.pool_host.view(np.int64).reshape(-1)).to(self.device)
+            self.work = torch.zeros((self.ROWS, keys.shape.nmax * 4), dtype=torch.int64, device=self.device)
+            torch.cuda.synchronize()
+        self.outs = np.zeros(14, dtype=G1_PROJECTIVE)
+        self.out_g2 = np.zeros(1, dtype=G2_PROJECTIVE)
+        self.rem = np.zeros((3, 4), dtype=np.uint64)
+        self.times = {"enqueue": 0.0, "wait": 0.0}
+
+
+def _clocks():
+    return (time.clock_gettime_ns(time.CLOCK_MONOTONIC), time.clock_gettime_ns(time.CLOCK_MONOTONIC_RAW), time.clock_gettime_ns(time.CLOCK_BOOTTIME), time.time_ns())
+
+
+def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None):
+    """The hot-path calls of ONE proof from ONE caller thread, issued for latency (configs[3]; the reference proves one transaction at a
+    time: synthesizer/snark/src/proving_key/mod.rs:37 -> VarunaSNARK::prove_batch, varuna.rs:336).  Same calls, sizes and operands as
+    `replay` - the 15 results are the same group elements - but:
+      * the whole proof is ONE deferred-synchronisation scope (snarkvm_hip_scope_begin_ex): no call waits for the GPU, the operand
+        copies ("the prover produced a polynomial") go onto the scope's own stream (snarkvm_hip_scope_stream), and with
+        SNARKVM_HIP_SCOPE_ASYNC_MSM the commitments of round k are only enqueued - they run on further streams beside the transforms of
+        round k + 1, their host Horner finishes run in snarkvm_hip_scope_end while the GPU works on the later rounds;
+      * the independent transforms of a round - the three matrices of rounds 3 and 4, which the reference hands to a job pool
+        (third.rs:160-175, fourth.rs:174-190) - are ONE batched call per size instead of one call per vector;
+      * the independent G2 MSM is issued first and runs underneath everything else.
+    async_msm=False: the same call list with synchronous MSMs (the A/B of the overlap).
+    marks: a list that receives (label, clocks) after every step was issued (tools/proof1_timeline.py lines them up with a kernel trace)."""
+    import torch
+
+    def mark(label):
+        if marks is not None:
+            marks.append((label, _clocks()))
+
+    mark("begin")
+
+    L = _lib.lib()
+    keys = ws.keys
+    sh = keys.shape
+    nR, nK = 1 << sh.lg_r, 1 << sh.lg_k
+    pool, w = ws.pool, ws.work
+    stride_b = w.stride(0) * 8
+    estride = ctypes.c_size_t(w.stride(0) // 4)
+    t0 = time.perf_counter()
+
+    def row(r):
+        return w.data_ptr() + r * stride_b
+
+    def rp(r):
+        return ctypes.c_void_p(row(r))
+
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(pool.data_ptr()), 1 if async_msm else 0))
+    try:
+        stream = torch.cuda.ExternalStream(L.snarkvm_hip_scope_stream(), device=ws.device)
+
+        def load(r, n, shift, count=1, zero_to=0):
+            """rows r .. r + count - 1 <- pool[shift + i + salt ...] (n coefficients each), zero up to `zero_to`; on the scope's stream"""
+            with torch.cuda.stream(stream):
+                w[r : r + count, : 4 * n].copy_(pool.as_strided((count, 4 * n), (4, 1), 4 * (shift + salt)))
+                if zero_to > n:
+                    w[r : r + count, 4 * n : 4 * zero_to].zero_()
+
+        def ntt(rows, lg, direction, kind=0):
+            k = len(rows)
+            ptrs = (ctypes.c_void_p * k)(*[row(r) for r in rows])
+            dirs = (ctypes.c_int * k)(*([direction] * k))
+            kinds = (ctypes.c_int * k)(*([kind] * k))
+            _lib.check(L.snarkvm_hip_ntt_device_batch(ptrs, ctypes.c_size_t(k), ctypes.c_uint32(lg), 0, dirs, kinds))
+
+        def mul(x, y, lg, count=1):  # rows x .. x + count - 1 *= rows y .. y + count - 1
+            _lib.check(L.snarkvm_hip_fr_vec_op_strided(2, rp(x), rp(x), rp(y), None, None, ctypes.c_size_t(1 << lg), ctypes.c_size_t(count), estride))
+
+        slot = [0]
+
+        def commit_round(polys):
+            """(pointer, n, hiding) per commitment; results land in ws.outs[slot ...] when the scope ends"""
+            k = len(polys)
+            ptrs = (ctypes.c_void_p * k)(*[p for p, _, _ in polys])
+            off0 = (ctypes.c_size_t * k)(*([0] * k))
+            n0 = (ctypes.c_size_t * k)(*[n for _, n, _ in polys])
+            off1 = (ctypes.c_size_t * k)(*([sh.nmax] * k))
+            n1 = (ctypes.c_size_t * k)(*[h for _, _, h in polys])
+            out = ctypes.c_void_p(ws.outs.ctypes.data + G1_PROJECTIVE.itemsize * slot[0])
+            _lib.check(L.snarkvm_hip_msm_registered_batch_ex(out, keys.h, k, off0, n0, off1, n1, ptrs, 1, 1, 0))
+            slot[0] += k
+
+        if keys.hg2:                                                                         # G2 leg: independent of everything else
+            _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, 1 << sh.lg_g2,
+                                                        ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0))
+        mark("g2 msm issued")
+        load(0, nR, 1, count=2)                                                              # round 1: rows 0, 1
+        ntt([0], sh.lg_r, 1); ntt([1], sh.lg_r, 0)
+        mark("round 1 transforms issued")
+        commit_round([(row(0), nR - 2, 2)])
+        mark("round 1 commit issued")
+        load(0, nR, 10, count=3, zero_to=2 * nR)                                             # round 2: z_a, z_b, z_c in rows 0, 1, 2
+        ntt([0, 1, 2], sh.lg_r, 1)
+        ntt([0, 1], sh.lg_r + 1, 0); mul(0, 1, sh.lg_r + 1); ntt([0], sh.lg_r + 1, 1)
+        _lib.check(L.snarkvm_hip_fr_vec_op(1, rp(0), rp(0), rp(2), None, None, ctypes.c_size_t(2 * nR), 1))
+        _lib.check(L.snarkvm_hip_fr_divide_by_vanishing(rp(1), rp(3), rp(0), ctypes.c_size_t(2 * nR), ctypes.c_size_t(nR), 1))
+        mark("round 2 transforms + passes issued")
+        commit_round([(row(1), nR, 0)])
+        mark("round 2 commit issued")
+        load(4, nR, 20, count=3, zero_to=2 * nR); load(7, nR, 30, count=3, zero_to=2 * nR)   # round 3: a_m in rows 4-6, b_m in rows 7-9
+        ntt([4, 5, 6], sh.lg_r, 1)
+        ntt([4, 7, 5, 8, 6, 9], sh.lg_r + 1, 0); mul(4, 7, sh.lg_r + 1, count=3); ntt([4, 5, 6], sh.lg_r + 1, 1)
+        mark("round 3 transforms issued")
+        commit_round([(row(6), nR - 1, 2), (row(9), nR, 0)])                                 # g_1 (hiding), h_1
+        mark("round 3 commits issued")
+        load(10, nK, 40, count=3, zero_to=2 * nK); load(13, nK, 50, count=3); load(16, nK, 60, count=3); load(19, nK, 70, zero_to=2 * nK)   # round 4
+        ntt([10, 11, 12, 13, 14, 15], sh.lg_k, 1)
+        ntt([16, 17, 18], sh.lg_k, 1, 1)
+        ntt([10, 19], sh.lg_k + 1, 0); mul(10, 19, sh.lg_k + 1); ntt([10], sh.lg_k + 1, 1)
+        mark("round 4 transforms issued")
+        commit_round([(row(10), nK - 1, 0), (row(11), nK - 1, 0), (row(12), nK - 1, 0)])
+        mark("round 4 commits issued")
+        base = pool.data_ptr()                                                               # round 5: straight from the pool
+        commit_round([(base + 32 * (o + salt), n, 0) for o, n in ((3, nK - 2), (5, nK), (9, nR), (11, nK))])
+        mark("round 5 commits issued")
+        opens = []                                                                           # openings
+        for i, (s, n) in enumerate(((13, nK), (17, nR), (19, nK))):
+            load(20 + i, n, s)
+            _lib.check(L.snarkvm_hip_fr_divide_by_linear(rp(23 + i), ctypes.c_void_p(ws.rem[i : i + 1].ctypes.data), rp(20 + i), ctypes.c_size_t(n),
+                                                          ctypes.c_void_p(keys.point.ctypes.data), 1))
+            opens.append((row(23 + i), n - 1, 0))
+        mark("opening divisions issued")
+        commit_round(opens)
+        mark("opening commits issued")
+        t1 = time.perf_counter()
+    finally:
+        end = L.snarkvm_hip_scope_end()
+    _lib.check(end)
+    mark("scope_end returned (all 15 results on the host)")
+    t2 = time.perf_counter()
+    ws.times["enqueue"] += t1 - t0
+    ws.times["wait"] += t2 - t1
+    if collect is not None:
+        collect.extend(ws.outs[i : i + 1].tobytes() for i in range(14))
+        if keys.hg2:
+            collect.append(ws.out_g2.tobytes())
+
+
 class LockstepWorkspace:
     """Device buffers of P proofs replayed in lock step on one device: four work matrices [P, nmax] (row p = proof p) + the data pool."""
 

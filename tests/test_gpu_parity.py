@@ -1013,3 +1013,24 @@ def test_bench_proofs64_two_rank_lockstep_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and len(d["rank_ms_per_proof"]) == 2
     assert "one_proof_vs_oracle" in d["checks"] and "lockstep_vs_callers" in d["checks"]
     assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
+
+
+def test_bench_proof1_two_rank_on_one_gpu():
+    """bench.py --workload proof1 with two ranks sharing this GPU over gloo (BASELINE.json configs[3] per rank, weak scaling): every rank
+    proves its own 32 proofs one at a time, compares each with the serial replay; rank 0 checks two whole proofs against the oracle and
+    prints the one JSON line with every rank's own time."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SNARKVM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29535",
+           os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--workload", "proof1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=util.ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 32 and d["scaling"] == "weak" and len(d["rank_ms_per_proof"]) == 2
+    assert "proofs_vs_oracle" in d["checks"] and "every_proof_vs_serial_replay" in d["checks"]
+    assert d["latency"]["workspace_growth_in_timed_region"]["device_allocations"] == 0
+    assert d["value"] > 0 and abs(d["value"] - 2 * 32 / (d["ms_per_step"] * 32e-3)) / d["value"] < 1e-6

@@ -216,3 +216,182 @@ def test_concurrent_replays_meet_in_the_coalescer_vs_oracle():
     for a, b in zip(got, serial):
         assert proofs.normalize_results(a) == proofs.normalize_results(b)
     keys.close()
+
+
+# ---- round 5: one proof at a time in one scope, asynchronous commitments, scopes under thread pressure, workspace growth --------
+
+def test_single_proof_scope_replay_every_result_vs_oracle():
+    """configs[3]: `replay_single` (one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof, the round's independent transforms as batches, the
+    commitments only enqueued and finished by scope_end, the G2 MSM underneath) for three proofs of the reduced shape: all 15
+    results of each against the oracle; the same with synchronous commitments; both equal the serial replay."""
+    shape = proofs.ProofShape(lg_r=12, lg_k=13, lg_g2=10)
+    keys = proofs.ProverKeys(shape, seed=8)
+    ws = proofs.SingleProofWorkspace(keys)
+    ref = proofs.ProofWorkspace(keys)
+    for salt in (0, 5, 2):
+        got_async, got_sync, serial = [], [], []
+        proofs.replay_single(ws, salt, got_async, async_msm=True)
+        proofs.replay_single(ws, salt, got_sync, async_msm=False)
+        proofs.replay(ref, salt, serial)
+        _check_against_oracle(keys, shape, salt, got_async)
+        assert proofs.normalize_results(got_async) == proofs.normalize_results(got_sync) == proofs.normalize_results(serial)
+    keys.close()
+
+
+def test_async_msm_scope_outputs_arrive_at_scope_end_and_inputs_may_be_reused():
+    """Inside an SNARKVM_HIP_SCOPE_ASYNC_MSM scope: five commitments of one scalar buffer that is overwritten (on the scope's stream)
+    between the calls - each MSM must see the contents of ITS moment; single, batch and two-range (`_ex`) entry points, and one host-scalar call in the middle (synchronous: flushes what is pending).  Outputs are
+    written by scope_end."""
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    n = 1 << 13
+    bases = oracle.g1_gen_bases(G, 1, 2 * n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    src = [synthetic.random_fr_integers(n, 7000 + i) for i in range(5)]
+    d_src = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in src]
+    buf = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    outs = np.zeros(5, dtype=G1_PROJECTIVE)
+    host_out = np.zeros(1, dtype=G1_PROJECTIVE)
+    sizes = [n, 4097, n - 3, 1, 2500]
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(buf.data_ptr()), 1))
+    assert L.snarkvm_hip_scope_stream()
+    stream = torch.cuda.ExternalStream(L.snarkvm_hip_scope_stream())
+    for i in range(5):
+        with torch.cuda.stream(stream):
+            buf.copy_(d_src[i])
+        o = ctypes.c_void_p(outs[i : i + 1].ctypes.data)
+        if i % 3 == 0:
+            _lib.check(L.snarkvm_hip_msm_registered(o, rb._h, 3, sizes[i], ctypes.c_void_p(buf.data_ptr()), 1, 0))
+        elif i % 3 == 1:
+            _lib.check(L.snarkvm_hip_msm_registered_ex(o, rb._h, 3, sizes[i] - 2, n, 2, ctypes.c_void_p(buf.data_ptr()), 1, 0, 0))
+        else:
+            ptrs = (ctypes.c_void_p * 1)(buf.data_ptr())
+            _lib.check(L.snarkvm_hip_msm_registered_batch(o, rb._h, 1, (ctypes.c_size_t * 1)(3), (ctypes.c_size_t * 1)(sizes[i]), ptrs, 1, 0, 0))
+        if i == 2:  # a host-scalar call: takes the synchronous path, after the scope's pending work
+            assert not outs[3:].view(np.uint8).any()
+            _lib.check(L.snarkvm_hip_msm_registered(ctypes.c_void_p(host_out.ctypes.data), rb._h, 0, 100, ctypes.c_void_p(src[0].ctypes.data), 0, 0))
+            assert outs[:3].view(np.uint8).any(axis=None)
+    _lib.check(L.snarkvm_hip_scope_end())
+    assert L.snarkvm_hip_scope_stream() is None
+    for i in range(5):
+        s = src[i][: sizes[i]]
+        if i % 3 == 1:
+            want = oracle.g1_add(oracle.g1_msm(bases[3 : 3 + sizes[i] - 2], s[: sizes[i] - 2]), oracle.g1_msm(bases[n : n + 2], s[sizes[i] - 2 :]))
+        else:
+            want = oracle.g1_msm(bases[3 : 3 + sizes[i]], s)
+        assert util.affine_equal(oracle.g1_to_affine(outs[i : i + 1]), oracle.g1_to_affine(want)), i
+    assert util.affine_equal(oracle.g1_to_affine(host_out), oracle.g1_to_affine(oracle.g1_msm(bases[:100], src[0][:100])))
+    rb.close()
+
+
+def test_many_threads_inside_scopes_issue_msms_without_deadlock():
+    """Round-4 review: scope_begin pins a lane; an MSM inside the scope needed another one; eight such threads held all eight lanes
+    and waited for a ninth forever.  Twelve threads open scopes (plain and asynchronous ones alternating), run a transform and an
+    MSM over its output, and end the scope, three times each - bounded by a timeout; every result against the oracle."""
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    lg, T = 10, 12
+    n = 1 << lg
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    xs = [oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 8100 + t)) for t in range(T)]
+    dev = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in xs]
+    torch.cuda.synchronize()
+    outs = np.zeros((T, 3), dtype=G1_PROJECTIVE)
+    errors = []
+    start = threading.Barrier(T)
+
+    def worker(t):
+        try:
+            start.wait()
+            for k in range(3):
+                _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(dev[t].data_ptr()), t & 1))
+                _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(dev[t].data_ptr()), ctypes.c_uint32(lg), 0, k & 1, 0))
+                _lib.check(L.snarkvm_hip_msm_registered_ex(ctypes.c_void_p(outs[t, k : k + 1].ctypes.data), rb._h, 0, n, 0, 0, ctypes.c_void_p(dev[t].data_ptr()), 1, 1, 0))
+                _lib.check(L.snarkvm_hip_scope_end())
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    assert not any(x.is_alive() for x in th), "threads inside scopes are stuck (lane pool exhausted)"
+    assert not errors, errors[:3]
+    for t in range(T):
+        v = xs[t]
+        for k in range(3):
+            v = oracle.ntt(v, oracle.ORDER_NN, k & 1, 0)
+            want = oracle.g1_msm(bases, oracle.fr_op("to_bigint", v))
+            assert util.affine_equal(oracle.g1_to_affine(outs[t, k : k + 1]), oracle.g1_to_affine(want)), (t, k)
+    rb.close()
+
+
+def test_divide_by_linear_host_operands_inside_a_scope_return_the_remainder():
+    """Round-4 advice: with on_device = 0 inside a scope the 32-byte remainder was parked until scope_end while the call itself had
+    already waited - the caller read stale bytes.  The value must be there when the call returns."""
+    import torch
+
+    L = _lib.lib()
+    n = 777
+    p = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n, 31))
+    z = oracle.fr_op("from_bigint", synthetic.random_fr_integers(1, 32))
+    q = np.zeros((n - 1, 4), dtype=np.uint64)
+    rem = np.zeros((1, 4), dtype=np.uint64)
+    anchor = torch.zeros(8, dtype=torch.int64, device="cuda")
+    _lib.check(L.snarkvm_hip_scope_begin(ctypes.c_void_p(anchor.data_ptr())))
+    _lib.check(L.snarkvm_hip_fr_divide_by_linear(ctypes.c_void_p(q.ctypes.data), ctypes.c_void_p(rem.ctypes.data), ctypes.c_void_p(p.ctypes.data), ctypes.c_size_t(n),
+                                                  ctypes.c_void_p(z.ctypes.data), 0))
+    got_inside = rem.copy()
+    _lib.check(L.snarkvm_hip_scope_end())
+    one = oracle.fr_op("from_bigint", np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    wq, _ = oracle.poly_divide(p, [(0, oracle.fr_op("neg", z)[0]), (1, one[0])])
+    assert np.array_equal(got_inside, oracle.poly_evaluate(p, z))
+    assert np.array_equal(q[: wq.shape[0]], wq)
+
+
+def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
+    """The "tables1" cliff of round 4 (93.6 vs 37 ms per step on the driver's box): a 2-instance batch whose second lane had to grow its
+    workspace behind the first lane's running MSM.  After ONE batch of a shape, the next batch of that shape must not allocate
+    (snarkvm_hip_alloc_stats) and must not take longer than 1.3 x the first one; results identical."""
+    import time
+
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    n = 1 << 20
+    d_bases = torch.empty(n * 104, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(d_bases.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(n)))
+    rb12 = msm.RegisteredBases(device_ptr=d_bases.data_ptr(), npoints=n, tables=13, window_bits=20)
+    rb1 = msm.RegisteredBases(device_ptr=d_bases.data_ptr(), npoints=n, tables=1)
+    sc = synthetic.random_fr_integers(n, 515)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    rb12.msm_batch(device_ptrs=[d_sc.data_ptr()] * 3, npoints=[n] * 3)  # lanes sized for the windowed geometry
+    rb1.msm(device_ptr=d_sc.data_ptr(), npoints=n)                      # one lane grows to the table-less geometry (round 4's warm-up)
+    stats = (ctypes.c_uint64 * 5)()
+    times, res = [], []
+    for _ in range(3):
+        _lib.check(L.snarkvm_hip_synchronize())
+        L.snarkvm_hip_alloc_stats(stats, 1)
+        t0 = time.perf_counter()
+        res.append(rb1.msm_batch(device_ptrs=[d_sc.data_ptr()] * 2, npoints=[n] * 2))
+        times.append(time.perf_counter() - t0)
+        L.snarkvm_hip_alloc_stats(stats, 0)
+        if len(times) > 1:
+            assert stats[0] == 0 and stats[2] == 0, f"batch {len(times)} of the same shape allocated: {list(stats)}"
+    assert times[1] <= 1.3 * times[0] and times[2] <= 1.3 * times[0], times
+    want = _closed(G, sc)
+    for r in res:
+        for k in range(2):
+            assert util.affine_equal(oracle.g1_to_affine(r[k : k + 1]), want)
+    rb12.close()
+    rb1.close()
