@@ -10,6 +10,8 @@
 #include "ffl.hip.h"
 
 runtime_t g_rt;
+thread_local thread_scope_t g_tl_scope;
+std::atomic<uint64_t> g_co_stats[4];
 static std::atomic<uint64_t> g_alloc_stats[5];  // {device allocations, device bytes, pinned allocations, pinned bytes, microseconds}
 void sv_alloc_note(int slot, size_t bytes, double ms) {
     g_alloc_stats[slot].fetch_add(1, std::memory_order_relaxed);
@@ -84,7 +86,7 @@ double snarkvm_hip_get_phase_ms(int i) {
     return (i >= 0 && i < (int)g_rt.last_phases.size()) ? g_rt.last_phases[i].second : 0.0;
 }
 
-// coalescer statistics of THIS translation unit's callers (the G1 entry points): out[4] = {batches dispatched, tickets in them, largest
+// coalescer statistics (G1 and G2 callers): out[4] = {batches dispatched, tickets in them, largest
 // batch, single-ticket batches}; reset != 0 clears them
 void snarkvm_hip_coalescer_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 4; i++) {

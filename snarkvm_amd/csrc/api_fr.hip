@@ -268,6 +268,24 @@ static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr
     // `count` vectors in one launch sequence (blockIdx.y): inputs / outputs `in_stride` / `out_stride` elements apart, the chunk values
     // of vector y in its own slice of the scratch area, d_first[y] = h_0 of vector y
     hipStream_t st = c.stream;
+    if (d_out && n >= 2048 && tuning().horner2) {
+        // quotient wanted: the three-launch form with a scan inside every workgroup (poly.hip.h); C coefficients per thread keep <= 256 workgroups
+        uint32_t C = 8;
+        while (((n + C - 1) / C + HORNER2_B - 1) / HORNER2_B > 256) C *= 2;
+        const size_t nblocks = ((n + C - 1) / C + HORNER2_B - 1) / HORNER2_B;
+        const size_t hs_stride = nblocks * HORNER2_B, bv_stride = nblocks;
+        c.poly[4].ensure(sizeof(fr_mem_t) * (HORNER2_TAB + count * (hs_stride + bv_stride)));
+        fr_mem_t* tab = c.poly[4].as<fr_mem_t>();
+        fr_mem_t* hs = tab + HORNER2_TAB;
+        fr_mem_t* bv = hs + count * hs_stride;
+        hipLaunchKernelGGL(fr_horner2_tables_kernel, dim3(1), dim3(HORNER2_B), 0, st, m, tab, C);
+        hipLaunchKernelGGL(fr_horner2_up_kernel, dim3((unsigned)nblocks, (unsigned)count), dim3(HORNER2_B), 0, st, d_in, n, m, (const fr_mem_t*)tab, hs, bv, C, in_stride,
+                           hs_stride, bv_stride);
+        hipLaunchKernelGGL(fr_horner2_down_kernel, dim3((unsigned)nblocks, (unsigned)count), dim3(HORNER2_B), 0, st, d_in, n, m, (const fr_mem_t*)tab, (const fr_mem_t*)hs,
+                           (const fr_mem_t*)bv, C, d_out, shift, d_first, in_stride, hs_stride, bv_stride, out_stride);
+        HIP_TRY(hipGetLastError());
+        return;
+    }
     int levels = 1;
     size_t total = 0;
     for (size_t t = n; t > 1;) {

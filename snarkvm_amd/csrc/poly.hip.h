@@ -105,6 +105,107 @@ static __global__ void fr_horner_down_kernel(const fr_mem_t* in, size_t n, const
     }
 }
 
+// ---- the same sums with a scan inside every workgroup (round 5) --------------------------------------------------------
+// The chunk recursion above is four dependent levels of 32 serial products each for the 2^17 coefficients of an opening, run by
+// 4 096 threads: eight launches of 50 - 100 us, 1.3 ms of the 9.5 ms of kernels of one proof (profiles/r05_proof1_timeline.md).
+// Here a workgroup of 256 threads owns 256 C consecutive coefficients (C = 8 up to 2^19 coefficients): every thread folds its C
+// coefficients (C serial products), the 256 thread values are turned into their suffix sums by a Kogge-Stone scan through LDS
+// (8 steps of one product, multipliers m^(C 2^j)), and a workgroup gets the carry of everything behind it as ONE product per
+// thread against a table of m^(256 C j) plus a tree of additions.  Three launches (tables, up, down), 17 dependent products.
+// Exact field arithmetic in another order: the same values bit for bit.
+static constexpr int HORNER2_B = 256;
+// tab: [0, 8) step[j] = m^(C 2^j) | [8, 8 + 257) pw[j] = m^(C j) | [265, 265 + 256) pwB[j] = m^(256 C j); internal form
+static constexpr int HORNER2_TAB = 8 + 257 + 256;
+static __global__ void __launch_bounds__(HORNER2_B) fr_horner2_tables_kernel(fr_mem_t m_mem, fr_mem_t* __restrict__ tab, uint32_t C) {
+    const uint32_t t = threadIdx.x;
+    const fr_t m = fr_t::load(&m_mem).from_mem_mont();
+    const fr_t mC = m.pow_u64(C);
+    const fr_t mB = mC.pow_u64(HORNER2_B);
+    mC.pow_u64(t).store(&tab[8 + t]);
+    mB.pow_u64(t).store(&tab[8 + 257 + t]);
+    if (t == 0) mB.store(&tab[8 + 256]);
+    if (t < 8) mC.pow_u64(1u << t).store(&tab[t]);
+}
+__device__ __forceinline__ void horner2_lds_put(uint32_t* sh, uint32_t t, const fr_t& x) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) sh[l * HORNER2_B + t] = x.v[l];
+}
+__device__ __forceinline__ fr_t horner2_lds_get(const uint32_t* sh, uint32_t t) {
+    fr_t x;
+#pragma unroll
+    for (int l = 0; l < 9; l++) x.v[l] = sh[l * HORNER2_B + t];
+    return x;
+}
+// hs[block * 256 + t] = the suffix sum of the block's thread values from thread t on (= h at the first coefficient of thread t, the
+// block taken alone); bv[block] = hs[block * 256] (the block's polynomial at m)
+static __global__ void __launch_bounds__(HORNER2_B) fr_horner2_up_kernel(const fr_mem_t* __restrict__ in, size_t n, fr_mem_t m_mem, const fr_mem_t* __restrict__ tab,
+                                                                  fr_mem_t* __restrict__ hs, fr_mem_t* __restrict__ bv, uint32_t C, size_t in_stride,
+                                                                  size_t hs_stride, size_t bv_stride) {
+    __shared__ uint32_t sh[9 * HORNER2_B];
+    const uint32_t t = threadIdx.x;
+    in += (size_t)blockIdx.y * in_stride;
+    hs += (size_t)blockIdx.y * hs_stride;
+    bv += (size_t)blockIdx.y * bv_stride;
+    const fr_t m = fr_t::load(&m_mem).from_mem_mont();
+    const size_t lo = ((size_t)blockIdx.x * HORNER2_B + t) * C;
+    const size_t hi = lo + C < n ? lo + C : n;
+    fr_t h = fr_t::zero();
+    for (size_t i = hi; i > lo;) {
+        i--;
+        h = fr_t::load(&in[i]) + m * h;
+    }
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        horner2_lds_put(sh, t, h);
+        __syncthreads();
+        if (t + (1u << j) < HORNER2_B) h = h + fr_t::load(&tab[j]) * horner2_lds_get(sh, t + (1u << j));
+        __syncthreads();
+    }
+    h.store(&hs[(size_t)blockIdx.x * HORNER2_B + t]);
+    if (t == 0) h.store(&bv[blockIdx.x]);
+}
+// out[i - shift] = h_i (i >= shift), *first = h_0 when shift == 1.  nblocks <= 256 + 1.
+static __global__ void __launch_bounds__(HORNER2_B) fr_horner2_down_kernel(const fr_mem_t* in, size_t n, fr_mem_t m_mem, const fr_mem_t* __restrict__ tab,
+                                                                    const fr_mem_t* __restrict__ hs, const fr_mem_t* __restrict__ bv, uint32_t C, fr_mem_t* out,
+                                                                    int shift, fr_mem_t* first, size_t in_stride, size_t hs_stride, size_t bv_stride,
+                                                                    size_t out_stride) {
+    __shared__ uint32_t sh[9 * HORNER2_B];
+    const uint32_t t = threadIdx.x, b = blockIdx.x, nblocks = gridDim.x;
+    in += (size_t)blockIdx.y * in_stride;
+    hs += (size_t)blockIdx.y * hs_stride;
+    bv += (size_t)blockIdx.y * bv_stride;
+    out += (size_t)blockIdx.y * out_stride;
+    if (first) first += blockIdx.y;
+    const fr_t m = fr_t::load(&m_mem).from_mem_mont();
+    // carry = h at the first coefficient of block b + 1 = sum_(s > b) bv[s] m^(256 C (s - b - 1)): one term per thread, then a tree of sums
+    fr_t term = fr_t::zero();
+    if (b + 1 + t < nblocks) term = fr_t::load(&tab[8 + 257 + t]) * fr_t::load(&bv[b + 1 + t]);
+#pragma unroll 1
+    for (uint32_t off = HORNER2_B / 2; off >= 1; off >>= 1) {
+        horner2_lds_put(sh, t, term);
+        __syncthreads();
+        if (t < off) term = term + horner2_lds_get(sh, t + off);
+        __syncthreads();
+    }
+    horner2_lds_put(sh, t, term);
+    __syncthreads();
+    const fr_t carry = horner2_lds_get(sh, 0);
+    const size_t lo = ((size_t)b * HORNER2_B + t) * C;
+    if (lo >= n) return;
+    const size_t hi = lo + C < n ? lo + C : n;
+    // h behind this thread's coefficients: the block's own suffix sum from thread t + 1 on, plus the carry moved across the threads in between
+    fr_t h = fr_t::load(&tab[8 + (HORNER2_B - 1 - t)]) * carry;
+    if (t + 1 < HORNER2_B) h = h + fr_t::load(&hs[(size_t)b * HORNER2_B + t + 1]);
+    for (size_t i = hi; i > lo;) {
+        i--;
+        h = fr_t::load(&in[i]) + m * h;
+        if (i >= (size_t)shift)
+            h.store(&out[i - shift]);
+        else if (first)
+            h.store(first);
+    }
+}
+
 // ---- batch inversion -----------------------------------------------------------------------------------------------
 // Montgomery's trick per thread over the strided set {t, t + T, t + 2T, ...} (any partition gives the same values; a
 // strided one keeps every access coalesced).  Prefix products are parked in `scratch` (n elements, internal form); one

@@ -451,10 +451,11 @@ struct thread_scope_t {
     bool aux_exhausted = false;  // a try for a further lane failed: not tried again in this scope
     std::vector<scope_pending_t> pending;
 };
-static thread_scope_t& tl_scope() {
-    static thread_local thread_scope_t s;
-    return s;
-}
+// ONE object per thread for the whole library: defined in api.hip.  (Rounds 3-4 kept it as a function-local static of this header,
+// i.e. one copy per translation unit: a scope opened by api.hip was invisible to the transforms and vector passes of api_fr.hip and
+// to the G2 calls of api_g2.hip - they took another lane and waited for it call by call, unordered against the scope's stream.)
+extern thread_local thread_scope_t g_tl_scope;
+static thread_scope_t& tl_scope() { return g_tl_scope; }
 // wait for everything the calling thread's scope has enqueued; deliver the results it owes (MSM outputs, parked host values)
 static void scope_flush() {
     thread_scope_t& sc = tl_scope();
@@ -1938,7 +1939,7 @@ struct msm_ticket_t {
     std::exception_ptr err;
 };
 // how the coalescer grouped its callers so far: {batches dispatched, tickets in them, largest batch, batches of one ticket}
-static std::atomic<uint64_t> g_co_stats[4];
+extern std::atomic<uint64_t> g_co_stats[4];  // api.hip (process-wide: G1 and G2 callers)
 static bool msm_other_caller_recently() {
     static std::atomic<uint64_t> last_ns{0}, last_tid{0};
     timespec ts;

@@ -57,6 +57,7 @@
 //   xcd             1        scatter kernels of the radix partition: XCD x walks a contiguous tile range (msm_sort.hip.h::xcd_tile)
 //   fold_threads2   128      G2: threads per output of a small fold (its kernels run one wave per SIMD: 256-thread workgroups = one per CU)
 //   coalesce_slots  2        dispatchers of the coalescer that may be inside the library at once (per handle)
+//   horner2         1        p / (X - z): three launches with a scan inside every workgroup (0: the four-level chunk recursion of round 3)
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,7 +71,7 @@ struct tuning_t {
     int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
-    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 0;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 0, horner2 = 1;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -82,7 +83,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2)
 #undef SV_TUNE_KEY
         return false;
     }

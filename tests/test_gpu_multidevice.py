@@ -263,6 +263,15 @@ for lg in (12, 14, 15, 16, 17):
             y = x.copy()
             plugin.NTT(1 << lg, y, NTTInputOutputOrder.NN, d, t)
             assert np.array_equal(y, oracle.ntt(x, oracle.ORDER_NN, d, t)), ("ntt", lg, d, t)
+# p / (X - z) and p(z) (tuning horner2: the workgroup-scan form / the chunk recursion)
+from snarkvm_amd import poly
+for n_lin in (2049, 100003):
+    pa = oracle.fr_op("from_bigint", synthetic.random_fr_integers(n_lin, 4300 + n_lin))
+    pz = oracle.fr_op("from_bigint", synthetic.random_fr_integers(1, 4301))
+    one = oracle.fr_op("from_bigint", np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    q_lin, rem_lin = poly.divide_by_linear(pa, pz)
+    wq_lin, _ = oracle.poly_divide(pa, [(0, oracle.fr_op("neg", pz)[0]), (1, one[0])])
+    assert np.array_equal(q_lin, wq_lin) and np.array_equal(rem_lin, oracle.poly_evaluate(pa, pz)), ("divide_by_linear", n_lin)
 # MSM: a single-round size, a multi-round size over wide windows, a fused batch of proof-sized instances
 n = (1 << 19) + 77
 bases = oracle.g1_gen_bases(G, 1, n)
@@ -293,7 +302,7 @@ print("AB_OK")
 
 @pytest.mark.parametrize("tuning", [
     "ntt_min_tiles=1", "ntt_min_tiles=1024", "lazy=0", "prefetch=0", "acc_one_wg=1,acc_lds=83968", "fuse_batch=0", "fused=0", "seg=96", "reduce_rounds=0", "reduce_rounds=2,seg2=8",
-    "hist=1", "ntt_signed=1", "ntt_batch=0", "ring_lanes=5", "coalesce=0", "taper=0", "fuse_max_k=2", "fuse_reduce=0", "lazy2=0", "lazy_tail=1", "xcd=0", "fold_threads2=256", "coalesce_slots=1"])
+    "hist=1", "ntt_signed=1", "ntt_batch=0", "ring_lanes=5", "coalesce=0", "taper=0", "fuse_max_k=2", "fuse_reduce=0", "lazy2=0", "lazy_tail=1", "xcd=0", "fold_threads2=256", "coalesce_slots=1", "horner2=0"])
 def test_ab_switches_are_bit_exact(tuning):
     """csrc/tuning.hip.h: one variable, parsed once per process; every key selects another kernel / launch shape for the same mathematics."""
     r = subprocess.run([sys.executable, "-c", AB_SCRIPT % util.ROOT], capture_output=True, text=True, env=dict(os.environ, SNARKVM_HIP_TUNING=tuning), timeout=900, cwd=util.ROOT)

@@ -250,7 +250,7 @@ def test_async_msm_scope_outputs_arrive_at_scope_end_and_inputs_may_be_reused():
     bases = oracle.g1_gen_bases(G, 1, 2 * n)
     rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
     src = [synthetic.random_fr_integers(n, 7000 + i) for i in range(5)]
-    d_src = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in src]
+    d_src = [torch.from_numpy(x.view(np.int64).reshape(-1).copy()).cuda() for x in src]
     buf = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     outs = np.zeros(5, dtype=G1_PROJECTIVE)

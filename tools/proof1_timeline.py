@@ -121,6 +121,18 @@ def report(db_path, marks_path):
             byname[short(r[0])] = byname.get(short(r[0]), 0) + (r[3] - r[2])
         top = ", ".join(f"{k} {v / 1e6:.3f}" for k, v in sorted(byname.items(), key=lambda kv: -kv[1])[:6])
         print(f"| {sid} | {(rs[0][2] - b) / 1e6:.3f} | {(max(r[3] for r in rs) - b) / 1e6:.3f} | {union_ns([(r[2], r[3]) for r in rs]) / 1e6:.3f} | {len(rs)} | {top} |")
+    print("\n### the same proof: every kernel (launches, summed ms, share of the summed kernel time)\n")
+    byname = {}
+    for r in ks:
+        e = byname.setdefault(short(r[0]), [0, 0])
+        e[0] += 1
+        e[1] += r[3] - r[2]
+    tot = sum(v[1] for v in byname.values())
+    print("| kernel | launches | ms | share |")
+    print("|---|---|---|---|")
+    for k, v in sorted(byname.items(), key=lambda kv: -kv[1][1]):
+        print(f"| {k} | {v[0]} | {v[1] / 1e6:.3f} | {v[1] / tot:.3f} |")
+    print(f"| all | {len(ks)} | {tot / 1e6:.3f} | 1 |")
     print("\n### the same proof: every accumulate launch (one per commitment round / MSM) and the gaps of the transform stream\n")
     print("| kernel | stream | start ms | end ms | ms |")
     print("|---|---|---|---|---|")
