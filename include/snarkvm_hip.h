@@ -122,11 +122,15 @@ RustError snarkvm_hip_scope_end(void);
  * overwritten by later calls of the scope (those wait on the GPU until the MSM has read them).  How one prover thread keeps the GPU
  * busy across the rounds of a proof: the commitments of round k run beside the transforms of round k + 1 and their host finishes run
  * while the GPU works (the reference's rayon workers overlap the same way on the CPU, polycommit/sonic_pc/mod.rs:186-245).
- * A thread holds at most 1 + 3 streams per scope and a GPU lends at most 6 of its 8 streams to scopes: the seventh scope_begin waits.
+ * SNARKVM_HIP_SCOPE_STABLE_INPUTS (with ASYNC_MSM): the caller promises not to touch the scalar vectors of its enqueued MSMs before the
+ * scope ends; the scope's stream then never waits for an MSM (without the flag every later call of the scope waits, on the GPU, until
+ * the MSM has read its scalars - which an MSM queued behind others does late).
+ * A thread holds at most 1 + 7 streams per scope and a GPU lends at most 12 of its 16 streams to scopes: a scope_begin beyond that waits,
+ * and a scope that finds no further stream free runs its MSMs on the streams it has.
  * snarkvm_hip_scope_stream: the hipStream_t the scope's device-resident calls are enqueued on (NULL outside a scope) - a caller that
  * produces operands with its own kernels or copies (hipMemcpyAsync, torch.cuda.ExternalStream) orders them with the scope's calls by
  * using this stream. */
-enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1 };
+enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1, SNARKVM_HIP_SCOPE_STABLE_INPUTS = 2 };
 RustError snarkvm_hip_scope_begin_ex(const void *d_any, uint32_t flags);
 void *snarkvm_hip_scope_stream(void);
 
@@ -347,6 +351,11 @@ int snarkvm_hip_selftest_g1_lazy_tail(uint64_t seed, int iters);
  * and restarts from infinity included, every coordinate compared after every step; products, squares and the raw partial-sum image
  * on the way.  0 = identical; > 0: first differing step; < 0: a field / conversion case. */
 int snarkvm_hip_selftest_fq2_lazy(const void *points, size_t npoints, uint64_t seed, int iters);
+/* The lane-pair Fq2 arithmetic of the G2 accumulate kernel (csrc/ffl2p.hip.h: the c0 component of every value on the even lane, c1 on
+ * the odd lane, operands exchanged inside the VALU) with both lanes of a pair run side by side on the host - the same source - against
+ * the exact arithmetic: the chain of snarkvm_hip_selftest_fq2_lazy; doublings and cancellations are resolved inside the pair arithmetic.
+ * 0 = identical; > 0: first differing step; < 0: a conversion case. */
+int snarkvm_hip_selftest_fq2_pair(const void *points, size_t npoints, uint64_t seed, int iters);
 /* The signed-limb butterfly arithmetic of the NTT passes (csrc/frs.hip.h) against the exact arithmetic, on the host: passes of up
  * to nine butterfly stages without a canonical form in between, the closing product, the bare reduction and the folded table
  * form.  0 = identical; > 0: first differing butterfly; < 0: a closing-step case. */

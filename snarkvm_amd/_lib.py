@@ -26,7 +26,7 @@ SYMBOLS = [
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize", "snarkvm_hip_coalescer_stats",
-    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_g1_lazy_tail", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_devtest_field",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_g1_lazy_tail", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_selftest_fq2_pair", "snarkvm_hip_devtest_field",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
         L.snarkvm_hip_selftest_g1_lazy_tail.restype = ctypes.c_int
         L.snarkvm_hip_selftest_fr_signed.restype = ctypes.c_int
         L.snarkvm_hip_selftest_fq2_lazy.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_fq2_pair.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_count.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_name.restype = ctypes.c_char_p
         L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double

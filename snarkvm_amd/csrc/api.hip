@@ -127,7 +127,7 @@ RustError snarkvm_hip_scope_begin_ex(const void* d_any, uint32_t flags) {
     API_TRY
     thread_scope_t& sc = tl_scope();
     if (sc.lane) throw hip_failure{hipErrorInvalidValue, "scope_begin: the calling thread already has an open scope", __LINE__};
-    if (flags & ~(uint32_t)SNARKVM_HIP_SCOPE_ASYNC_MSM) throw hip_failure{hipErrorInvalidValue, "scope_begin: unknown flag", __LINE__};
+    if (flags & ~(uint32_t)(SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS)) throw hip_failure{hipErrorInvalidValue, "scope_begin: unknown flag", __LINE__};
     g_rt.configure();
     const int nd = (int)g_rt.devs.size();
     int dev = device_for(d_any, d_any ? 1 : 0);

@@ -263,4 +263,72 @@ int snarkvm_hip_selftest_fq2_lazy(const void* points, size_t npoints, uint64_t s
 #endif
 }
 
+// ---- test hook: the lane-pair Fq2 arithmetic of the G2 accumulate kernel (ffl2p.hip.h) against the exact arithmetic, on the host ----
+// The SAME source the kernel runs (fq2p::xyzz_pair_t) instantiated with the two-lane host exchange policy: a chain of `iters` mixed
+// additions of +- points[k] - the same point again (doubling, resolved inside the pair arithmetic), its negative (cancellation),
+// restarts from infinity - with every coordinate component compared with xyzz_t<fq2_t>::add_affine after every step, the raw partial-sum
+// image and its conversion on the way.  0 = identical; > 0: first differing step; < 0: a conversion case.
+int snarkvm_hip_selftest_fq2_pair(const void* points, size_t npoints, uint64_t seed, int iters) {
+#ifdef SV_NO_G2
+    (void)points, (void)npoints, (void)seed, (void)iters;
+    return -1;
+#else
+    if (!points || npoints < 2) return -2;
+    std::vector<aff_t<fq2_t>> pool;
+    for (size_t i = 0; i < npoints; i++) {
+        const uint32_t* src = (const uint32_t*)((const uint8_t*)points + 200 * i);
+        pool.push_back({fq2_t::from_raw_words(src), fq2_t::from_raw_words(src + 24)});
+    }
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto same = [](const fql_t (&l)[2], const fq2_t& e) { return l[0].to_exact() == e.c0 && l[1].to_exact() == e.c1; };
+    xyzz_t<fq2_t> exact = xyzz_t<fq2_t>::inf();
+    fq2p::xyzz_pair_t<fq2p::xp_host> pr;
+    pr.inf = true;
+    int prev = -1;
+    bool prev_neg = false;
+    for (int it = 0; it < iters; it++) {
+        const uint64_t r = next();
+        int k = (int)(r % npoints);
+        bool neg = ((r >> 8) & 1) != 0;
+        const int mode = (int)((r >> 16) % 16);
+        if (mode == 0 && prev >= 0) k = prev, neg = prev_neg;
+        if (mode == 1 && prev >= 0) k = prev, neg = !prev_neg;
+        if (mode == 2) {
+            exact = xyzz_t<fq2_t>::inf();
+            pr.inf = true;
+        }
+        prev = k;
+        prev_neg = neg;
+        const aff_t<fq2_t> p = pool[k];
+        exact.add_affine(p, neg);
+        // the base slot as the kernel reads it: component c of x and y
+        alignas(128) aff_mem_t<fq2_t> slot;
+        const fq_t c406 = fq_t::from_table(FqLConv::C406);
+        g2_lazy_slot_t::store(&slot, {p.x.c0 * c406, p.x.c1 * c406}, {p.y.c0 * c406, p.y.c1 * c406}, false);
+        fql_t px[2], py[2];
+        for (int c = 0; c < 2; c++) ((const g2_lazy_slot_t*)&slot)->component(c, px[c], py[c]);
+        pr.madd(px, py, neg);
+        if (pr.inf != exact.is_inf()) return it + 1;
+        if (!pr.inf && !(same(pr.x, exact.x) && same(pr.y, exact.y) && same(pr.zz, exact.zz) && same(pr.zzz, exact.zzz))) return it + 1;
+        if (!pr.inf && (it & 7) == 0) {  // the raw partial-sum image through the conversion the device kernel applies per component
+            const fql_t* cs[4] = {pr.x, pr.y, pr.zz, pr.zzz};
+            const fq2_t* es[4] = {&exact.x, &exact.y, &exact.zz, &exact.zzz};
+            for (int c4 = 0; c4 < 4; c4++)
+                for (int c = 0; c < 2; c++) {
+                    fql_t back;
+                    for (int j = 0; j < 13; j++) back.v[j] = cs[c4][c].v[j];
+                    if (!(back.to_exact() == (c ? es[c4]->c1 : es[c4]->c0))) return -(it + 1);
+                }
+        }
+    }
+    return 0;
+#endif
+}
+
 }  // extern "C"

@@ -241,34 +241,53 @@ SV_HD fql_t cond_neg_canonical(const fql_t& y, bool neg) {
 
 }  // namespace fq2l
 
-// A base slot of a G2 MSM on this arithmetic: the 256 bytes of an aff_mem_t<fq2_t> reinterpreted as 52 limbs - x.c0, x.c1, y.c0, y.c1,
-// canonical residues of the coordinates times 2^406, one 29-bit limb per word - and a flag word for the point at infinity.
+// A base slot of a G2 MSM on this arithmetic: the 256 bytes of an aff_mem_t<fq2_t> reinterpreted as four groups of 16 words - x.c0, x.c1,
+// y.c0, y.c1: 13 limbs each (canonical residues of the coordinate components times 2^406, one 29-bit limb per word) and three words of
+// padding, so that a lane of the pair kernel (ffl2p.hip.h) reads ITS component of a coordinate as four aligned 16-byte loads - and a flag
+// word for the point at infinity in the first group's padding.
 struct alignas(128) g2_lazy_slot_t {
-    uint32_t w[64];  // [0, 52): limbs, [52]: 1 = point at infinity
+    static constexpr int GROUP = 16, INF_WORD = 15;
+    uint32_t w[64];  // [16 g, 16 g + 13): limbs of component g (x.c0, x.c1, y.c0, y.c1); w[15]: 1 = point at infinity
     SV_HD void coords(fq2l_t& px, fq2l_t& py) const {
 #pragma unroll
         for (int i = 0; i < 13; i++) {
-            px.c0.v[i] = (int32_t)w[i], px.c1.v[i] = (int32_t)w[13 + i];
-            py.c0.v[i] = (int32_t)w[26 + i], py.c1.v[i] = (int32_t)w[39 + i];
+            px.c0.v[i] = (int32_t)w[i], px.c1.v[i] = (int32_t)w[GROUP + i];
+            py.c0.v[i] = (int32_t)w[2 * GROUP + i], py.c1.v[i] = (int32_t)w[3 * GROUP + i];
         }
         SV_OPAQUE_13(px.c0.v);
         SV_OPAQUE_13(px.c1.v);
         SV_OPAQUE_13(py.c0.v);
         SV_OPAQUE_13(py.c1.v);
     }
+    // component `comp` (0: c0, 1: c1) of x and y
+    SV_HD void component(int comp, fql_t& px, fql_t& py) const {
+        const uint4* q = (const uint4*)w;
+        uint32_t t[32];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 a = q[4 * comp + k], b = q[8 + 4 * comp + k];
+            t[4 * k] = a.x, t[4 * k + 1] = a.y, t[4 * k + 2] = a.z, t[4 * k + 3] = a.w;
+            t[16 + 4 * k] = b.x, t[16 + 4 * k + 1] = b.y, t[16 + 4 * k + 2] = b.z, t[16 + 4 * k + 3] = b.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) px.v[i] = (int32_t)t[i], py.v[i] = (int32_t)t[16 + i];
+        SV_OPAQUE_13(px.v);
+        SV_OPAQUE_13(py.v);
+    }
     // x406, y406: canonical residues of coordinate * 2^406 (exact-arithmetic values whose limbs are read as plain integers)
     SV_HD static void store(aff_mem_t<fq2_t>* slot, const fq2_t& x406, const fq2_t& y406, bool inf) {
         uint4* q = (uint4*)slot;
-        uint32_t t[56];
+        uint32_t t[64];
+#pragma unroll
+        for (int i = 0; i < 64; i++) t[i] = 0;
 #pragma unroll
         for (int i = 0; i < 13; i++) {
-            t[i] = inf ? 0u : x406.c0.v[i], t[13 + i] = inf ? 0u : x406.c1.v[i];
-            t[26 + i] = inf ? 0u : y406.c0.v[i], t[39 + i] = inf ? 0u : y406.c1.v[i];
+            t[i] = inf ? 0u : x406.c0.v[i], t[GROUP + i] = inf ? 0u : x406.c1.v[i];
+            t[2 * GROUP + i] = inf ? 0u : y406.c0.v[i], t[3 * GROUP + i] = inf ? 0u : y406.c1.v[i];
         }
-        t[52] = inf ? 1u : 0u;
-        t[53] = t[54] = t[55] = 0;
+        t[INF_WORD] = inf ? 1u : 0u;
 #pragma unroll
-        for (int i = 0; i < 14; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        for (int i = 0; i < 16; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
     }
 };
 static_assert(sizeof(g2_lazy_slot_t) == sizeof(aff_mem_t<fq2_t>), "a lazy G2 base slot overlays the exact one");

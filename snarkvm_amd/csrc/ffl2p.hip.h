@@ -34,7 +34,6 @@ namespace fq2p {
 static constexpr int N = 13;
 static constexpr uint32_t MASK = fql_t::MASK;
 
-#if defined(__HIP_DEVICE_COMPILE__)
 struct xp_dev {
     static constexpr int NL = 1;
     __device__ __forceinline__ static bool odd(int) { return (threadIdx.x & 1u) != 0; }
@@ -53,7 +52,6 @@ struct xp_dev {
         return f[0] && o != 0;
     }
 };
-#endif
 struct xp_host {
     static constexpr int NL = 2;
     static bool odd(int l) { return l == 1; }
@@ -65,9 +63,8 @@ struct xp_host {
 };
 
 // ---- per-lane pieces (pure: host and device) ------------------------------------------------------------------------------------------
-struct opa_t {
-    fql_t own;
-    int32_t recv[N];
+struct opa_t {  // the a-operand as the column sum wants it: X meets the lane's own b limbs, Y the limbs its partner sent
+    int32_t X[N], Y[N];
 };
 struct opb_t {
     fql_t own;
@@ -86,10 +83,7 @@ SV_HD void send_b(const fql_t& b, bool odd, int32_t* o) {  // even: (b0, 0)   od
     o[N] = odd ? t5[N] : 0;
 }
 // this lane's component of a * b, quotient subtracted: normalised, in (-q - e, e)
-SV_HD fql_t mul_core(const opa_t& a, const opb_t& b, bool odd) {
-    int32_t X[N], Y[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) X[i] = odd ? a.recv[i] : a.own.v[i], Y[i] = odd ? a.own.v[i] : a.recv[i];
+SV_HD fql_t mul_core(const opa_t& a, const opb_t& b) {
     uint32_t m[FqL::STEPS];
     fql_t r;
     int64_t acc = 0;
@@ -98,8 +92,8 @@ SV_HD fql_t mul_core(const opa_t& a, const opb_t& b, bool odd) {
 #pragma unroll
         for (int i = 0; i < N; i++) {
             const int j = k - i;
-            if (j >= 0 && j < N) acc += (int64_t)X[i] * b.own.v[j];
-            if (j >= 0 && j <= N) acc += (int64_t)Y[i] * b.recv[j];
+            if (j >= 0 && j < N) acc += (int64_t)a.X[i] * b.own.v[j];
+            if (j >= 0 && j <= N) acc += (int64_t)a.Y[i] * b.recv[j];
         }
 #pragma unroll
         for (int i = 0; i < FqL::STEPS; i++) {
@@ -168,9 +162,9 @@ struct pair_ops {
         XP::template swap<N>(s, r);
 #pragma unroll
         for (int l = 0; l < NL; l++) {
-            o[l].own = v[l];
+            const bool odd = XP::odd(l);  // even: (own, received) = (a0, -a1)   odd: (received, own) = (a0, a1)
 #pragma unroll
-            for (int i = 0; i < N; i++) o[l].recv[i] = r[l][i];
+            for (int i = 0; i < N; i++) o[l].X[i] = odd ? r[l][i] : v[l].v[i], o[l].Y[i] = odd ? v[l].v[i] : r[l][i];
         }
     }
     SV_HD static void prep_b(const val_t& v, opb_t (&o)[XP::NL]) {
@@ -187,7 +181,7 @@ struct pair_ops {
     }
     SV_HD static void mul(const opa_t (&a)[XP::NL], const opb_t (&b)[XP::NL], val_t& out) {
 #pragma unroll
-        for (int l = 0; l < NL; l++) out[l] = mul_core(a[l], b[l], XP::odd(l));
+        for (int l = 0; l < NL; l++) out[l] = mul_core(a[l], b[l]);
     }
 };
 
@@ -212,7 +206,7 @@ struct xyzz_pair_t {
             return;
         }
         opa_t A[XP::NL];
-        opb_t B[XP::NL], Bpp[XP::NL], Bppp[XP::NL];
+        opb_t B[XP::NL];
         fql_t u2[XP::NL], s2[XP::NL], p[XP::NL], r[XP::NL];
         ops::prep_a(zz, A);
         ops::prep_b(px, B);
@@ -239,14 +233,23 @@ struct xyzz_pair_t {
                 return;
             }
         }
+        // (order: every value is consumed as early as the formulas allow - ZZ and ZZZ are updated in place as soon as PP / PPP exist - so
+        // that the live set stays below 256 registers: accumulator 52, two prepared operands 53, b and X3 26, the column sum ~45)
         fql_t pp[XP::NL], ppp[XP::NL], q[XP::NL], rr[XP::NL], x3[XP::NL], d[XP::NL], a[XP::NL], b[XP::NL];
         ops::prep_a(p, A);
         ops::prep_b(p, B);
         ops::mul(A, B, pp);  // PP = P^2
-        ops::prep_b(pp, Bpp);
-        ops::mul(A, Bpp, ppp);  // PPP = P PP
+        ops::prep_b(pp, B);
+        ops::mul(A, B, ppp);  // PPP = P PP
         ops::prep_a(x, A);
-        ops::mul(A, Bpp, q);  // Q = X1 PP
+        ops::mul(A, B, q);  // Q = X1 PP
+        ops::prep_a(zz, A);
+        ops::mul(A, B, zz);  // ZZ3 = ZZ1 PP
+        ops::prep_b(ppp, B);
+        ops::prep_a(zzz, A);
+        ops::mul(A, B, zzz);  // ZZZ3 = ZZZ1 PPP
+        ops::prep_a(y, A);
+        ops::mul(A, B, b);  // Y1 PPP
         ops::prep_a(r, A);
         ops::prep_b(r, B);
         ops::mul(A, B, rr);  // R^2
@@ -260,20 +263,10 @@ struct xyzz_pair_t {
         }
         ops::prep_b(d, B);
         ops::mul(A, B, a);  // R (Q - X3)
-        ops::prep_a(y, A);
-        ops::prep_b(ppp, Bppp);
-        ops::mul(A, Bppp, b);  // Y1 PPP
-        ops::prep_a(zz, A);
-        fql_t zz3[XP::NL], zzz3[XP::NL];
-        ops::mul(A, Bpp, zz3);
-        ops::prep_a(zzz, A);
-        ops::mul(A, Bppp, zzz3);
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             y[l] = fq2l::sub_norm(a[l], b[l], -1);  // + q if negative -> [0, 1 + 2 e]
             x[l] = x3[l];
-            zz[l] = zz3[l];
-            zzz[l] = zzz3[l];
         }
     }
     // this = 2 (px, ny): mdbl-2008-s-1 (ec.hip.h dbl_affine).  U = 2 y enters as 2 y - q: tight.

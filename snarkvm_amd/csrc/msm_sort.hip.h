@@ -18,6 +18,7 @@
 #pragma once
 #include "ffl.hip.h"
 #include "ffl2.hip.h"
+#include "ffl2p.hip.h"
 #include "msm.hip.h"
 
 namespace sv {
@@ -1035,7 +1036,7 @@ __global__ void __launch_bounds__(256, 1) msm_accumulate_lazy2_kernel(const aff_
         const g2_lazy_slot_t* sp = slot_of(e);
         e_cur = e_n1;
         if (pos + 2 < hi) e_n1 = sorted[pos + 2];
-        if (sp->w[52]) continue;  // the point at infinity
+        if (sp->w[g2_lazy_slot_t::INF_WORD]) continue;  // the point at infinity
         const bool neg = (e >> 31) != 0;
         fq2l_t px, py;
         sp->coords(px, py);
@@ -1047,6 +1048,92 @@ __global__ void __launch_bounds__(256, 1) msm_accumulate_lazy2_kernel(const aff_
         }
     }
     (void)PREFETCH;  // the 52-limb slot is read at its use: a second resident slot would not fit the register file
+}
+
+// ---- G2 on a lane pair (round 5; ffl2p.hip.h): lanes 2 t and 2 t + 1 walk segment t together, the even lane holding the c0 component of
+// every value and the odd lane the c1 component; every case of the addition law stays in the pair arithmetic.  Partial sums leave as
+// g2_pair_partial_t (each lane stores its four components) and g2_pair_partials_to_exact_kernel converts them - one thread per coordinate
+// component - into the exact representation the tail kernels read.
+static __global__ void __launch_bounds__(256) g2_pair_partials_to_exact_kernel(const g2_pair_partial_t* __restrict__ raw, xyzz_mem_t<fq2_t>* __restrict__ partial,
+                                                                        const uint32_t* __restrict__ start, uint32_t nbt) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = g >> 3, k = g & 7;  // partial sum, component (2 * coordinate + c0 / c1)
+    if (i >= start[nbt]) return;
+    const uint4* q = (const uint4*)&raw[i].w[16 * k];
+    uint32_t t[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint4 u = q[j];
+        t[4 * j] = u.x, t[4 * j + 1] = u.y, t[4 * j + 2] = u.z, t[4 * j + 3] = u.w;
+    }
+    fql_t c;
+#pragma unroll
+    for (int j = 0; j < 13; j++) c.v[j] = (int32_t)t[j];
+    c.to_exact().store(&((fq_mem_t*)&partial[i])[k]);
+}
+template <bool PREFETCH>  // (a template so that only the unit that launches it - api_g2.hip - compiles it)
+__global__ void __launch_bounds__(256, 2) msm_accumulate_pair2_kernel(const aff_mem_t<fq2_t>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                               const uint32_t* __restrict__ boff, const uint32_t* __restrict__ start,
+                                                               g2_pair_partial_t* __restrict__ partial, uint32_t nbt, uint32_t S, uint32_t debug_idx_mask) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt >> 1;            // the segment of this lane pair
+    const int comp = (int)(gt & 1u);       // 0: c0 (even lane), 1: c1 (odd lane)
+    const uint32_t total = boff[nbt];
+    const uint64_t lo64 = (uint64_t)t * S;
+    if (lo64 >= total) return;  // both lanes of a pair leave together
+    const uint32_t lo = (uint32_t)lo64;
+    const uint32_t hi = (total - lo < S) ? total : lo + S;
+    uint32_t k = find_bucket(boff, nbt, lo);
+    uint32_t kend = boff[k + 1];
+    uint32_t kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];  // bucket bookkeeping one bucket ahead (see msm_accumulate_lazy_kernel)
+    uint32_t start_k = start[k];
+    uint32_t part_off = t - boff[k] / S;
+    fq2p::xyzz_pair_t<fq2p::xp_dev> acc;
+    acc.inf = true;
+    auto slot_of = [&](uint32_t e) -> const g2_lazy_slot_t* { return (const g2_lazy_slot_t*)&bases[(e & 0x7fffffffu) & debug_idx_mask]; };
+    uint32_t e_cur = sorted[lo];
+    uint32_t e_n1 = lo + 1 < hi ? sorted[lo + 1] : 0u;
+    for (uint32_t pos = lo;; pos++) {
+        const bool end = pos >= hi;
+        if (end || pos >= kend) {
+            uint4* q = (uint4*)&partial[start_k + part_off].w[16 * comp];  // component (2 * coordinate + comp) at words 32 * coordinate + 16 * comp
+            if (acc.inf) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) q[8 * c4 + j] = make_uint4(0, 0, 0, 0);
+            } else {
+                const fql_t* cs[4] = {&acc.x[0], &acc.y[0], &acc.zz[0], &acc.zzz[0]};
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    const int32_t* v = cs[c4]->v;
+                    q[8 * c4 + 0] = make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
+                    q[8 * c4 + 1] = make_uint4((uint32_t)v[4], (uint32_t)v[5], (uint32_t)v[6], (uint32_t)v[7]);
+                    q[8 * c4 + 2] = make_uint4((uint32_t)v[8], (uint32_t)v[9], (uint32_t)v[10], (uint32_t)v[11]);
+                    q[8 * c4 + 3] = make_uint4((uint32_t)v[12], 0u, 0u, 0u);
+                }
+            }
+            if (end) break;
+            part_off = 0;
+            acc.inf = true;
+            k++;
+            kend = kend2;
+            while (pos >= kend) {
+                k++;
+                kend = boff[k + 1];
+            }
+            kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+            start_k = start[k];
+        }
+        const uint32_t e = e_cur;
+        const g2_lazy_slot_t* sp = slot_of(e);
+        e_cur = e_n1;
+        if (pos + 2 < hi) e_n1 = sorted[pos + 2];
+        if (sp->w[g2_lazy_slot_t::INF_WORD]) continue;  // the point at infinity (both lanes read the same word)
+        fql_t px[1], py[1];
+        sp->component(comp, px[0], py[0]);
+        acc.madd(px, py, (e >> 31) != 0);
+    }
 }
 
 }  // namespace sv

@@ -232,17 +232,17 @@ struct device_t {
     ntt_tables_t tb{};
     dev_buf tables_mem;
     ntt_tw_cache_t tw;
-    static constexpr int LANES = 8;
+    static constexpr int LANES = 16;  // streams are created up front; a lane's buffers only when it is first used
     lane_t lane[LANES];
     // token pool
     std::mutex mu;
     std::condition_variable cv;
     uint32_t busy = 0;
-    // lanes held by deferred-synchronisation scopes (for as long as the scope is open).  At most SCOPE_LANES_MAX of them: two lanes of
+    // lanes held by deferred-synchronisation scopes (for as long as the scope is open).  At most SCOPE_LANES_MAX of them: four lanes of
     // every device always belong to calls that return their lane when they return, so a thread that waits for a lane - the ninth
     // scope_begin, a call on another device from inside a scope, the per-device worker threads of a multi-GPU call - waits for
     // something that ends (round-4 review: eight scopes that each issued an MSM held all eight lanes and waited for a ninth).
-    static constexpr int SCOPE_LANES_MAX = LANES - 2;
+    static constexpr int SCOPE_LANES_MAX = LANES - 4;
     int scope_held = 0;
 
     void init() {  // the calling thread has this device current
@@ -436,7 +436,7 @@ static void tu_kernel_attributes(int logical) {
 // SNARKVM_HIP_SCOPE_ASYNC_MSM: MSMs over registered bases with device-resident scalars are enqueued as well - on up to SCOPE_AUX_MAX
 // further lanes of the scope, in turn, each behind an event of the scope's stream - and their host finishes (the Horner chain over the
 // bit planes) run when the scope is flushed.
-static constexpr int SCOPE_AUX_MAX = 3;
+static constexpr int SCOPE_AUX_MAX = 7;  // one proof: six commitment rounds + the G2 MSM, every one on its own stream
 struct scope_pending_t {
     hipEvent_t done;               // everything the finish reads has arrived in pinned memory
     std::function<void()> finish;  // host Horner chains -> the callers' `out` buffers
@@ -1187,6 +1187,7 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
             // scalars are all equal (a 2^18-pair instance then leaves ~70 000 partial sums in ONE bucket: 1 100 dependent additions per
             // lane of its row) at the price of one more pass over the partial sums of well-behaved instances.
             if (mu && tuning().fuse_reduce > 0) rounds = tuning().fuse_reduce > 4 ? 4 : tuning().fuse_reduce;
+            if (mu && tuning().fuse_reduce < 0) rounds = mu->K >= 8 ? 1 : 0;
             hipLaunchKernelGGL(msm_alloc_seg_kernel, dim3((nbt + 1 + 255) / 256), dim3(256), 0, st, boffp, c.cnt_a.as<uint32_t>(), nbt, pl.S);
             exclusive_scan_u32(st, c.cnt_a.as<uint32_t>(), c.start_a.as<uint32_t>(), (size_t)nbt + 1, c.scan_tmp.as<uint32_t>());
             const size_t nthreads = (E_max + pl.S - 1) / pl.S;
@@ -1224,6 +1225,17 @@ static msm_pending_t msm_run(lane_t& c, const aff_mem_t<F>* d_bases, const uint4
                 }
             } else {
 #ifndef SV_NO_G2
+                if (msm_lazy_on<F>() && tuning().pair2) {
+                    // G2 on a lane pair (ffl2p.hip.h): two lanes per segment, two waves per SIMD; raw 512-byte partial sums, then the dense conversion
+                    const size_t tmax = nthreads + nbt + 1;
+                    c.part_raw.ensure(tmax * sizeof(g2_pair_partial_t));
+                    hipLaunchKernelGGL((msm_accumulate_pair2_kernel<false>), dim3((unsigned)((2 * nthreads + 255) / 256)), dim3(256), 0, st, vbase, c.sorted.as<uint32_t>(),
+                                       boffp, c.start_a.as<uint32_t>(), c.part_raw.as<g2_pair_partial_t>(), nbt, pl.S, dbg_mask);
+                    hipLaunchKernelGGL(g2_pair_partials_to_exact_kernel, dim3((unsigned)((8 * tmax + 255) / 256)), dim3(256), 0, st,
+                                       (const g2_pair_partial_t*)c.part_raw.as<g2_pair_partial_t>(), c.part_a.as<xyzz_mem_t<fq2_t>>(),
+                                       (const uint32_t*)c.start_a.as<uint32_t>(), nbt);
+                    goto accumulated;
+                }
                 if (msm_lazy_on<F>()) {  // G2 on the lazy Fq2 arithmetic of ffl2.hip.h: raw 416-byte partial sums, then the dense conversion
                     const size_t tmax = nthreads + nbt + 1;
                     c.part_raw.ensure(tmax * sizeof(g2_lazy_partial_t));
@@ -1351,7 +1363,7 @@ static void precompute_tables_run(lane_t& c, aff_mem_t<F>* d, size_t n, int tabl
 // workspace footprint of big ones down (a 2^24 lane holds ~4 GB)
 static int batch_lanes(size_t npoints) {
     const int env = tuning().lanes;
-    int l = env > 0 ? env : (npoints >= ((size_t)1 << 20) ? 3 : device_t::LANES);  // measured: 8 lanes +7 % below 2^20, no gain above
+    int l = env > 0 ? env : (npoints >= ((size_t)1 << 20) ? 3 : 8);  // measured: 8 lanes +7 % below 2^20, no gain above
     return l < 1 ? 1 : (l > device_t::LANES ? device_t::LANES : l);
 }
 static constexpr size_t MSM_SPLIT_MIN = (size_t)1 << 18;  // pairs per device below which a point-range split costs more than it saves
@@ -1893,7 +1905,8 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
         uint8_t* planes = c.pin.template as<uint8_t>() + c.pin_used;
         msm_inst_t* tab = (msm_inst_t*)(planes + pb);
         c.pin_used += pb + tb;
-        hipEvent_t read = (&c != sc.lane) ? c.scope_event() : nullptr;
+        // SNARKVM_HIP_SCOPE_STABLE_INPUTS: the caller leaves the scalar vectors alone until the scope ends - the scope's stream does not wait
+        hipEvent_t read = (&c != sc.lane && !(sc.flags & SNARKVM_HIP_SCOPE_STABLE_INPUTS)) ? c.scope_event() : nullptr;
         const msm_pending_t pd = msm_enqueue_job<F>(c, h, d->logical, rq->data(), j, planes, tab, 1, scalars_montgomery, window_bits, read);
         if (read) HIP_TRY(hipStreamWaitEvent(sc.lane->stream, read, 0));
         hipEvent_t done = c.scope_event();

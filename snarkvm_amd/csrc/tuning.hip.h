@@ -14,11 +14,12 @@
 //
 //   key             default  meaning
 //   lazy            1        G1 accumulation on the signed-limb arithmetic of ffl.hip.h (0: exact kernel)
-//   lazy_tail       0        1: G1 reduce rounds, bucket merge, fold and bit planes on the lazy arithmetic too (ffl.hip.h::fqz_t), no conversion pass.
+//   lazy_tail       1        1: G1 reduce rounds, bucket merge, fold and bit planes on the lazy arithmetic too (ffl.hip.h::fqz_t), no conversion pass.
 //                            Measured at 2^24: the conversion pass goes (-0.52 ms) but the tail kernels do not get faster (reduce 0.89 vs 0.87 ms,
 //                            fold + bit planes 1.54 vs 1.46 ms: every sum / difference is a 13-step carry chain in a latency-bound kernel, and the
-//                            fold / bit-plane kernels spill 808 B at 256 registers): 30.71 vs 30.88 ms per step, 197.4 vs 196.6 proofs/s - kept as
-//                            a bit-exact switch, off by default
+//                            fold / bit-plane kernels spill 808 B at 256 registers): 30.71 vs 30.88 ms per step, 197.4 vs 196.6 proofs/s.  Round 5: ON - where it
+//                            pays is a single proof (no conversion pass in any of its six commitment rounds: 8.49 vs 8.88 ms per proof,
+//                            profiles/r05_proof1_timeline.md)
 //   lazy2           1        G2 accumulation on the signed-limb Fq2 arithmetic (0: exact kernel)
 //   fused           1        wide windows: scalar read fused with the level-1 partition (0: stand-alone digit matrix)
 //   hist            2        scalar-read kernel variant (1: 512 threads x 4 scalars, one LDS histogram - round 3; 2: 1 024 threads x 2
@@ -33,8 +34,9 @@
 //   fold_flat       1        flattened-list fold for every MSM (0: per-bucket lists for big ones)
 //   fuse_batch      1        small instances of a batch travel as fused multi-instance groups
 //   fuse_max_k      64       instances per fused group
-//   fuse_reduce     1        reduce rounds of a fused group before its fold (0: none; 1: +1.6 % on the lock-step proof replay and a bound on
-//                            what an all-equal scalar vector can leave in one bucket)
+//   fuse_reduce     -1       reduce rounds of a fused group before its fold (0: none; 1: +1.6 % on the lock-step proof replay and a bound on
+//                            what an all-equal scalar vector can leave in one bucket; -1: one round for groups of >= 8 instances, none for
+//                            the 1 - 4 instances of a single proof's commitment round, where the extra pass is pure latency: 8.69 vs 8.88 ms per proof)
 //   coalesce        1        concurrent callers of small registered MSMs are fused by an in-library dispatcher
 //   coalesce_us     40       how long a dispatcher waits for further callers when others are inside the library
 //   lanes           0        lanes a batch cycles through (0: 8 below 2^20 pairs, 3 above)
@@ -57,6 +59,7 @@
 //   xcd             1        scatter kernels of the radix partition: XCD x walks a contiguous tile range (msm_sort.hip.h::xcd_tile)
 //   fold_threads2   128      G2: threads per output of a small fold (its kernels run one wave per SIMD: 256-thread workgroups = one per CU)
 //   coalesce_slots  2        dispatchers of the coalescer that may be inside the library at once (per handle)
+//   pair2           1        G2 accumulation on a lane pair (ffl2p.hip.h: c0 on the even lane, c1 on the odd lane; 0: both components in one lane, ffl2.hip.h)
 //   horner2         1        p / (X - z): three launches with a scan inside every workgroup (0: the four-level chunk recursion of round 3)
 #pragma once
 #include <stdio.h>
@@ -68,10 +71,10 @@ namespace sv {
 struct tuning_t {
     int lazy = 1, lazy2 = 1, fused = 1, hist = 2, prefetch = 2;
     long acc_lds = 96 * 1024;
-    int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
+    int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = -1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
-    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 0, horner2 = 1;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 1, horner2 = 1, pair2 = 1;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -83,7 +86,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2) SV_TUNE_KEY(pair2)
 #undef SV_TUNE_KEY
         return false;
     }
@@ -118,7 +121,7 @@ struct tuning_t {
         fix("coalesce_slots", coalesce_slots, 1, 8);
         fix("coalesce_us", coalesce_us, 0, 100000);
         fix("fuse_max_k", fuse_max_k, 2, 256);
-        fix("fuse_reduce", fuse_reduce, 0, 4);
+        fix("fuse_reduce", fuse_reduce, -1, 4);
         fix("reduce_rounds", reduce_rounds, 0, 8);
         fix("lanes", lanes, 0, 8);
         fix("ring_lanes", ring_lanes, 2, 8);

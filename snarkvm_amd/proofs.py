@@ -232,7 +232,7 @@ class SingleProofWorkspace:
     """Device buffers of ONE proof proved at a time by one caller thread (BASELINE.json configs[3]): every vector of the proof has
     its own row, so that the independent transforms of a round can travel as one batch and nothing has to wait for a buffer."""
 
-    ROWS = 26
+    ROWS = 28
 
     def __init__(self, keys, device_index=0):
         import torch
@@ -289,7 +289,8 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None):
     def rp(r):
         return ctypes.c_void_p(row(r))
 
-    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(pool.data_ptr()), 1 if async_msm else 0))
+    # every committed vector keeps its row until the proof is done (SNARKVM_HIP_SCOPE_STABLE_INPUTS: the transform stream never waits for an MSM)
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(pool.data_ptr()), 3 if async_msm else 0))
     try:
         stream = torch.cuda.ExternalStream(L.snarkvm_hip_scope_stream(), device=ws.device)
 
@@ -328,10 +329,10 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None):
             _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, 1 << sh.lg_g2,
                                                         ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0))
         mark("g2 msm issued")
-        load(0, nR, 1, count=2)                                                              # round 1: rows 0, 1
-        ntt([0], sh.lg_r, 1); ntt([1], sh.lg_r, 0)
+        load(26, nR, 1, count=2)                                                             # round 1: rows 26, 27
+        ntt([26], sh.lg_r, 1); ntt([27], sh.lg_r, 0)
         mark("round 1 transforms issued")
-        commit_round([(row(0), nR - 2, 2)])
+        commit_round([(row(26), nR - 2, 2)])
         mark("round 1 commit issued")
         load(0, nR, 10, count=3, zero_to=2 * nR)                                             # round 2: z_a, z_b, z_c in rows 0, 1, 2
         ntt([0, 1, 2], sh.lg_r, 1)
@@ -582,13 +583,17 @@ class ProofBatch:
     """`count` proofs replayed by `workers` concurrent caller threads (BASELINE.json configs[4]: 64 proofs; one process per GPU
     takes its share, or one process drives every device the backend uses)."""
 
-    def __init__(self, keys, workers=4, devices=None):
+    def __init__(self, keys, workers=4, devices=None, scope=False):
+        """scope=True: every worker issues its proof inside ONE asynchronous scope (`replay_single`: nothing waits for the GPU until the
+        proof's results are due, a round's independent transforms are one batched call); False: one synchronous call per step (`replay`)."""
         import torch
 
         self.keys = keys
+        self.scope = scope
         ndev = torch.cuda.device_count()
         devices = list(range(ndev)) if devices is None else list(devices)
-        self.workspaces = [ProofWorkspace(keys, devices[w % len(devices)]) for w in range(workers)]
+        cls = SingleProofWorkspace if scope else ProofWorkspace
+        self.workspaces = [cls(keys, devices[w % len(devices)]) for w in range(workers)]
         self._free = list(self.workspaces)
         self._lock = threading.Lock()
 
@@ -601,7 +606,7 @@ class ProofBatch:
                 ws = self._free.pop()
             try:
                 got = [] if collect else None
-                replay(ws, salts[i], got)
+                (replay_single if self.scope else replay)(ws, salts[i], got)
                 results[i] = got
             finally:
                 with self._lock:

@@ -302,7 +302,7 @@ print("AB_OK")
 
 @pytest.mark.parametrize("tuning", [
     "ntt_min_tiles=1", "ntt_min_tiles=1024", "lazy=0", "prefetch=0", "acc_one_wg=1,acc_lds=83968", "fuse_batch=0", "fused=0", "seg=96", "reduce_rounds=0", "reduce_rounds=2,seg2=8",
-    "hist=1", "ntt_signed=1", "ntt_batch=0", "ring_lanes=5", "coalesce=0", "taper=0", "fuse_max_k=2", "fuse_reduce=0", "lazy2=0", "lazy_tail=1", "xcd=0", "fold_threads2=256", "coalesce_slots=1", "horner2=0"])
+    "hist=1", "ntt_signed=1", "ntt_batch=0", "ring_lanes=5", "coalesce=0", "taper=0", "fuse_max_k=2", "fuse_reduce=0", "lazy2=0", "lazy_tail=1", "xcd=0", "fold_threads2=256", "coalesce_slots=1", "horner2=0", "lazy_tail=0", "fuse_reduce=1", "fuse_reduce=0", "pair2=0"])
 def test_ab_switches_are_bit_exact(tuning):
     """csrc/tuning.hip.h: one variable, parsed once per process; every key selects another kernel / launch shape for the same mathematics."""
     r = subprocess.run([sys.executable, "-c", AB_SCRIPT % util.ROOT], capture_output=True, text=True, env=dict(os.environ, SNARKVM_HIP_TUNING=tuning), timeout=900, cwd=util.ROOT)

@@ -225,3 +225,15 @@ def test_lazy_g2_accumulate_arithmetic_matches_exact():
     for seed in (1, 7, 0xC0FFEE):
         rc = L.snarkvm_hip_selftest_fq2_lazy(ctypes.c_void_p(pts.ctypes.data), ctypes.c_size_t(pts.shape[0]), ctypes.c_uint64(seed), ctypes.c_int(1500))
         assert rc == 0, (seed, rc)
+
+
+def test_fq2_lane_pair_arithmetic_matches_exact():
+    """csrc/ffl2p.hip.h (round 5): the G2 accumulate kernel's Fq2 arithmetic split over a lane pair - c0 on the even lane, c1 on the odd
+    lane, one two-product column sum per lane, operands exchanged between the lanes - run on the host with both lanes side by side
+    (the same source, exchange = a swap of two array entries) against the exact Fq2 / XYZZ arithmetic: chains of G2 mixed additions with
+    doublings and cancellations (resolved inside the pair arithmetic, mdbl-2008-s-1) and restarts, every component after every step."""
+    L = _lib.lib()
+    pts = synthetic.g2_points(48, distinct=48)
+    for seed in (1, 7, 0xC0FFEE, 99):
+        rc = L.snarkvm_hip_selftest_fq2_pair(ctypes.c_void_p(pts.ctypes.data), ctypes.c_size_t(pts.shape[0]), ctypes.c_uint64(seed), ctypes.c_int(1500))
+        assert rc == 0, (seed, rc)

@@ -5,7 +5,8 @@
 // the 14 commitments of every proof are compared (affine) with a single-threaded replay of the same proof.
 //   build: g++ -std=c++17 -O2 -pthread -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bench_proof_callers.cpp -o /tmp/bench_proof_callers
 //          -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib
-//   run:   /tmp/bench_proof_callers [g2 points file (200 B each, 2^16 of them) or -] [threads ...]
+//   run:   /tmp/bench_proof_callers [g2 points file (200 B each, 2^16 of them) or -] [--scope] [threads ...]
+//          --scope: every caller issues its proof inside ONE asynchronous scope (replay_scope below) instead of one synchronous call per step
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
@@ -46,6 +47,8 @@ struct keys_t {
 };
 struct workspace_t {
     uint8_t* v[4];  // a, b, c, d: NMAX elements each
+    uint8_t* rows = nullptr;  // replay_scope: 28 vectors of NMAX elements
+    uint64_t rem[3][4];
     hipStream_t st;
     std::vector<uint8_t> results;  // 14 x 144 B per proof
     uint8_t g2_out[288];
@@ -120,10 +123,83 @@ static void replay(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14)
     }
 }
 
+// The same proof issued for overlap (snarkvm_amd/proofs.py::replay_single): ONE deferred-synchronisation scope per proof with
+// SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS - no call waits for the GPU, the operand copies go onto the scope's own stream, the
+// independent transforms of a round are one batched call, the commitment rounds run on further streams and are finished by scope_end.
+// w.rows: 28 vectors of NMAX elements (every committed vector keeps its row until the proof is done).
+static void replay_scope(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14) {
+    size_t nout = 0;
+    auto row = [&](int r) { return w.rows + (size_t)r * NMAX * 32; };
+    RK(snarkvm_hip_scope_begin_ex(K.pool, SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS));
+    hipStream_t st = (hipStream_t)snarkvm_hip_scope_stream();
+    auto load = [&](int r, size_t n, size_t shift, int count = 1, size_t zero_to = 0) {
+        for (int i = 0; i < count; i++) {
+            CK(hipMemcpyAsync(row(r + i), K.pool + 32 * (shift + i + salt), 32 * n, hipMemcpyDeviceToDevice, st));
+            if (zero_to > n) CK(hipMemsetAsync(row(r + i) + 32 * n, 0, 32 * (zero_to - n), st));
+        }
+    };
+    auto ntt = [&](std::vector<int> rows, int lg, int dir, int type = 0) {
+        std::vector<void*> ptrs;
+        for (int r : rows) ptrs.push_back(row(r));
+        std::vector<int> dirs(rows.size(), dir), types(rows.size(), type);
+        RK(snarkvm_hip_ntt_device_batch(ptrs.data(), ptrs.size(), (uint32_t)lg, 0, dirs.data(), types.data()));
+    };
+    auto mul = [&](int x, int y, int lg, size_t count = 1) { RK(snarkvm_hip_fr_vec_op_strided(2, row(x), row(x), row(y), nullptr, nullptr, (size_t)1 << lg, count, NMAX)); };
+    struct poly_t {
+        const void* p;
+        size_t n, hiding;
+    };
+    auto commit_round = [&](std::vector<poly_t> polys) {
+        const size_t k = polys.size();
+        std::vector<size_t> off0(k, 0), n0(k), off1(k, NMAX), n1(k);
+        std::vector<const void*> ptrs(k);
+        for (size_t i = 0; i < k; i++) ptrs[i] = polys[i].p, n0[i] = polys[i].n, n1[i] = polys[i].hiding;
+        RK(snarkvm_hip_msm_registered_batch_ex(out14 + 144 * nout, K.h, k, off0.data(), n0.data(), off1.data(), n1.data(), ptrs.data(), 1, 1, 0));
+        nout += k;
+    };
+    if (K.hg2) RK(snarkvm_hip_msm_g2_registered(w.g2_out, K.hg2, 0, (size_t)1 << LG_G2, K.pool + 32 * (23 + salt), 1, 0));
+    load(26, N_R, 1, 2);  // round 1
+    ntt({26}, LG_R, 1), ntt({27}, LG_R, 0);
+    commit_round({{row(26), N_R - 2, 2}});
+    load(0, N_R, 10, 3, 2 * N_R);  // round 2
+    ntt({0, 1, 2}, LG_R, 1);
+    ntt({0, 1}, LG_R + 1, 0), mul(0, 1, LG_R + 1), ntt({0}, LG_R + 1, 1);
+    RK(snarkvm_hip_fr_vec_op(1, row(0), row(0), row(2), nullptr, nullptr, 2 * N_R, 1));
+    RK(snarkvm_hip_fr_divide_by_vanishing(row(1), row(3), row(0), 2 * N_R, N_R, 1));
+    commit_round({{row(1), N_R, 0}});
+    load(4, N_R, 20, 3, 2 * N_R), load(7, N_R, 30, 3, 2 * N_R);  // round 3
+    ntt({4, 5, 6}, LG_R, 1);
+    ntt({4, 7, 5, 8, 6, 9}, LG_R + 1, 0), mul(4, 7, LG_R + 1, 3), ntt({4, 5, 6}, LG_R + 1, 1);
+    commit_round({{row(6), N_R - 1, 2}, {row(9), N_R, 0}});
+    load(10, N_K, 40, 3, 2 * N_K), load(13, N_K, 50, 3), load(16, N_K, 60, 3), load(19, N_K, 70, 1, 2 * N_K);  // round 4
+    ntt({10, 11, 12, 13, 14, 15}, LG_K, 1);
+    ntt({16, 17, 18}, LG_K, 1, 1);
+    ntt({10, 19}, LG_K + 1, 0), mul(10, 19, LG_K + 1), ntt({10}, LG_K + 1, 1);
+    commit_round({{row(10), N_K - 1, 0}, {row(11), N_K - 1, 0}, {row(12), N_K - 1, 0}});
+    commit_round({{K.pool + 32 * (3 + salt), N_K - 2, 0}, {K.pool + 32 * (5 + salt), N_K, 0}, {K.pool + 32 * (9 + salt), N_R, 0}, {K.pool + 32 * (11 + salt), N_K, 0}});
+    const size_t os[3] = {13, 17, 19}, on[3] = {N_K, N_R, N_K};
+    for (int i = 0; i < 3; i++) {
+        load(20 + i, on[i], os[i]);
+        RK(snarkvm_hip_fr_divide_by_linear(row(23 + i), w.rem[i], row(20 + i), on[i], K.point, 1));
+    }
+    commit_round({{row(23), N_K - 1, 0}, {row(24), N_R - 1, 0}, {row(25), N_K - 1, 0}});
+    RK(snarkvm_hip_scope_end());
+    if (nout != 14) {
+        fprintf(stderr, "replay_scope: %zu results\n", nout);
+        exit(4);
+    }
+}
+
 int main(int argc, char** argv) {
     const char* g2file = argc > 1 ? argv[1] : "-";
     std::vector<int> thread_counts;
-    for (int i = 2; i < argc; i++) thread_counts.push_back(atoi(argv[i]));
+    bool scope_mode = false;
+    for (int i = 2; i < argc; i++) {
+        if (!strcmp(argv[i], "--scope"))
+            scope_mode = true;  // callers issue every proof inside one asynchronous scope (replay_scope)
+        else
+            thread_counts.push_back(atoi(argv[i]));
+    }
     if (thread_counts.empty()) thread_counts = {1, 4, 8, 16};
     const int nproofs = 64;
     CK(hipSetDevice(0));
@@ -166,6 +242,8 @@ int main(int argc, char** argv) {
     std::vector<workspace_t> ws(max_threads);
     for (auto& w : ws) {
         for (auto& v : w.v) CK(hipMalloc((void**)&v, NMAX * 32));
+        CK(hipMalloc((void**)&w.rows, 28 * NMAX * 32));
+        CK(hipMemset(w.rows, 0, 28 * NMAX * 32));
         CK(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
     }
     // reference: every proof replayed alone on workspace 0, commitments normalised
@@ -177,17 +255,19 @@ int main(int argc, char** argv) {
     }
     const double serial_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
     printf("one caller, %d proofs one after the other (including the normalisation of the reference results): %.2f ms per proof\n\n", nproofs, serial_ms / nproofs);
+    printf("callers: %s\n\n", scope_mode ? "one SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS scope per proof (replay_scope)" : "one synchronous call per step (replay)");
     printf("| caller threads | proofs | wall ms | proofs/s | ms per proof | coalescer: batches | instances per batch | largest | results |\n|---|---|---|---|---|---|---|---|---|\n");
     for (int T : thread_counts) {
         if (T > max_threads) T = max_threads;
         std::vector<uint8_t> got((size_t)nproofs * 14 * 144);
-        for (int t = 0; t < T; t++) replay(K, ws[t], 1000 + t, raw.data());  // warm-up: one proof per worker
+        auto run = [&](workspace_t& w, size_t p, uint8_t* out) { scope_mode ? replay_scope(K, w, p, out) : replay(K, w, p, out); };
+        for (int t = 0; t < T; t++) run(ws[t], 1000 + t, raw.data());  // warm-up: one proof per worker
         snarkvm_hip_coalescer_stats(nullptr, 1);
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int t = 0; t < T; t++)
             th.emplace_back([&, t] {
-                for (int p = t; p < nproofs; p += T) replay(K, ws[t], (size_t)p, &got[(size_t)p * 14 * 144]);
+                for (int p = t; p < nproofs; p += T) run(ws[t], (size_t)p, &got[(size_t)p * 14 * 144]);
             });
         for (auto& x : th) x.join();
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
