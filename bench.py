@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64, callers mode)")
     ap.add_argument("--proof-geometry", default="17x15", help="base tables x window bits of the proofs' registered SRS (proofs64)")
     ap.add_argument("--proof-group", type=int, default=32, help="proofs replayed in lock step per group (proofs64, lockstep mode)")
+    ap.add_argument("--lockstep-sync", action="store_true", help="proofs64: round 4's lock-step form (a scope per step, synchronous commitment calls)")
     ap.add_argument("--proof1-sync-msm", action="store_true", help="proof1: synchronous commitments (the A/B of SNARKVM_HIP_SCOPE_ASYNC_MSM)")
     ap.add_argument("--no-proof-legs", action="store_true", help="default workload: skip the proof1 / proofs64 / concurrent_callers legs")
     args = ap.parse_args()
@@ -839,27 +840,40 @@ def proof_legs(dev_index, with_oracle):
     leg = dict(proof1_summary(dt, lat, times, grown, P), value=P / dt, unit="proofs/s",
                what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof (bench.py --workload proof1)")
     out["proof1"] = leg
-    # ---- proofs64 shape, 32 proofs in lock step
-    lock = proofs.LockstepBatch(keys, group=P, devices=[dev_index])
-    lock.run(salts)
-    for ws in lock.workspaces:
-        ws.times = {k: 0.0 for k in ws.times}
-    _lib.check(L.snarkvm_hip_synchronize())
-    t0 = time.perf_counter()
-    _, got_lock = lock.run(salts, collect=True)
-    _lib.check(L.snarkvm_hip_synchronize())
-    dt_lock = time.perf_counter() - t0
-    t_lock = dict(lock.workspaces[0].times)
-    del lock
-    torch.cuda.empty_cache()
+    # ---- proofs64 shape, 32 proofs in lock step: one asynchronous scope per group (`value`), then round 4's form (a scope per step, synchronous
+    # commitment calls), whose call times give the pair rates inside the fused MSM calls
+    def lockstep(async_scope):
+        lock = proofs.LockstepBatch(keys, group=P, devices=[dev_index], async_scope=async_scope)
+        lock.run(salts)
+        for ws in lock.workspaces:
+            ws.times = {k: 0.0 for k in ws.times}
+        _lib.check(L.snarkvm_hip_synchronize())
+        t0 = time.perf_counter()
+        _, got = lock.run(salts, collect=True)
+        _lib.check(L.snarkvm_hip_synchronize())
+        dt = time.perf_counter() - t0
+        times = dict(lock.workspaces[0].times)
+        del lock
+        torch.cuda.empty_cache()
+        return dt, got, times
+
+    dt_lock, got_lock, t_async = lockstep(True)
+    dt_lock_sync, got_lock_sync, t_lock = lockstep(False)
+    if [proofs.normalize_results(r) for r in got_lock] != [proofs.normalize_results(r) for r in got_lock_sync]:
+        raise SystemExit("bench.py: proof legs: the two lock-step forms differ")
     norm1 = [proofs.normalize_results(r) for r in got1]
     norm_lock = [proofs.normalize_results(r) for r in got_lock]
     if norm1 != norm_lock:
         raise SystemExit("bench.py: proof legs: the one-at-a-time replay and the lock-step replay differ")
     out["proofs64"] = {"value": P / dt_lock, "unit": "proofs/s", "proofs": P, "ms_per_proof": dt_lock / P * 1e3,
-                       "g1_pairs_per_s_inside_msm_calls": P * shape.pairs() / t_lock["msm"] if t_lock.get("msm") else None,
-                       "g2_pairs_per_s_inside_msm_calls": P * (1 << shape.lg_g2) / t_lock["g2"] if t_lock.get("g2") else None,
-                       "call_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_lock.items()},
+                       "g1_pairs_per_s": P * shape.pairs() / dt_lock, "g2_pairs_per_s": P * (1 << shape.lg_g2) / dt_lock,
+                       "host_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_async.items()},
+                       "synchronous_commitment_calls": {
+                           "value": P / dt_lock_sync, "unit": "proofs/s", "ms_per_proof": dt_lock_sync / P * 1e3,
+                           "g1_pairs_per_s_inside_msm_calls": P * shape.pairs() / t_lock["msm"] if t_lock.get("msm") else None,
+                           "g2_pairs_per_s_inside_msm_calls": P * (1 << shape.lg_g2) / t_lock["g2"] if t_lock.get("g2") else None,
+                           "call_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_lock.items()},
+                           "what": "round 4's lock-step form: a scope per step, every commitment round a synchronous fused call"},
                        "what": "BASELINE.json configs[4] on one GPU with 32 proofs in lock step (bench.py --workload proofs64 runs 64, and the concurrent-caller mode)",
                        "checks": {"lockstep_vs_proof1": f"all {P} proofs x 15 results identical in both replays"}}
     leg["checks"] = {"proof1_vs_lockstep": f"all {P} proofs x 15 results identical in both replays"}
@@ -950,7 +964,7 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
     mine = list(range(rank, args.proofs, world))
     checks = {}
     # ---- lock step
-    lock = proofs.LockstepBatch(keys, group=min(args.proof_group, max(1, len(mine))), devices=[dev_index])
+    lock = proofs.LockstepBatch(keys, group=min(args.proof_group, max(1, len(mine))), devices=[dev_index], async_scope=not args.lockstep_sync)
     lock.run(mine[: lock.group])  # warm-up: allocations, twiddle tables
     for ws in lock.workspaces:
         ws.times = {k: 0.0 for k in ws.times}
@@ -969,8 +983,8 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
     # call per step (replay: the proof-sized MSMs of concurrent callers meet in the coalescer) - round 4's mode, kept beside it
     L = _lib.lib()
 
-    def callers(scope):
-        batch = proofs.ProofBatch(keys, workers=args.proof_workers, devices=[dev_index], scope=scope)
+    def callers(scope, async_msm=True):
+        batch = proofs.ProofBatch(keys, workers=args.proof_workers, devices=[dev_index], scope=scope, async_msm=async_msm)
         batch.run(list(range(len(batch.workspaces))))  # warm-up: one proof per worker
         for ws in batch.workspaces:
             ws.times = {k: 0.0 for k in ws.times}
@@ -989,13 +1003,15 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
         return dt, got, co, times, n_ws
 
     dt_thr, got_thr, _, t_scope, n_workers = callers(True)
+    dt_mix, got_mix, co_mix, _, _ = callers(True, async_msm=False)  # (c) a scope per proof for the transforms and passes, synchronous commitment rounds that meet in the coalescer
     dt_ser, got_ser, co, t_thr, _ = callers(False)
     # ---- checks (outside the timed regions)
     norm_lock = [proofs.normalize_results(r) for r in got_lock]
     norm_thr = [proofs.normalize_results(r) for r in got_thr]
     norm_ser = [proofs.normalize_results(r) for r in got_ser]
+    norm_mix = [proofs.normalize_results(r) for r in got_mix]
     for i, p in enumerate(mine):
-        if norm_lock[i] != norm_thr[i] or norm_lock[i] != norm_ser[i]:
+        if norm_lock[i] != norm_thr[i] or norm_lock[i] != norm_ser[i] or norm_lock[i] != norm_mix[i]:
             raise SystemExit(f"bench.py: proof {p}: the lock-step replay and the concurrent-caller replays differ")
     checks["lockstep_vs_callers"] = f"all {len(mine)} proofs of this rank: 14 commitments + the G2 result identical in the lock-step replay and both caller modes"
     if rank == 0 and mine and not args.no_cpu_baseline:
@@ -1038,18 +1054,26 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
             "config": {"workload": "64 x (14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM); "
                                    "device-resident random data, transfer_private domain sizes; lock-step batch (prove_batch shape)",
                        "proofs": args.proofs, "lockstep_group": min(args.proof_group, max(1, len(mine))), "proofs_per_rank": len(mine),
-                       "registered_srs": f"{ptab} tables x {pbits}-bit windows"},
+                       "registered_srs": f"{ptab} tables x {pbits}-bit windows",
+                       "lockstep_form": "a scope per step, synchronous commitment calls" if args.lockstep_sync else "one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per group"},
             "g1_pairs_per_s": args.proofs * shape.pairs() / dt_lock,
             "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt_lock,
             "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_lock.items()},
             # the fused G1 rate on the proof mix: pairs of this rank / wall time spent inside its snarkvm_hip_msm_registered_batch_ex calls
-            "g1_pairs_per_s_inside_msm_calls": (len(mine) * shape.pairs() / t_lock["msm"]) if t_lock.get("msm") else None,
-            "g2_pairs_per_s_inside_msm_calls": (len(mine) * (1 << shape.lg_g2) / t_lock["g2"]) if t_lock.get("g2") else None,
+            # (only with --lockstep-sync: an asynchronous scope's calls return at once)
+            "g1_pairs_per_s_inside_msm_calls": (len(mine) * shape.pairs() / t_lock["msm"]) if (t_lock.get("msm") and args.lockstep_sync) else None,
+            "g2_pairs_per_s_inside_msm_calls": (len(mine) * (1 << shape.lg_g2) / t_lock["g2"]) if (t_lock.get("g2") and args.lockstep_sync) else None,
             "concurrent_callers": {"value": args.proofs / dt_thr, "unit": "proofs/s", "ms_per_proof": dt_thr / args.proofs * 1e3,
                                    "caller_threads_per_rank": n_workers, "g1_pairs_per_s": args.proofs * shape.pairs() / dt_thr,
                                    "rank0_host_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_scope.items()},
                                    "what": "one proof per caller thread at a time (the reference's rayon fan-out), every proof issued inside one asynchronous scope "
                                            "(SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS: snarkvm_amd/proofs.py::replay_single)",
+                                   "scope_with_synchronous_commitments": {
+                                       "value": args.proofs / dt_mix, "unit": "proofs/s", "ms_per_proof": dt_mix / args.proofs * 1e3,
+                                       "coalescer": {"batches": int(co_mix[0]), "msm_instances": int(co_mix[1]), "largest_batch": int(co_mix[2]),
+                                                     "instances_per_batch": (co_mix[1] / co_mix[0]) if co_mix[0] else None},
+                                       "what": "a scope per proof for the transforms and passes (no wait per call, batched transforms); the commitment rounds are synchronous calls that meet "
+                                               "other callers' rounds in the coalescer"},
                                    "one_synchronous_call_per_step": {
                                        "value": args.proofs / dt_ser, "unit": "proofs/s", "ms_per_proof": dt_ser / args.proofs * 1e3,
                                        "coalescer": {"batches": int(co[0]), "msm_instances": int(co[1]), "largest_batch": int(co[2]), "single_instance_batches": int(co[3]),

@@ -226,10 +226,19 @@ struct xyzz_pair_t {
 #pragma unroll
             for (int l = 0; l < NL; l++) pz[l] = is_zero_mod_q(p[l]), rz[l] = is_zero_mod_q(r[l]);
             if (XP::both(pz)) {
-                if (XP::both(rz))
-                    mdbl(px, ny);
-                else
+                if (XP::both(rz)) {
+                    // out of line, on copies (an accumulator whose address escapes would live in scratch for the whole loop): the
+                    // doubling's eleven temporaries stay out of the register allocation of the loop body
+                    xyzz_pair_t tmp;
+                    fql_t cx[XP::NL], cy[XP::NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) cx[l] = px[l], cy[l] = ny[l];
+                    mdbl_ool(&tmp, cx, cy);
+#pragma unroll
+                    for (int l = 0; l < NL; l++) x[l] = tmp.x[l], y[l] = tmp.y[l], zz[l] = tmp.zz[l], zzz[l] = tmp.zzz[l];
+                } else {
                     inf = true;
+                }
                 return;
             }
         }
@@ -268,6 +277,12 @@ struct xyzz_pair_t {
             y[l] = fq2l::sub_norm(a[l], b[l], -1);  // + q if negative -> [0, 1 + 2 e]
             x[l] = x3[l];
         }
+    }
+    static __host__ __device__ __noinline__ void mdbl_ool(xyzz_pair_t* out, const fql_t* px, const fql_t* ny) {
+        fql_t cx[XP::NL], cy[XP::NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) cx[l] = px[l], cy[l] = ny[l];
+        out->mdbl(cx, cy);
     }
     // this = 2 (px, ny): mdbl-2008-s-1 (ec.hip.h dbl_affine).  U = 2 y enters as 2 y - q: tight.
     SV_HD void mdbl(const fql_t (&px)[XP::NL], const fql_t (&ny)[XP::NL]) {

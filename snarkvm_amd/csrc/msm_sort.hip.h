@@ -1085,14 +1085,11 @@ __global__ void __launch_bounds__(256, 2) msm_accumulate_pair2_kernel(const aff_
     const uint32_t hi = (total - lo < S) ? total : lo + S;
     uint32_t k = find_bucket(boff, nbt, lo);
     uint32_t kend = boff[k + 1];
-    uint32_t kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];  // bucket bookkeeping one bucket ahead (see msm_accumulate_lazy_kernel)
-    uint32_t start_k = start[k];
+    uint32_t start_k = start[k];  // (no look-ahead of the bucket bookkeeping here: two resident waves hide the loads, and the registers are needed)
     uint32_t part_off = t - boff[k] / S;
     fq2p::xyzz_pair_t<fq2p::xp_dev> acc;
     acc.inf = true;
     auto slot_of = [&](uint32_t e) -> const g2_lazy_slot_t* { return (const g2_lazy_slot_t*)&bases[(e & 0x7fffffffu) & debug_idx_mask]; };
-    uint32_t e_cur = sorted[lo];
-    uint32_t e_n1 = lo + 1 < hi ? sorted[lo + 1] : 0u;
     for (uint32_t pos = lo;; pos++) {
         const bool end = pos >= hi;
         if (end || pos >= kend) {
@@ -1116,19 +1113,14 @@ __global__ void __launch_bounds__(256, 2) msm_accumulate_pair2_kernel(const aff_
             if (end) break;
             part_off = 0;
             acc.inf = true;
-            k++;
-            kend = kend2;
-            while (pos >= kend) {
+            do {
                 k++;
                 kend = boff[k + 1];
-            }
-            kend2 = boff[k + 2 <= nbt ? k + 2 : nbt];
+            } while (pos >= kend);
             start_k = start[k];
         }
-        const uint32_t e = e_cur;
+        const uint32_t e = sorted[pos];
         const g2_lazy_slot_t* sp = slot_of(e);
-        e_cur = e_n1;
-        if (pos + 2 < hi) e_n1 = sorted[pos + 2];
         if (sp->w[g2_lazy_slot_t::INF_WORD]) continue;  // the point at infinity (both lanes read the same word)
         fql_t px[1], py[1];
         sp->component(comp, px[0], py[0]);

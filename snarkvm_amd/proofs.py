@@ -395,13 +395,17 @@ class LockstepWorkspace:
             self.work = [torch.empty((count, keys.shape.nmax * 4), dtype=torch.int64, device=self.device) for _ in range(4)]
             torch.cuda.synchronize()
         self.rem = np.zeros((3, count, 4), dtype=np.uint64)
-        self.times = {"msm": 0.0, "ntt": 0.0, "poly": 0.0, "g2": 0.0, "load": 0.0}
+        self.times = {"msm": 0.0, "ntt": 0.0, "poly": 0.0, "g2": 0.0, "load": 0.0, "wait": 0.0}
 
 
-def replay_lockstep(ws, salts, collect=False):
+def replay_lockstep(ws, salts, collect=False, async_scope=True):
     """The hot-path calls of len(salts) <= ws.count proofs, issued step by step for all proofs together (same calls, sizes and
     operands as `replay` per proof: results are the same group elements).  Returns per proof the list of its 14 commitments (+ the
-    G2 result) when collect is set."""
+    G2 result) when collect is set.
+    async_scope (round 5): the whole group is ONE SNARKVM_HIP_SCOPE_ASYNC_MSM scope - the operand copies go onto the scope's stream, a
+    round's fused MSM call is only enqueued (on one of the scope's further streams; the work matrices are reused by the next steps, which
+    wait on the GPU until the MSM has read them) and finished by scope_end, the G2 batch runs underneath.  False: round 4's form (a scope
+    per step, synchronous commitment calls)."""
     import torch
 
     L = _lib.lib()
@@ -421,12 +425,20 @@ def replay_lockstep(ws, salts, collect=False):
     def vec(v, p):
         return ws.work[v].data_ptr() + p * stride
 
-    class scope:  # device-resident calls between loads: enqueued on one stream, one wait at the end
+    stream = None
+    deferred = []  # (proof-major outputs array, instances per proof) of the commitment calls, read after scope_end
+    if async_scope:
+        _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(pool.data_ptr()), 1))
+        stream = torch.cuda.ExternalStream(L.snarkvm_hip_scope_stream(), device=ws.device)
+
+    class scope:  # device-resident calls between loads: enqueued on one stream, one wait at the end (async_scope: the group's one scope is open already)
         def __enter__(self):
-            _lib.check(L.snarkvm_hip_scope_begin(ctypes.c_void_p(pool.data_ptr())))
+            if not async_scope:
+                _lib.check(L.snarkvm_hip_scope_begin(ctypes.c_void_p(pool.data_ptr())))
 
         def __exit__(self, *exc):
-            _lib.check(L.snarkvm_hip_scope_end())
+            if not async_scope:
+                _lib.check(L.snarkvm_hip_scope_end())
             return False
 
     def timed(kind, fn):
@@ -437,7 +449,7 @@ def replay_lockstep(ws, salts, collect=False):
     def load(v, n, shift):  # a fresh "polynomial" of n coefficients per proof (device copies on torch's stream: not part of the hot path)
         t0 = time.perf_counter()
         w = ws.work[v]
-        with torch.cuda.device(ws.device):
+        with torch.cuda.device(ws.device), torch.cuda.stream(stream):
             if arithmetic:
                 w[:P, : 4 * n].copy_(pool.as_strided((P, 4 * n), (4 * step, 1), 4 * (shift + salts[0])))
             else:
@@ -446,7 +458,8 @@ def replay_lockstep(ws, salts, collect=False):
                     w[p, : 4 * n].copy_(pool[s0 : s0 + 4 * n])
             if w.shape[1] > 4 * n:
                 w[:P, 4 * n :].zero_()
-            torch.cuda.current_stream().synchronize()
+            if not async_scope:
+                torch.cuda.current_stream().synchronize()
         t["load"] += time.perf_counter() - t0
 
     def ntt_all(vs, lg, direction, kind=0):  # the same transform of vectors `vs` of every proof: one call, one launch per pass per 48 vectors
@@ -478,9 +491,7 @@ def replay_lockstep(ws, salts, collect=False):
         n1 = (ctypes.c_size_t * k)(*[h for _ in range(P) for _, _, h in polys])
         outs = np.zeros(k, dtype=G1_PROJECTIVE)
         timed("msm", lambda: _lib.check(L.snarkvm_hip_msm_registered_batch_ex(ctypes.c_void_p(outs.ctypes.data), keys.h, k, off0, n0, off1, n1, ptrs, 1, 1, 0)))
-        if collect:
-            for p in range(P):
-                results[p].extend(outs[p * m + j : p * m + j + 1].tobytes() for j in range(m))
+        deferred.append((outs, m))  # (asynchronous scope: written by scope_end)
 
     def work_ptr(v):
         return lambda p: vec(v, p)
@@ -493,9 +504,10 @@ def replay_lockstep(ws, salts, collect=False):
         load(v, nR, 10 + i)
     with scope():
         ntt_all((A, B, C), sh.lg_r, 1)
-    with torch.cuda.device(ws.device):
+    with torch.cuda.device(ws.device), torch.cuda.stream(stream):
         ws.work[D][:P].copy_(ws.work[C][:P])
-        torch.cuda.current_stream().synchronize()
+        if not async_scope:
+            torch.cuda.current_stream().synchronize()
     with scope():
         product(A, B, sh.lg_r + 1)
         timed("poly", lambda: _lib.check(L.snarkvm_hip_fr_vec_op_strided(1, vp(A), vp(A), vp(D), None, None, ctypes.c_size_t(2 * nR), ctypes.c_size_t(P), estride)))
@@ -538,7 +550,15 @@ def replay_lockstep(ws, salts, collect=False):
         ns = (ctypes.c_size_t * P)(*([n2] * P))
         outs2 = np.zeros(P, dtype=G2_PROJECTIVE)
         timed("g2", lambda: _lib.check(L.snarkvm_hip_msm_g2_registered_batch(ctypes.c_void_p(outs2.ctypes.data), keys.hg2, P, offs, ns, ptrs, 1, 0)))
-        if collect:
+    else:
+        outs2 = None
+    if async_scope:
+        timed("wait", lambda: _lib.check(L.snarkvm_hip_scope_end()))
+    if collect:
+        for outs, m in deferred:
+            for p in range(P):
+                results[p].extend(outs[p * m + j : p * m + j + 1].tobytes() for j in range(m))
+        if outs2 is not None:
             for p in range(P):
                 results[p].append(outs2[p : p + 1].tobytes())
     return results
@@ -547,10 +567,11 @@ def replay_lockstep(ws, salts, collect=False):
 class LockstepBatch:
     """`count` proofs in groups of `group` replayed in lock step by one thread per device (see the module docstring)."""
 
-    def __init__(self, keys, group=16, devices=None):
+    def __init__(self, keys, group=16, devices=None, async_scope=True):
         import torch
 
         self.keys = keys
+        self.async_scope = async_scope
         ndev = torch.cuda.device_count()
         devices = list(range(ndev)) if devices is None else list(devices)
         self.group = group
@@ -563,7 +584,13 @@ class LockstepBatch:
         results = [None] * len(chunks)
 
         def one(ci):
-            results[ci] = replay_lockstep(self.workspaces[ci % nws], chunks[ci], collect)
+            try:
+                results[ci] = replay_lockstep(self.workspaces[ci % nws], chunks[ci], collect, self.async_scope)
+            except BaseException:
+                err = _lib.lib().snarkvm_hip_scope_end()  # a failed call must not leave this thread's scope open
+                if err.message:
+                    _lib._libc.free(err.message)
+                raise
 
         t0 = time.perf_counter()
         if nws == 1:
@@ -583,13 +610,14 @@ class ProofBatch:
     """`count` proofs replayed by `workers` concurrent caller threads (BASELINE.json configs[4]: 64 proofs; one process per GPU
     takes its share, or one process drives every device the backend uses)."""
 
-    def __init__(self, keys, workers=4, devices=None, scope=False):
+    def __init__(self, keys, workers=4, devices=None, scope=False, async_msm=True):
         """scope=True: every worker issues its proof inside ONE asynchronous scope (`replay_single`: nothing waits for the GPU until the
         proof's results are due, a round's independent transforms are one batched call); False: one synchronous call per step (`replay`)."""
         import torch
 
         self.keys = keys
         self.scope = scope
+        self.async_msm = async_msm  # scope mode only; False: the commitment rounds are synchronous calls (and meet other callers' in the coalescer)
         ndev = torch.cuda.device_count()
         devices = list(range(ndev)) if devices is None else list(devices)
         cls = SingleProofWorkspace if scope else ProofWorkspace
@@ -606,7 +634,10 @@ class ProofBatch:
                 ws = self._free.pop()
             try:
                 got = [] if collect else None
-                (replay_single if self.scope else replay)(ws, salts[i], got)
+                if self.scope:
+                    replay_single(ws, salts[i], got, self.async_msm)
+                else:
+                    replay(ws, salts[i], got)
                 results[i] = got
             finally:
                 with self._lock:
