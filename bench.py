@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--proof-workers", type=int, default=8, help="concurrent caller threads per rank (proofs64, callers mode)")
     ap.add_argument("--proof-geometry", default="17x15", help="base tables x window bits of the proofs' registered SRS (proofs64)")
     ap.add_argument("--proof-group", type=int, default=32, help="proofs replayed in lock step per group (proofs64, lockstep mode)")
-    ap.add_argument("--lockstep-sync", action="store_true", help="proofs64: round 4's lock-step form (a scope per step, synchronous commitment calls)")
+    ap.add_argument("--lockstep-async", action="store_true", help="proofs64: the whole lock-step group in ONE asynchronous scope (measured slower: 191 vs 203 proofs/s)")
     ap.add_argument("--proof1-sync-msm", action="store_true", help="proof1: synchronous commitments (the A/B of SNARKVM_HIP_SCOPE_ASYNC_MSM)")
     ap.add_argument("--no-proof-legs", action="store_true", help="default workload: skip the proof1 / proofs64 / concurrent_callers legs")
     args = ap.parse_args()
@@ -840,8 +840,8 @@ def proof_legs(dev_index, with_oracle):
     leg = dict(proof1_summary(dt, lat, times, grown, P), value=P / dt, unit="proofs/s",
                what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof (bench.py --workload proof1)")
     out["proof1"] = leg
-    # ---- proofs64 shape, 32 proofs in lock step: one asynchronous scope per group (`value`), then round 4's form (a scope per step, synchronous
-    # commitment calls), whose call times give the pair rates inside the fused MSM calls
+    # ---- proofs64 shape, 32 proofs in lock step (a scope per step, every commitment round one synchronous fused call), and the same group inside
+    # ONE asynchronous scope (measured slower: the fused groups fill the chip by themselves)
     def lockstep(async_scope):
         lock = proofs.LockstepBatch(keys, group=P, devices=[dev_index], async_scope=async_scope)
         lock.run(salts)
@@ -857,25 +857,19 @@ def proof_legs(dev_index, with_oracle):
         torch.cuda.empty_cache()
         return dt, got, times
 
-    dt_lock, got_lock, t_async = lockstep(True)
-    dt_lock_sync, got_lock_sync, t_lock = lockstep(False)
-    if [proofs.normalize_results(r) for r in got_lock] != [proofs.normalize_results(r) for r in got_lock_sync]:
-        raise SystemExit("bench.py: proof legs: the two lock-step forms differ")
+    dt_lock, got_lock, t_lock = lockstep(False)
+    dt_lock_async, got_lock_async, _ = lockstep(True)
     norm1 = [proofs.normalize_results(r) for r in got1]
     norm_lock = [proofs.normalize_results(r) for r in got_lock]
-    if norm1 != norm_lock:
-        raise SystemExit("bench.py: proof legs: the one-at-a-time replay and the lock-step replay differ")
+    if norm1 != norm_lock or norm_lock != [proofs.normalize_results(r) for r in got_lock_async]:
+        raise SystemExit("bench.py: proof legs: the one-at-a-time replay and the lock-step replays differ")
     out["proofs64"] = {"value": P / dt_lock, "unit": "proofs/s", "proofs": P, "ms_per_proof": dt_lock / P * 1e3,
-                       "g1_pairs_per_s": P * shape.pairs() / dt_lock, "g2_pairs_per_s": P * (1 << shape.lg_g2) / dt_lock,
-                       "host_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_async.items()},
-                       "synchronous_commitment_calls": {
-                           "value": P / dt_lock_sync, "unit": "proofs/s", "ms_per_proof": dt_lock_sync / P * 1e3,
-                           "g1_pairs_per_s_inside_msm_calls": P * shape.pairs() / t_lock["msm"] if t_lock.get("msm") else None,
-                           "g2_pairs_per_s_inside_msm_calls": P * (1 << shape.lg_g2) / t_lock["g2"] if t_lock.get("g2") else None,
-                           "call_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_lock.items()},
-                           "what": "round 4's lock-step form: a scope per step, every commitment round a synchronous fused call"},
-                       "what": "BASELINE.json configs[4] on one GPU with 32 proofs in lock step (bench.py --workload proofs64 runs 64, and the concurrent-caller mode)",
-                       "checks": {"lockstep_vs_proof1": f"all {P} proofs x 15 results identical in both replays"}}
+                       "g1_pairs_per_s_inside_msm_calls": P * shape.pairs() / t_lock["msm"] if t_lock.get("msm") else None,
+                       "g2_pairs_per_s_inside_msm_calls": P * (1 << shape.lg_g2) / t_lock["g2"] if t_lock.get("g2") else None,
+                       "call_time_ms_per_proof": {k: v / P * 1e3 for k, v in t_lock.items()},
+                       "one_asynchronous_scope_per_group": {"value": P / dt_lock_async, "unit": "proofs/s", "ms_per_proof": dt_lock_async / P * 1e3},
+                       "what": "BASELINE.json configs[4] on one GPU with 32 proofs in lock step (bench.py --workload proofs64 runs 64, and the concurrent-caller modes)",
+                       "checks": {"lockstep_vs_proof1": f"all {P} proofs x 15 results identical in the lock-step replays and the one-at-a-time replay"}}
     leg["checks"] = {"proof1_vs_lockstep": f"all {P} proofs x 15 results identical in both replays"}
     # ---- checks (outside the timed regions)
     if with_oracle:
@@ -964,7 +958,7 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
     mine = list(range(rank, args.proofs, world))
     checks = {}
     # ---- lock step
-    lock = proofs.LockstepBatch(keys, group=min(args.proof_group, max(1, len(mine))), devices=[dev_index], async_scope=not args.lockstep_sync)
+    lock = proofs.LockstepBatch(keys, group=min(args.proof_group, max(1, len(mine))), devices=[dev_index], async_scope=args.lockstep_async)
     lock.run(mine[: lock.group])  # warm-up: allocations, twiddle tables
     for ws in lock.workspaces:
         ws.times = {k: 0.0 for k in ws.times}
@@ -1002,8 +996,10 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
         torch.cuda.empty_cache()
         return dt, got, co, times, n_ws
 
-    dt_thr, got_thr, _, t_scope, n_workers = callers(True)
-    dt_mix, got_mix, co_mix, _, _ = callers(True, async_msm=False)  # (c) a scope per proof for the transforms and passes, synchronous commitment rounds that meet in the coalescer
+    # (a) a scope per proof for the transforms and passes + synchronous commitment rounds that meet other callers' rounds in the coalescer (the
+    # fastest: `concurrent_callers.value`); (b) everything of a proof in one asynchronous scope; (c) round 4's mode, one synchronous call per step
+    dt_thr, got_thr, co_mix, t_scope, n_workers = callers(True, async_msm=False)
+    dt_mix, got_mix, _, _, _ = callers(True, async_msm=True)
     dt_ser, got_ser, co, t_thr, _ = callers(False)
     # ---- checks (outside the timed regions)
     norm_lock = [proofs.normalize_results(r) for r in got_lock]
@@ -1055,25 +1051,25 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
                                    "device-resident random data, transfer_private domain sizes; lock-step batch (prove_batch shape)",
                        "proofs": args.proofs, "lockstep_group": min(args.proof_group, max(1, len(mine))), "proofs_per_rank": len(mine),
                        "registered_srs": f"{ptab} tables x {pbits}-bit windows",
-                       "lockstep_form": "a scope per step, synchronous commitment calls" if args.lockstep_sync else "one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per group"},
+                       "lockstep_form": "one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per group" if args.lockstep_async else "a scope per step, synchronous commitment calls"},
             "g1_pairs_per_s": args.proofs * shape.pairs() / dt_lock,
             "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt_lock,
             "rank0_call_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_lock.items()},
             # the fused G1 rate on the proof mix: pairs of this rank / wall time spent inside its snarkvm_hip_msm_registered_batch_ex calls
-            # (only with --lockstep-sync: an asynchronous scope's calls return at once)
-            "g1_pairs_per_s_inside_msm_calls": (len(mine) * shape.pairs() / t_lock["msm"]) if (t_lock.get("msm") and args.lockstep_sync) else None,
-            "g2_pairs_per_s_inside_msm_calls": (len(mine) * (1 << shape.lg_g2) / t_lock["g2"]) if (t_lock.get("g2") and args.lockstep_sync) else None,
+            # (not with --lockstep-async: an asynchronous scope's calls return at once)
+            "g1_pairs_per_s_inside_msm_calls": (len(mine) * shape.pairs() / t_lock["msm"]) if (t_lock.get("msm") and not args.lockstep_async) else None,
+            "g2_pairs_per_s_inside_msm_calls": (len(mine) * (1 << shape.lg_g2) / t_lock["g2"]) if (t_lock.get("g2") and not args.lockstep_async) else None,
             "concurrent_callers": {"value": args.proofs / dt_thr, "unit": "proofs/s", "ms_per_proof": dt_thr / args.proofs * 1e3,
                                    "caller_threads_per_rank": n_workers, "g1_pairs_per_s": args.proofs * shape.pairs() / dt_thr,
+                                   "coalescer": {"batches": int(co_mix[0]), "msm_instances": int(co_mix[1]), "largest_batch": int(co_mix[2]), "single_instance_batches": int(co_mix[3]),
+                                                 "instances_per_batch": (co_mix[1] / co_mix[0]) if co_mix[0] else None},
                                    "rank0_host_time_ms_per_proof": {k: v / max(1, len(mine)) * 1e3 for k, v in t_scope.items()},
-                                   "what": "one proof per caller thread at a time (the reference's rayon fan-out), every proof issued inside one asynchronous scope "
-                                           "(SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS: snarkvm_amd/proofs.py::replay_single)",
-                                   "scope_with_synchronous_commitments": {
+                                   "what": "one proof per caller thread at a time (the reference's rayon fan-out): a deferred-synchronisation scope per proof for the transforms and "
+                                           "passes (no wait per call, a round's independent transforms batched), the commitment rounds as synchronous calls that meet other callers' "
+                                           "rounds in the in-library coalescer (snarkvm_amd/proofs.py::replay_single, async_msm=False)",
+                                   "one_asynchronous_scope_per_proof": {
                                        "value": args.proofs / dt_mix, "unit": "proofs/s", "ms_per_proof": dt_mix / args.proofs * 1e3,
-                                       "coalescer": {"batches": int(co_mix[0]), "msm_instances": int(co_mix[1]), "largest_batch": int(co_mix[2]),
-                                                     "instances_per_batch": (co_mix[1] / co_mix[0]) if co_mix[0] else None},
-                                       "what": "a scope per proof for the transforms and passes (no wait per call, batched transforms); the commitment rounds are synchronous calls that meet "
-                                               "other callers' rounds in the coalescer"},
+                                       "what": "SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS per proof (the single-caller latency path, bench.py --workload proof1): nothing is fused across callers"},
                                    "one_synchronous_call_per_step": {
                                        "value": args.proofs / dt_ser, "unit": "proofs/s", "ms_per_proof": dt_ser / args.proofs * 1e3,
                                        "coalescer": {"batches": int(co[0]), "msm_instances": int(co[1]), "largest_batch": int(co[2]), "single_instance_batches": int(co[3]),

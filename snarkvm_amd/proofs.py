@@ -398,14 +398,15 @@ class LockstepWorkspace:
         self.times = {"msm": 0.0, "ntt": 0.0, "poly": 0.0, "g2": 0.0, "load": 0.0, "wait": 0.0}
 
 
-def replay_lockstep(ws, salts, collect=False, async_scope=True):
+def replay_lockstep(ws, salts, collect=False, async_scope=False):
     """The hot-path calls of len(salts) <= ws.count proofs, issued step by step for all proofs together (same calls, sizes and
     operands as `replay` per proof: results are the same group elements).  Returns per proof the list of its 14 commitments (+ the
     G2 result) when collect is set.
-    async_scope (round 5): the whole group is ONE SNARKVM_HIP_SCOPE_ASYNC_MSM scope - the operand copies go onto the scope's stream, a
-    round's fused MSM call is only enqueued (on one of the scope's further streams; the work matrices are reused by the next steps, which
-    wait on the GPU until the MSM has read them) and finished by scope_end, the G2 batch runs underneath.  False: round 4's form (a scope
-    per step, synchronous commitment calls)."""
+    async_scope=True (round 5, measured and NOT the default): the whole group is ONE SNARKVM_HIP_SCOPE_ASYNC_MSM scope - the operand copies go
+    onto the scope's stream, a round's fused MSM call is only enqueued (on one of the scope's further streams; the work matrices are reused
+    by the next steps, which wait on the GPU until the MSM has read them) and finished by scope_end, the G2 batch runs underneath.  The
+    fused groups of 32 - 128 instances fill the chip by themselves, so running them beside each other buys nothing and the extra streams
+    cost: 191 proofs/s against 203 for the default form (a scope per step, synchronous commitment calls; profiles/r05_proofs64.md)."""
     import torch
 
     L = _lib.lib()
@@ -567,7 +568,7 @@ def replay_lockstep(ws, salts, collect=False, async_scope=True):
 class LockstepBatch:
     """`count` proofs in groups of `group` replayed in lock step by one thread per device (see the module docstring)."""
 
-    def __init__(self, keys, group=16, devices=None, async_scope=True):
+    def __init__(self, keys, group=16, devices=None, async_scope=False):
         import torch
 
         self.keys = keys

@@ -7,6 +7,7 @@
 //          -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib
 //   run:   /tmp/bench_proof_callers [g2 points file (200 B each, 2^16 of them) or -] [--scope] [threads ...]
 //          --scope: every caller issues its proof inside ONE asynchronous scope (replay_scope below) instead of one synchronous call per step
+//          --scope-sync: the same scope without SNARKVM_HIP_SCOPE_ASYNC_MSM: the commitment rounds are synchronous calls that meet in the coalescer
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
@@ -127,10 +128,11 @@ static void replay(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14)
 // SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS - no call waits for the GPU, the operand copies go onto the scope's own stream, the
 // independent transforms of a round are one batched call, the commitment rounds run on further streams and are finished by scope_end.
 // w.rows: 28 vectors of NMAX elements (every committed vector keeps its row until the proof is done).
+static uint32_t g_scope_flags = SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS;  // --scope-sync: 0 (synchronous, coalesced commitment rounds)
 static void replay_scope(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14) {
     size_t nout = 0;
     auto row = [&](int r) { return w.rows + (size_t)r * NMAX * 32; };
-    RK(snarkvm_hip_scope_begin_ex(K.pool, SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS));
+    RK(snarkvm_hip_scope_begin_ex(K.pool, g_scope_flags));
     hipStream_t st = (hipStream_t)snarkvm_hip_scope_stream();
     auto load = [&](int r, size_t n, size_t shift, int count = 1, size_t zero_to = 0) {
         for (int i = 0; i < count; i++) {
@@ -197,6 +199,8 @@ int main(int argc, char** argv) {
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--scope"))
             scope_mode = true;  // callers issue every proof inside one asynchronous scope (replay_scope)
+        else if (!strcmp(argv[i], "--scope-sync"))
+            scope_mode = true, g_scope_flags = 0;  // a scope per proof for the transforms and passes; the commitment rounds are synchronous calls (coalescer)
         else
             thread_counts.push_back(atoi(argv[i]));
     }
@@ -255,7 +259,9 @@ int main(int argc, char** argv) {
     }
     const double serial_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
     printf("one caller, %d proofs one after the other (including the normalisation of the reference results): %.2f ms per proof\n\n", nproofs, serial_ms / nproofs);
-    printf("callers: %s\n\n", scope_mode ? "one SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS scope per proof (replay_scope)" : "one synchronous call per step (replay)");
+    printf("callers: %s\n\n", !scope_mode ? "one synchronous call per step (replay)"
+                                   : g_scope_flags ? "one SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS scope per proof (replay_scope)"
+                                                   : "a scope per proof for the transforms and passes, synchronous commitment rounds through the coalescer (replay_scope, --scope-sync)");
     printf("| caller threads | proofs | wall ms | proofs/s | ms per proof | coalescer: batches | instances per batch | largest | results |\n|---|---|---|---|---|---|---|---|---|\n");
     for (int T : thread_counts) {
         if (T > max_threads) T = max_threads;
