@@ -77,6 +77,7 @@ inline Projective msm(const Affine* points, size_t npoints_available, const Scal
 class Scope {
 public:
     // flags: 0, or SNARKVM_HIP_SCOPE_ASYNC_MSM (registered-bases MSMs over device scalars are enqueued too; their outputs are written by end())
+    // [| SNARKVM_HIP_SCOPE_STABLE_INPUTS: the scalar vectors of those MSMs are not touched before end()]
     explicit Scope(const void* d_any = nullptr, uint32_t flags = 0) { check(snarkvm_hip_scope_begin_ex(d_any, flags)); }
     void* stream() const { return snarkvm_hip_scope_stream(); }  // the hipStream_t of the scope's calls
     Scope(const Scope&) = delete;

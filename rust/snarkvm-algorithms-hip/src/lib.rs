@@ -317,6 +317,9 @@ pub mod resident {
     /// `Scope::begin_with`: MSMs over registered bases with device-resident scalars are enqueued too; their outputs are written when the
     /// scope ends (include/snarkvm_hip.h: SNARKVM_HIP_SCOPE_ASYNC_MSM).  The output buffers must outlive the guard.
     pub const SCOPE_ASYNC_MSM: u32 = 1;
+    /// With `SCOPE_ASYNC_MSM`: the caller leaves the scalar vectors of its enqueued MSMs untouched until the guard is dropped; the scope's
+    /// stream then never waits for an MSM (SNARKVM_HIP_SCOPE_STABLE_INPUTS).
+    pub const SCOPE_STABLE_INPUTS: u32 = 2;
     impl Scope {
         pub fn begin(device_ptr: *const c_void) -> Result<Self, Error> {
             unsafe { sys::snarkvm_hip_scope_begin(device_ptr) }.into_result()?;

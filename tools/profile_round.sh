@@ -3,7 +3,7 @@
 # separate runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Run on the GPU box from the repo
 # root: bash tools/profile_round.sh <tag>; outputs go to gpurun_out/<tag>prof/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
