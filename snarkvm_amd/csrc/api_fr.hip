@@ -268,8 +268,10 @@ static void fr_suffix_horner(lane_t& c, const fr_mem_t* d_in, size_t n, const fr
     // `count` vectors in one launch sequence (blockIdx.y): inputs / outputs `in_stride` / `out_stride` elements apart, the chunk values
     // of vector y in its own slice of the scratch area, d_first[y] = h_0 of vector y
     hipStream_t st = c.stream;
-    if (d_out && n >= 2048 && tuning().horner2) {
-        // quotient wanted: the three-launch form with a scan inside every workgroup (poly.hip.h); C coefficients per thread keep <= 256 workgroups
+    if (d_out && n >= 2048 && n <= ((size_t)1 << 20) && tuning().horner2) {
+        // quotient wanted, a proof-sized polynomial: the three-launch form with a scan inside every workgroup (poly.hip.h); C coefficients per thread keep
+        // <= 256 workgroups.  (Beyond 2^20 coefficients a thread would fold 32+ of them serially on a quarter of the chip's lanes - round 3 measured that
+        // shape at 2^24: 1.69 vs 1.04 ms - and the chunk recursion below, 2^19 threads at its first level, is the better form.)
         uint32_t C = 8;
         while (((n + C - 1) / C + HORNER2_B - 1) / HORNER2_B > 256) C *= 2;
         const size_t nblocks = ((n + C - 1) / C + HORNER2_B - 1) / HORNER2_B;

@@ -71,6 +71,7 @@ timeout 100 python tools/phase_ffi.py > $O/phase_ffi.md 2> $O/phase_ffi.err; cat
 timeout 150 python tools/bench_g2.py > $O/g2.md 2> $O/g2.err; cut -c1-75 $O/g2.md | tail -4
 SNARKVM_HIP_TUNING=pair2=0 timeout 150 python tools/bench_g2.py > $O/g2_pair0.md 2> $O/g2_pair0.err; cut -c1-75 $O/g2_pair0.md | tail -4
 timeout 120 tools/exp/mfma_reduction > $O/r05_mfma_reduction.txt 2>&1; cat $O/r05_mfma_reduction.txt
+timeout 200 python tools/tables1_cliff.py > $O/r05_tables1_cliff.md 2> $O/tables1_cliff.err; cat $O/r05_tables1_cliff.md
 g++ -std=c++17 -O2 -pthread -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bench_callers.cpp -o /tmp/bench_callers -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib && GPU_MAX_HW_QUEUES=8 timeout 120 /tmp/bench_callers 1 8 32 > $O/callers.md 2> $O/callers.err; cat $O/callers.md
 python - <<'PY'
 import sys

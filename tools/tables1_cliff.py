@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""The "tables1" cliff of round 4's driver run (93.6 ms per step against 37 ms in the builder's runs), taken apart.
+
+The leg: a 2^24 MSM over registered bases WITHOUT precomputed tables (16 digit rows per scalar) right after the headline leg, whose
+lanes hold workspaces sized for 12 digit rows.  Round 4 warmed ONE lane with a synchronous call and then timed a 2-instance batch:
+lane 1 had to outgrow a dozen buffers of 0.5 - 1 GB inside the timed region, behind lane 0's running MSM.  This script times that
+exact shape on the current library and reports what snarkvm_hip_alloc_stats saw in each call, then the shape the bench uses now (a
+warm-up batch of the same shape over every lane).  What is left of the cliff with deferred frees = the time inside hipMalloc;
+what is gone = hipFree waiting for every stream of the device (lane 0's whole MSM) before lane 1 could be enqueued."""
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from snarkvm_amd import _lib, synthetic  # noqa: E402
+from snarkvm_amd.layout import G1_AFFINE  # noqa: E402
+from snarkvm_amd.msm import RegisteredBases  # noqa: E402
+
+L = _lib.lib()
+torch.cuda.set_device(0)
+_lib.check(L.snarkvm_hip_set_device(0))
+n = 1 << 24
+bases = torch.empty(n * G1_AFFINE.itemsize, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+_lib.check(L.snarkvm_hip_g1_generate_bases_device(ctypes.c_void_p(bases.data_ptr()), ctypes.c_uint64(1), ctypes.c_size_t(n)))
+sc = torch.from_numpy(synthetic.random_fr_integers(n, 1).view(np.int64)).cuda()
+torch.cuda.synchronize()
+
+
+def stats(reset=False):
+    v = (ctypes.c_uint64 * 5)()
+    L.snarkvm_hip_alloc_stats(v, 1 if reset else 0)
+    return f"{v[0]} device allocations ({v[1] / 2**30:.2f} GiB), {v[4] / 1e3:.1f} ms inside them"
+
+
+def timed(label, fn):
+    _lib.check(L.snarkvm_hip_synchronize())
+    stats(reset=True)
+    t0 = time.perf_counter()
+    fn()
+    _lib.check(L.snarkvm_hip_synchronize())
+    dt = (time.perf_counter() - t0) * 1e3
+    print(f"| {label} | {dt:.1f} | {stats()} |")
+
+
+print("| call | wall ms | workspace growth inside the call |")
+print("|---|---|---|")
+rb = RegisteredBases(device_ptr=bases.data_ptr(), npoints=n, tables=12, window_bits=22)
+timed("headline geometry (12 x 22-bit tables), batch of 3: first use of three lanes", lambda: rb.msm_batch(device_ptrs=[sc.data_ptr()] * 3, npoints=[n] * 3))
+timed("the same batch again", lambda: rb.msm_batch(device_ptrs=[sc.data_ptr()] * 3, npoints=[n] * 3))
+rb1 = RegisteredBases(device_ptr=bases.data_ptr(), npoints=n, tables=1)
+timed("no tables (16 digit rows): ONE synchronous call = round 4's warm-up (lane 0 grows)", lambda: rb1.msm(device_ptr=sc.data_ptr(), npoints=n))
+timed("round 4's timed region: batch of 2 (lane 1 grows behind lane 0's running MSM)", lambda: rb1.msm_batch(device_ptrs=[sc.data_ptr()] * 2, npoints=[n] * 2))
+timed("the same batch again (what the bench times now, after a warm-up batch over every lane)", lambda: rb1.msm_batch(device_ptrs=[sc.data_ptr()] * 2, npoints=[n] * 2))
+timed("and again", lambda: rb1.msm_batch(device_ptrs=[sc.data_ptr()] * 2, npoints=[n] * 2))
