@@ -406,7 +406,7 @@ def replay_lockstep(ws, salts, collect=False, async_scope=False):
     onto the scope's stream, a round's fused MSM call is only enqueued (on one of the scope's further streams; the work matrices are reused
     by the next steps, which wait on the GPU until the MSM has read them) and finished by scope_end, the G2 batch runs underneath.  The
     fused groups of 32 - 128 instances fill the chip by themselves, so running them beside each other buys nothing and the extra streams
-    cost: 191 proofs/s against 203 for the default form (a scope per step, synchronous commitment calls; profiles/r05_proofs64.md)."""
+    cost: 188 - 191 proofs/s against 199 - 207 for the default form (a scope per step, synchronous commitment calls; profiles/r05_summary.md)."""
     import torch
 
     L = _lib.lib()

@@ -365,6 +365,8 @@ def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
     import torch
 
     L = _lib.lib()
+    if L.snarkvm_hip_num_devices() > 1:
+        pytest.skip("several logical devices: device-resident instances are dealt round-robin over them, a later batch may meet a lane for the first time")
     G = util.g1_generator_affine()
     n = 1 << 20
     d_bases = torch.empty(n * 104, dtype=torch.uint8, device="cuda")

@@ -58,3 +58,45 @@ timed("no tables (16 digit rows): ONE synchronous call = round 4's warm-up (lane
 timed("round 4's timed region: batch of 2 (lane 1 grows behind lane 0's running MSM)", lambda: rb1.msm_batch(device_ptrs=[sc.data_ptr()] * 2, npoints=[n] * 2))
 timed("the same batch again (what the bench times now, after a warm-up batch over every lane)", lambda: rb1.msm_batch(device_ptrs=[sc.data_ptr()] * 2, npoints=[n] * 2))
 timed("and again", lambda: rb1.msm_batch(device_ptrs=[sc.data_ptr()] * 2, npoints=[n] * 2))
+
+# ---- what round 4's dev_buf::ensure did inside the timed region: hipFree of an outgrown block (+ hipMalloc of its successor), measured directly
+hip = ctypes.CDLL("libamdhip64.so")
+
+
+def raw_alloc(n_bytes):
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n_bytes)) == 0
+    return p
+
+
+print("\n| six blocks of 768 MiB (what lane 1 outgrew) | ms |")
+print("|---|---|")
+blocks = [raw_alloc(768 << 20) for _ in range(6)]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for b in blocks:
+    assert hip.hipFree(b) == 0
+print(f"| hipFree x 6, device idle | {(time.perf_counter() - t0) * 1e3:.2f} |")
+blocks = [raw_alloc(768 << 20) for _ in range(6)]
+a = torch.randn(8192, 8192, device="cuda")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(40):
+    a = a @ a * 1e-4  # ~40 ms of queued kernels on torch's stream: the "other lane's running MSM"
+t_q = time.perf_counter() - t0
+t0 = time.perf_counter()
+assert hip.hipFree(blocks[0]) == 0
+t_first = time.perf_counter() - t0
+t0 = time.perf_counter()
+for b in blocks[1:]:
+    assert hip.hipFree(b) == 0
+t_rest = time.perf_counter() - t0
+torch.cuda.synchronize()
+print(f"| enqueue of ~40 ms of kernels on another stream | {t_q * 1e3:.2f} |")
+print(f"| first hipFree while those kernels run | {t_first * 1e3:.2f} |")
+print(f"| the other five hipFree | {t_rest * 1e3:.2f} |")
+t0 = time.perf_counter()
+blocks = [raw_alloc(1 << 30) for _ in range(6)]
+print(f"| hipMalloc x 6 of 1 GiB | {(time.perf_counter() - t0) * 1e3:.2f} |")
+for b in blocks:
+    hip.hipFree(b)
