@@ -376,10 +376,11 @@ def main():
         extra["registration_ms"] = registration_ms
         extra["table_bytes"] = table_bytes
         # -- the same MSM without precomputed tables (registered bases only: 16 windows of 16 bits, Horner chain on the host)
-        # (16 digit rows per scalar instead of 12: every lane the batch cycles through must GROW its workspace first.  Round 4 warmed one
-        # lane with a synchronous call and timed a 2-instance batch: lane 1 outgrew its buffers inside the timed region, behind lane 0's
-        # running MSM - 93.6 ms per step on the driver's box.  The warm-up now is a batch of the same shape over every lane, and the
-        # library no longer frees an outgrown buffer in the middle of a call; `tables1_workspace_growth` must read zero allocations.)
+        # (16 digit rows per scalar instead of 12: every lane the batch cycles through must GROW its workspace first.  Round 4 warmed one lane with a
+        # synchronous call and timed a 2-instance batch, i.e. lane 1 outgrew six buffers - hipFree + hipMalloc, 2.8 GiB - inside the timed region, behind
+        # lane 0's running MSM; the driver's round-4 run read 93.6 ms per step here, which round 5 could not reproduce, not even with round 4's library
+        # (profiles/r05_summary.md).  The warm-up now is a batch of the same shape over every lane, the library no longer frees an outgrown buffer in the
+        # middle of a call, and `tables1_workspace_growth` says whether anything grew inside the timed region: it must read zero allocations.)
         rb1 = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=1)
         k1 = 2
         lanes1 = max(k1, L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n)))
@@ -718,7 +719,7 @@ def alloc_stats(L, reset=False):
     return {"device_allocations": int(v[0]), "device_bytes": int(v[1]), "pinned_allocations": int(v[2]), "pinned_bytes": int(v[3]), "ms": v[4] / 1e3}
 
 
-def proof1_run(keys, dev_index, salts, warm=4, async_msm=True):
+def proof1_run(keys, dev_index, salts, warm=4, async_msm=True, await_rounds=False):
     """`salts`: the proofs, proved ONE AT A TIME by this thread (snarkvm_amd/proofs.py::replay_single).  Returns (seconds of the whole
     run, per-proof latencies, per-proof result lists, call-time split, workspace growth inside the timed region)."""
     from snarkvm_amd import _lib, proofs
@@ -726,7 +727,7 @@ def proof1_run(keys, dev_index, salts, warm=4, async_msm=True):
     L = _lib.lib()
     ws = proofs.SingleProofWorkspace(keys, dev_index)
     for sidx in salts[:warm]:
-        proofs.replay_single(ws, sidx, None, async_msm)
+        proofs.replay_single(ws, sidx, None, async_msm, None, await_rounds)
     ws.times = {k: 0.0 for k in ws.times}
     _lib.check(L.snarkvm_hip_synchronize())
     alloc_stats(L, reset=True)
@@ -735,7 +736,7 @@ def proof1_run(keys, dev_index, salts, warm=4, async_msm=True):
     for sidx in salts:
         got = []
         t0 = time.perf_counter()
-        proofs.replay_single(ws, sidx, got, async_msm)
+        proofs.replay_single(ws, sidx, got, async_msm, None, await_rounds)
         lat.append(time.perf_counter() - t0)
         results.append(got)
     dt = time.perf_counter() - t_begin
@@ -773,14 +774,18 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
     dt_job = max_over_ranks(dt_rank)
     rank_dts = gather_over_ranks(dt_rank)
     _, lat_b, got_b, times_b, _ = proof1_run(keys, dev_index, mine, async_msm=bool(args.proof1_sync_msm))
+    # the order a real prover is bound to: round k's commitments are awaited (snarkvm_hip_scope_collect) before round k + 1 is issued
+    _, lat_c, got_c, times_c, _ = proof1_run(keys, dev_index, mine, async_msm=True, await_rounds=True)
     # ---- checks (outside the timed regions)
     ref_ws = proofs.ProofWorkspace(keys, dev_index)
     for i, p in enumerate(mine):
         ref = []
         proofs.replay(ref_ws, p, ref)
-        if proofs.normalize_results(ref) != proofs.normalize_results(got[i]) or proofs.normalize_results(ref) != proofs.normalize_results(got_b[i]):
+        nref = proofs.normalize_results(ref)
+        if nref != proofs.normalize_results(got[i]) or nref != proofs.normalize_results(got_b[i]) or nref != proofs.normalize_results(got_c[i]):
             raise SystemExit(f"bench.py: proof {p}: the one-scope replay differs from the serial replay")
-    checks["every_proof_vs_serial_replay"] = f"all {len(mine)} timed proofs x 15 results (asynchronous and synchronous commitments) == one synchronous call per step"
+    checks["every_proof_vs_serial_replay"] = (f"all {len(mine)} timed proofs x 15 results (asynchronous commitments, commitments awaited round by round, synchronous commitments) "
+                                              f"== one synchronous call per step")
     if rank == 0 and not args.no_cpu_baseline:
         secs = [oracle_check_proof(keys, shape, got[mine.index(p)], p) for p in (mine[0], mine[-1])]
         checks["proofs_vs_oracle"] = (f"proofs {mine[0]} and {mine[-1]}: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py "
@@ -788,6 +793,7 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
     if rank == 0:
         a = proof1_summary(dt_rank, lat, times, grown, len(mine))
         b = proof1_summary(sum(lat_b), lat_b, times_b, None, len(mine))
+        c = proof1_summary(sum(lat_c), lat_c, times_c, None, len(mine))
         print(json.dumps({
             "metric": "Varuna-proof-shaped hot-path replays per second, ONE proof at a time from one caller thread (BASELINE.json configs[3])",
             "value": world * len(mine) / dt_job,
@@ -806,6 +812,9 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
                        "proofs_per_rank": len(mine), "registered_srs": f"{ptab} tables x {pbits}-bit windows",
                        "commitments": "synchronous" if args.proof1_sync_msm else "SNARKVM_HIP_SCOPE_ASYNC_MSM"},
             "latency": a,
+            # Fiat-Shamir order: the host has round k's commitments in hand before it issues round k + 1 (a real prover derives the next challenge from them;
+            # this replay takes its challenges as inputs, so `value` - everything enqueued at once - is the library's ceiling, this is what a prover gets)
+            "commitments_awaited_round_by_round": dict(c, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM + snarkvm_hip_scope_collect(out) after every commitment round"),
             "other_commitment_mode": dict(b, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM" if args.proof1_sync_msm else "synchronous"),
             "g1_pairs_per_s": world * len(mine) * shape.pairs() / dt_job,
             "rank_ms_per_proof": [d / len(mine) * 1e3 for d in rank_dts],
@@ -837,8 +846,14 @@ def proof_legs(dev_index, with_oracle):
     salts = list(range(P))
     # ---- proof1
     dt, lat, got1, times, grown = proof1_run(keys, dev_index, salts)
+    dt_aw, lat_aw, got_aw, _, _ = proof1_run(keys, dev_index, salts, await_rounds=True)
     leg = dict(proof1_summary(dt, lat, times, grown, P), value=P / dt, unit="proofs/s",
+               commitments_awaited_round_by_round={"ms_per_proof": dt_aw / P * 1e3, "value": P / dt_aw, "unit": "proofs/s",
+                                                   "what": "the same scope, but the host waits for every round's commitments (snarkvm_hip_scope_collect) before it issues the "
+                                                           "next round: the Fiat-Shamir order of a real prover"},
                what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof (bench.py --workload proof1)")
+    if [proofs.normalize_results(r) for r in got_aw] != [proofs.normalize_results(r) for r in got1]:
+        raise SystemExit("bench.py: proof legs: awaiting the commitments round by round changes a result")
     out["proof1"] = leg
     # ---- proofs64 shape, 32 proofs in lock step (a scope per step, every commitment round one synchronous fused call), and the same group inside
     # ONE asynchronous scope (measured slower: the fused groups fill the chip by themselves)

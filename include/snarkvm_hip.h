@@ -131,7 +131,13 @@ RustError snarkvm_hip_scope_end(void);
  * produces operands with its own kernels or copies (hipMemcpyAsync, torch.cuda.ExternalStream) orders them with the scope's calls by
  * using this stream. */
 enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1, SNARKVM_HIP_SCOPE_STABLE_INPUTS = 2 };
+/* snarkvm_hip_scope_collect(out): waits until the MSM call that was given `out` as its (first) output buffer is done and writes its outputs
+ * (out == NULL: every MSM this thread's scope has enqueued so far); the scope stays open, the work queued on its own stream is NOT waited for
+ * and the other enqueued MSMs stay pending.  What a prover needs between two rounds: the commitments of round k
+ * go into the Fiat-Shamir transcript before the challenge of round k + 1 exists (snark/varuna/varuna.rs:336 ff.), while transforms that do
+ * not depend on that challenge - and the tails of earlier MSMs, and an independent MSM - keep running. */
 RustError snarkvm_hip_scope_begin_ex(const void *d_any, uint32_t flags);
+RustError snarkvm_hip_scope_collect(const void *out);
 void *snarkvm_hip_scope_stream(void);
 
 /* Register a base vector once (SRS powers are static per proving key; the reference re-uploads

@@ -124,6 +124,7 @@ mod sys {
         pub fn snarkvm_hip_free_bases(handle: *mut c_void);
         pub fn snarkvm_hip_scope_begin(d_any: *const c_void) -> Error;
         pub fn snarkvm_hip_scope_begin_ex(d_any: *const c_void, flags: u32) -> Error;
+        pub fn snarkvm_hip_scope_collect(out: *const c_void) -> Error;
         pub fn snarkvm_hip_scope_end() -> Error;
         pub fn snarkvm_hip_scope_stream() -> *mut c_void;
         pub fn snarkvm_hip_alloc_stats(out: *mut u64, reset: i32);
@@ -328,6 +329,11 @@ pub mod resident {
         pub fn begin_with(device_ptr: *const c_void, flags: u32) -> Result<Self, Error> {
             unsafe { sys::snarkvm_hip_scope_begin_ex(device_ptr, flags) }.into_result()?;
             Ok(Scope(core::marker::PhantomData))
+        }
+        /// Waits for the MSM call that was given `out` as its first output (null: every MSM enqueued so far) and writes its outputs - a round's
+        /// commitments for the transcript; the scope stays open and the other enqueued MSMs stay pending.
+        pub fn collect(&self, out: *const c_void) -> Result<(), Error> {
+            unsafe { sys::snarkvm_hip_scope_collect(out) }.into_result()
         }
         /// The `hipStream_t` the scope's calls are enqueued on (for the caller's own copies / kernels that feed them).
         pub fn stream(&self) -> *mut c_void {

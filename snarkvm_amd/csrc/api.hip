@@ -160,6 +160,11 @@ void* snarkvm_hip_scope_stream(void) {
     lane_t* l = tl_scope().lane;
     return l ? (void*)l->stream : nullptr;
 }
+RustError snarkvm_hip_scope_collect(const void* out) {
+    API_TRY
+    scope_collect(out);
+    API_CATCH
+}
 RustError snarkvm_hip_scope_end(void) {
     thread_scope_t& sc = tl_scope();
     lane_t* l = sc.lane;

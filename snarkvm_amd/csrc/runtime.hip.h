@@ -77,10 +77,12 @@ static double host_now_ms() {
 // every stream): counted, so that a caller - or a test - can see that a timed region allocated nothing
 // (snarkvm_hip_alloc_stats: {device allocations, device bytes, pinned allocations, pinned bytes, microseconds inside them}).
 void sv_alloc_note(int slot, size_t bytes, double ms);  // api.hip: the process-wide counters (this header is compiled into four units)
-// A buffer that is outgrown in the middle of a call is not freed on the spot: hipFree waits for EVERY stream of the device, i.e. the
-// second instance of a pipelined batch would only be enqueued after the first one had finished (the "tables1" leg of round 4's bench:
-// 93.6 instead of 37 ms per step when lane 1 grew its workspace behind lane 0's running MSM).  The old block goes to a process-wide
-// list and is released by sv_drain_frees() when a call ends (lane_t::end_call, scope flush), or at once when an allocation fails.
+// A buffer that is outgrown in the middle of a call is not freed on the spot: hipFree returns only when EVERY stream of the device is
+// idle (measured: 281 ms behind ~280 ms of kernels queued on another stream, tools/tables1_cliff.py), i.e. the second instance of a
+// pipelined batch would only be enqueued after the first one had finished, and a caller on another lane would stall behind this one.
+// The old block goes to a process-wide list and is released by sv_drain_frees() when a call ends (lane_t::end_call, scope flush), or at
+// once when an allocation fails.  (Round 4's "tables1" bench leg had six such frees inside its timed region; whether they were what
+// the driver's 93.6 ms per step came from could not be reproduced - profiles/r05_summary.md.)
 void sv_defer_free(void* p);
 void sv_drain_frees();
 struct alloc_timer_t {
@@ -440,6 +442,7 @@ static constexpr int SCOPE_AUX_MAX = 7;  // one proof: six commitment rounds + t
 struct scope_pending_t {
     hipEvent_t done;               // everything the finish reads has arrived in pinned memory
     std::function<void()> finish;  // host Horner chains -> the callers' `out` buffers
+    const void* tag;               // the first `out` pointer of the call that enqueued it (snarkvm_hip_scope_collect(out))
 };
 struct thread_scope_t {
     lane_t* lane = nullptr;
@@ -480,6 +483,30 @@ static void scope_flush() {
     sc.lane->pin_used = 0;
     sc.lane->scope_events_used = 0;
     for (int i = 0; i < sc.naux; i++) sc.aux[i]->pin_used = 0, sc.aux[i]->scope_events_used = 0;
+    if (err) std::rethrow_exception(err);
+}
+// the outputs of the MSM call that was given `tag` as its (first) output - or, tag == nullptr, of every MSM the scope has enqueued so far
+// (snarkvm_hip_scope_collect): the scope stays open, its own stream is not waited for, the other pending MSMs stay pending
+static void scope_collect(const void* tag) {
+    thread_scope_t& sc = tl_scope();
+    if (!sc.lane) return;
+    std::exception_ptr err;
+    std::vector<scope_pending_t> keep;
+    for (scope_pending_t& p : sc.pending) {
+        if (tag && p.tag != tag) {
+            keep.push_back(std::move(p));
+            continue;
+        }
+        try {
+            HIP_TRY(hipEventSynchronize(p.done));
+            p.finish();
+        } catch (...) {
+            if (!err) err = std::current_exception();
+        }
+    }
+    sc.pending.swap(keep);
+    if (sc.pending.empty())  // every MSM lane is idle now (an MSM is the only work it gets): staging areas and events can be handed out again
+        for (int i = 0; i < sc.naux; i++) sc.aux[i]->pin_used = 0, sc.aux[i]->scope_events_used = 0;
     if (err) std::rethrow_exception(err);
 }
 struct lane_guard {
@@ -1911,7 +1938,7 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
         if (read) HIP_TRY(hipStreamWaitEvent(sc.lane->stream, read, 0));
         hipEvent_t done = c.scope_event();
         HIP_TRY(hipEventRecord(done, c.stream));
-        sc.pending.push_back(scope_pending_t{done, [rq, j, pd] { msm_finish_job<F>(rq->data(), j, pd, 4); }});
+        sc.pending.push_back(scope_pending_t{done, [rq, j, pd] { msm_finish_job<F>(rq->data(), j, pd, 4); }, req[0].out});
     }
     return true;
 }

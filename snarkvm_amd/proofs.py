@@ -253,7 +253,7 @@ def _clocks():
     return (time.clock_gettime_ns(time.CLOCK_MONOTONIC), time.clock_gettime_ns(time.CLOCK_MONOTONIC_RAW), time.clock_gettime_ns(time.CLOCK_BOOTTIME), time.time_ns())
 
 
-def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None):
+def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_rounds=False):
     """The hot-path calls of ONE proof from ONE caller thread, issued for latency (configs[3]; the reference proves one transaction at a
     time: synthesizer/snark/src/proving_key/mod.rs:37 -> VarunaSNARK::prove_batch, varuna.rs:336).  Same calls, sizes and operands as
     `replay` - the 15 results are the same group elements - but:
@@ -265,6 +265,10 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None):
         (third.rs:160-175, fourth.rs:174-190) - are ONE batched call per size instead of one call per vector;
       * the independent G2 MSM is issued first and runs underneath everything else.
     async_msm=False: the same call list with synchronous MSMs (the A/B of the overlap).
+    await_rounds=True (with async_msm): after every commitment round the host WAITS for that round's results (snarkvm_hip_scope_collect) before it
+    issues the next round - the order a real prover is bound to, because the commitments of round k enter the Fiat-Shamir transcript that yields
+    the challenge of round k + 1 (this replay takes its challenges as inputs, so nothing here needs them); the scope's stream, the earlier tails
+    and the G2 MSM keep running meanwhile.
     marks: a list that receives (label, clocks) after every step was issued (tools/proof1_timeline.py lines them up with a kernel trace)."""
     import torch
 
@@ -324,6 +328,8 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None):
             out = ctypes.c_void_p(ws.outs.ctypes.data + G1_PROJECTIVE.itemsize * slot[0])
             _lib.check(L.snarkvm_hip_msm_registered_batch_ex(out, keys.h, k, off0, n0, off1, n1, ptrs, 1, 1, 0))
             slot[0] += k
+            if await_rounds and async_msm:
+                _lib.check(L.snarkvm_hip_scope_collect(out))  # this round's commitments; the G2 MSM and nothing else is waited for
 
         if keys.hg2:                                                                         # G2 leg: independent of everything else
             _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, 1 << sh.lg_g2,

@@ -229,12 +229,13 @@ def test_single_proof_scope_replay_every_result_vs_oracle():
     ws = proofs.SingleProofWorkspace(keys)
     ref = proofs.ProofWorkspace(keys)
     for salt in (0, 5, 2):
-        got_async, got_sync, serial = [], [], []
+        got_async, got_sync, got_await, serial = [], [], [], []
         proofs.replay_single(ws, salt, got_async, async_msm=True)
         proofs.replay_single(ws, salt, got_sync, async_msm=False)
+        proofs.replay_single(ws, salt, got_await, async_msm=True, await_rounds=True)  # snarkvm_hip_scope_collect after every commitment round
         proofs.replay(ref, salt, serial)
         _check_against_oracle(keys, shape, salt, got_async)
-        assert proofs.normalize_results(got_async) == proofs.normalize_results(got_sync) == proofs.normalize_results(serial)
+        assert proofs.normalize_results(got_async) == proofs.normalize_results(got_sync) == proofs.normalize_results(got_await) == proofs.normalize_results(serial)
     keys.close()
 
 
@@ -397,3 +398,35 @@ def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
             assert util.affine_equal(oracle.g1_to_affine(r[k : k + 1]), want)
     rb12.close()
     rb1.close()
+
+
+def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
+    """snarkvm_hip_scope_collect(out): inside an asynchronous scope two MSM calls are enqueued; collecting the SECOND one writes its output and
+    leaves the first one's buffer untouched (its host finish has not run); collect(NULL) then delivers the rest, the scope is still open (a
+    further transform and MSM go through), scope_end delivers those.  Every result against the oracle."""
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    lg = 12
+    n = 1 << lg
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    xs = [synthetic.random_fr_integers(n, 9300 + i) for i in range(3)]
+    dev = [torch.from_numpy(x.view(np.int64).reshape(-1).copy()).cuda() for x in xs]
+    torch.cuda.synchronize()
+    outs = np.zeros(3, dtype=G1_PROJECTIVE)
+    o = [ctypes.c_void_p(outs[i : i + 1].ctypes.data) for i in range(3)]
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(dev[0].data_ptr()), 3))
+    _lib.check(L.snarkvm_hip_msm_registered(o[0], rb._h, 0, n, ctypes.c_void_p(dev[0].data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_msm_registered(o[1], rb._h, 0, n - 5, ctypes.c_void_p(dev[1].data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_scope_collect(o[1]))
+    assert outs[1:2].view(np.uint8).any() and not outs[0:1].view(np.uint8).any() and not outs[2:3].view(np.uint8).any()
+    _lib.check(L.snarkvm_hip_scope_collect(None))
+    assert outs[0:1].view(np.uint8).any()
+    _lib.check(L.snarkvm_hip_msm_registered(o[2], rb._h, 7, n - 7, ctypes.c_void_p(dev[2].data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_scope_end())
+    want = [oracle.g1_msm(bases, xs[0]), oracle.g1_msm(bases[: n - 5], xs[1][: n - 5]), oracle.g1_msm(bases[7:n], xs[2][: n - 7])]
+    for i in range(3):
+        assert util.affine_equal(oracle.g1_to_affine(outs[i : i + 1]), oracle.g1_to_affine(want[i])), i
+    rb.close()

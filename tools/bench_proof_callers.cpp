@@ -129,6 +129,7 @@ static void replay(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14)
 // independent transforms of a round are one batched call, the commitment rounds run on further streams and are finished by scope_end.
 // w.rows: 28 vectors of NMAX elements (every committed vector keeps its row until the proof is done).
 static uint32_t g_scope_flags = SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS;  // --scope-sync: 0 (synchronous, coalesced commitment rounds)
+static bool g_await_rounds = false;  // --scope-await: snarkvm_hip_scope_collect(out) after every commitment round (the Fiat-Shamir order of a real prover)
 static void replay_scope(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14) {
     size_t nout = 0;
     auto row = [&](int r) { return w.rows + (size_t)r * NMAX * 32; };
@@ -157,6 +158,7 @@ static void replay_scope(const keys_t& K, workspace_t& w, size_t salt, uint8_t* 
         std::vector<const void*> ptrs(k);
         for (size_t i = 0; i < k; i++) ptrs[i] = polys[i].p, n0[i] = polys[i].n, n1[i] = polys[i].hiding;
         RK(snarkvm_hip_msm_registered_batch_ex(out14 + 144 * nout, K.h, k, off0.data(), n0.data(), off1.data(), n1.data(), ptrs.data(), 1, 1, 0));
+        if (g_await_rounds && g_scope_flags) RK(snarkvm_hip_scope_collect(out14 + 144 * nout));
         nout += k;
     };
     if (K.hg2) RK(snarkvm_hip_msm_g2_registered(w.g2_out, K.hg2, 0, (size_t)1 << LG_G2, K.pool + 32 * (23 + salt), 1, 0));
@@ -199,6 +201,8 @@ int main(int argc, char** argv) {
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--scope"))
             scope_mode = true;  // callers issue every proof inside one asynchronous scope (replay_scope)
+        else if (!strcmp(argv[i], "--scope-await"))
+            scope_mode = true, g_await_rounds = true;  // asynchronous scope, but every round's commitments are awaited before the next round is issued
         else if (!strcmp(argv[i], "--scope-sync"))
             scope_mode = true, g_scope_flags = 0;  // a scope per proof for the transforms and passes; the commitment rounds are synchronous calls (coalescer)
         else
@@ -260,6 +264,7 @@ int main(int argc, char** argv) {
     const double serial_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
     printf("one caller, %d proofs one after the other (including the normalisation of the reference results): %.2f ms per proof\n\n", nproofs, serial_ms / nproofs);
     printf("callers: %s\n\n", !scope_mode ? "one synchronous call per step (replay)"
+                                   : g_await_rounds ? "one asynchronous scope per proof, every round's commitments awaited (snarkvm_hip_scope_collect) before the next round (replay_scope, --scope-await)"
                                    : g_scope_flags ? "one SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS scope per proof (replay_scope)"
                                                    : "a scope per proof for the transforms and passes, synchronous commitment rounds through the coalescer (replay_scope, --scope-sync)");
     printf("| caller threads | proofs | wall ms | proofs/s | ms per proof | coalescer: batches | instances per batch | largest | results |\n|---|---|---|---|---|---|---|---|---|\n");

@@ -25,7 +25,8 @@ python - <<'PY'
 import json
 try:
     d = json.load(open("gpurun_out/r05_final/r05_proof1.json"))
-    print("proof1", round(d["ms_per_step"], 3), "ms/proof", d["latency"], "| sync commitments:", round(d["other_commitment_mode"]["ms_per_proof"], 3), d["checks"])
+    print("proof1", round(d["ms_per_step"], 3), "ms/proof", d["latency"], "| awaited round by round:", round(d["commitments_awaited_round_by_round"]["ms_per_proof"], 3),
+          "| sync commitments:", round(d["other_commitment_mode"]["ms_per_proof"], 3), d["checks"])
     d = json.load(open("gpurun_out/r05_final/r05_proofs64.json"))
     c = d["concurrent_callers"]
     print("proofs64 lockstep", round(d["value"], 1), "proofs/s; callers", round(c["value"], 1), c["coalescer"], "| async scope", round(c["one_asynchronous_scope_per_proof"]["value"], 1),
@@ -44,15 +45,15 @@ from snarkvm_amd import _lib, proofs
 torch.cuda.set_device(0)
 _lib.check(_lib.lib().snarkvm_hip_set_device(0))
 keys = proofs.ProverKeys(proofs.ProofShape(lg_g2=0), tables=17, window_bits=15)
-for mode in (True, False):
+for label, mode, aw in (("asynchronous commitments", True, False), ("commitments awaited round by round (snarkvm_hip_scope_collect)", True, True), ("synchronous commitments", False, False)):
     ws = proofs.SingleProofWorkspace(keys)
     for s in range(4):
-        proofs.replay_single(ws, s, None, mode)
+        proofs.replay_single(ws, s, None, mode, None, aw)
     lat = []
     for s in range(32):
-        t0 = time.perf_counter(); proofs.replay_single(ws, s, None, mode); lat.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); proofs.replay_single(ws, s, None, mode, None, aw); lat.append(time.perf_counter() - t0)
     lat.sort()
-    print(f"one proof at a time, NO G2 MSM (14 G1 results), {'asynchronous' if mode else 'synchronous'} commitments: mean {sum(lat) / len(lat) * 1e3:.3f} ms, median {lat[16] * 1e3:.3f}, min {lat[0] * 1e3:.3f}")
+    print(f"one proof at a time, NO G2 MSM (14 G1 results), {label}: mean {sum(lat) / len(lat) * 1e3:.3f} ms, median {lat[16] * 1e3:.3f}, min {lat[0] * 1e3:.3f}")
 PY
 cat $O/r05_proof1_without_g2.txt
 for mode in async sync; do
@@ -80,9 +81,10 @@ from snarkvm_amd import synthetic
 open("/tmp/g2pts.bin", "wb").write(synthetic.g2_points(1 << 16).tobytes())
 PY
 g++ -std=c++17 -O2 -pthread -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bench_proof_callers.cpp -o /tmp/bench_proof_callers -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib && {
-  for mode in "" "--scope" "--scope-sync"; do
+  for mode in "" "--scope" "--scope-await" "--scope-sync"; do
     GPU_MAX_HW_QUEUES=8 timeout 200 /tmp/bench_proof_callers - $mode 1 8 16 > "$O/proof_callers_nog2$mode.md" 2> "$O/proof_callers_nog2$mode.err"; cat "$O/proof_callers_nog2$mode.md"
   done
   GPU_MAX_HW_QUEUES=8 timeout 200 /tmp/bench_proof_callers /tmp/g2pts.bin --scope-sync 1 8 16 > "$O/proof_callers_g2--scope-sync.md" 2>&1; cat "$O/proof_callers_g2--scope-sync.md"
 }
 ls $O
+bash tools/logical_devices.sh r05 > $O/logical_devices.log 2>&1; tail -8 $O/logical_devices.log; cp gpurun_out/r05_logical/*.log $O/ 2>/dev/null

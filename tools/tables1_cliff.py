@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""The "tables1" cliff of round 4's driver run (93.6 ms per step against 37 ms in the builder's runs), taken apart.
+"""The "tables1" leg of the bench (93.6 ms per step in the driver's round-4 run against 37 ms everywhere else; not reproduced in round 5, not even with
+round 4's library), taken apart.
 
 The leg: a 2^24 MSM over registered bases WITHOUT precomputed tables (16 digit rows per scalar) right after the headline leg, whose
 lanes hold workspaces sized for 12 digit rows.  Round 4 warmed ONE lane with a synchronous call and then timed a 2-instance batch:
-lane 1 had to outgrow a dozen buffers of 0.5 - 1 GB inside the timed region, behind lane 0's running MSM.  This script times that
-exact shape on the current library and reports what snarkvm_hip_alloc_stats saw in each call, then the shape the bench uses now (a
-warm-up batch of the same shape over every lane).  What is left of the cliff with deferred frees = the time inside hipMalloc;
-what is gone = hipFree waiting for every stream of the device (lane 0's whole MSM) before lane 1 could be enqueued."""
+lane 1 had to outgrow six buffers (2.8 GiB) inside the timed region, behind lane 0's running MSM.  This script times that exact shape on
+the current library and reports what snarkvm_hip_alloc_stats saw in each call, then the shape the bench uses now (a warm-up batch of the
+same shape over every lane), then hipFree / hipMalloc directly: a free issued while another stream runs kernels returns only when the
+device is idle - the one thing in that timed region that can stall a device, now deferred to the end of the call."""
 import ctypes
 import os
 import sys
