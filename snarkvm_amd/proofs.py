@@ -404,7 +404,7 @@ class LockstepWorkspace:
         self.times = {"msm": 0.0, "ntt": 0.0, "poly": 0.0, "g2": 0.0, "load": 0.0, "wait": 0.0}
 
 
-def replay_lockstep(ws, salts, collect=False, async_scope=False):
+def replay_lockstep(ws, salts, collect=False, async_scope=False, await_rounds=False):
     """The hot-path calls of len(salts) <= ws.count proofs, issued step by step for all proofs together (same calls, sizes and
     operands as `replay` per proof: results are the same group elements).  Returns per proof the list of its 14 commitments (+ the
     G2 result) when collect is set.
@@ -498,7 +498,9 @@ def replay_lockstep(ws, salts, collect=False, async_scope=False):
         n1 = (ctypes.c_size_t * k)(*[h for _ in range(P) for _, _, h in polys])
         outs = np.zeros(k, dtype=G1_PROJECTIVE)
         timed("msm", lambda: _lib.check(L.snarkvm_hip_msm_registered_batch_ex(ctypes.c_void_p(outs.ctypes.data), keys.h, k, off0, n0, off1, n1, ptrs, 1, 1, 0)))
-        deferred.append((outs, m))  # (asynchronous scope: written by scope_end)
+        if async_scope and await_rounds:  # this round's commitments now (the transcript order); the G2 batch and the scope's stream keep running
+            timed("msm", lambda: _lib.check(L.snarkvm_hip_scope_collect(ctypes.c_void_p(outs.ctypes.data))))
+        deferred.append((outs, m))  # (asynchronous scope: written by scope_end / scope_collect)
 
     def work_ptr(v):
         return lambda p: vec(v, p)
@@ -574,11 +576,12 @@ def replay_lockstep(ws, salts, collect=False, async_scope=False):
 class LockstepBatch:
     """`count` proofs in groups of `group` replayed in lock step by one thread per device (see the module docstring)."""
 
-    def __init__(self, keys, group=16, devices=None, async_scope=False):
+    def __init__(self, keys, group=16, devices=None, async_scope=False, await_rounds=False):
         import torch
 
         self.keys = keys
         self.async_scope = async_scope
+        self.await_rounds = await_rounds
         ndev = torch.cuda.device_count()
         devices = list(range(ndev)) if devices is None else list(devices)
         self.group = group
@@ -592,7 +595,7 @@ class LockstepBatch:
 
         def one(ci):
             try:
-                results[ci] = replay_lockstep(self.workspaces[ci % nws], chunks[ci], collect, self.async_scope)
+                results[ci] = replay_lockstep(self.workspaces[ci % nws], chunks[ci], collect, self.async_scope, self.await_rounds)
             except BaseException:
                 err = _lib.lib().snarkvm_hip_scope_end()  # a failed call must not leave this thread's scope open
                 if err.message:
