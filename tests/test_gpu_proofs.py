@@ -430,3 +430,52 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     for i in range(3):
         assert util.affine_equal(oracle.g1_to_affine(outs[i : i + 1]), oracle.g1_to_affine(want[i])), i
     rb.close()
+
+
+def test_a_bad_request_among_coalesced_callers_fails_alone():
+    """Round-4 review: one failing ticket failed every caller of its coalesced batch.  Eight threads issue proof-sized MSMs at the same time; two of
+    them pass a range that exceeds the registered bases (validated BEFORE the ticket is queued) and one a device pointer the library does not own:
+    exactly those calls return an error, every other caller gets its own correct result."""
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    n = 1 << 13
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    pool = synthetic.random_fr_integers(n, 9400)
+    d_pool = torch.from_numpy(pool.view(np.int64).reshape(-1).copy()).cuda()
+    torch.cuda.synchronize()
+    T, rounds = 8, 6
+    outs = np.zeros((T, rounds), dtype=G1_PROJECTIVE)
+    codes = np.zeros((T, rounds), dtype=np.int64)
+    start = threading.Barrier(T)
+
+    def worker(t):
+        start.wait()
+        for k in range(rounds):
+            o = ctypes.c_void_p(outs[t, k : k + 1].ctypes.data)
+            if t in (2, 5):      # range exceeds the registered bases
+                err = L.snarkvm_hip_msm_registered(o, rb._h, n - 100, 4096, ctypes.c_void_p(d_pool.data_ptr()), 1, 0)
+            elif t == 7:         # "device" scalars that are host memory
+                err = L.snarkvm_hip_msm_registered(o, rb._h, 0, 4096, ctypes.c_void_p(pool.ctypes.data), 1, 0)
+            else:
+                err = L.snarkvm_hip_msm_registered(o, rb._h, 0, 4096 + t, ctypes.c_void_p(d_pool.data_ptr() + 32 * k), 1, 0)
+            codes[t, k] = err.code
+            if err.message:
+                _lib._libc.free(err.message)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for t in range(T):
+        if t in (2, 5, 7):
+            assert (codes[t] != 0).all(), (t, codes[t])
+        else:
+            assert (codes[t] == 0).all(), (t, codes[t])
+            for k in range(rounds):
+                want = oracle.g1_msm(bases[: 4096 + t], pool[k : k + 4096 + t])
+                assert util.affine_equal(oracle.g1_to_affine(outs[t, k : k + 1]), oracle.g1_to_affine(want)), (t, k)
+    rb.close()
