@@ -505,8 +505,13 @@ static void scope_collect(const void* tag) {
         }
     }
     sc.pending.swap(keep);
-    if (sc.pending.empty())  // every MSM lane is idle now (an MSM is the only work it gets): staging areas and events can be handed out again
+    if (sc.pending.empty()) {
+        // nothing of an enqueued MSM is in flight any more: the staging areas and the events can be handed out again - on the MSM lanes (an MSM is
+        // the only work they get) and on the scope's own lane (its events were "inputs ready" marks for those MSMs, or, without a free MSM lane, the
+        // MSMs' own "done" marks; parked host values live in pin2, not in pin)
+        sc.lane->pin_used = 0, sc.lane->scope_events_used = 0;
         for (int i = 0; i < sc.naux; i++) sc.aux[i]->pin_used = 0, sc.aux[i]->scope_events_used = 0;
+    }
     if (err) std::rethrow_exception(err);
 }
 struct lane_guard {

@@ -429,6 +429,17 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     want = [oracle.g1_msm(bases, xs[0]), oracle.g1_msm(bases[: n - 5], xs[1][: n - 5]), oracle.g1_msm(bases[7:n], xs[2][: n - 7])]
     for i in range(3):
         assert util.affine_equal(oracle.g1_to_affine(outs[i : i + 1]), oracle.g1_to_affine(want[i])), i
+    # a long scope that collects after every call: staging areas and events are handed out again each time (60 calls through 7 MSM lanes)
+    many = np.zeros(60, dtype=G1_PROJECTIVE)
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(dev[0].data_ptr()), 3))
+    for k in range(60):
+        ok = ctypes.c_void_p(many[k : k + 1].ctypes.data)
+        _lib.check(L.snarkvm_hip_msm_registered(ok, rb._h, k, n - 64, ctypes.c_void_p(dev[k % 3].data_ptr()), 1, 0))
+        _lib.check(L.snarkvm_hip_scope_collect(ok if k % 2 else None))
+        assert many[k : k + 1].view(np.uint8).any()
+    _lib.check(L.snarkvm_hip_scope_end())
+    for k in (0, 1, 2, 29, 59):
+        assert util.affine_equal(oracle.g1_to_affine(many[k : k + 1]), oracle.g1_to_affine(oracle.g1_msm(bases[k : k + n - 64], xs[k % 3][: n - 64]))), k
     rb.close()
 
 
