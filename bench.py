@@ -719,7 +719,7 @@ def alloc_stats(L, reset=False):
     return {"device_allocations": int(v[0]), "device_bytes": int(v[1]), "pinned_allocations": int(v[2]), "pinned_bytes": int(v[3]), "ms": v[4] / 1e3}
 
 
-def proof1_run(keys, dev_index, salts, warm=4, async_msm=True, await_rounds=False):
+def proof1_run(keys, dev_index, salts, warm=4, async_msm=True, await_rounds=False, msm_in_stream=False):
     """`salts`: the proofs, proved ONE AT A TIME by this thread (snarkvm_amd/proofs.py::replay_single).  Returns (seconds of the whole
     run, per-proof latencies, per-proof result lists, call-time split, workspace growth inside the timed region)."""
     from snarkvm_amd import _lib, proofs
@@ -727,7 +727,7 @@ def proof1_run(keys, dev_index, salts, warm=4, async_msm=True, await_rounds=Fals
     L = _lib.lib()
     ws = proofs.SingleProofWorkspace(keys, dev_index)
     for sidx in salts[:warm]:
-        proofs.replay_single(ws, sidx, None, async_msm, None, await_rounds)
+        proofs.replay_single(ws, sidx, None, async_msm, None, await_rounds, msm_in_stream)
     ws.times = {k: 0.0 for k in ws.times}
     _lib.check(L.snarkvm_hip_synchronize())
     alloc_stats(L, reset=True)
@@ -736,7 +736,7 @@ def proof1_run(keys, dev_index, salts, warm=4, async_msm=True, await_rounds=Fals
     for sidx in salts:
         got = []
         t0 = time.perf_counter()
-        proofs.replay_single(ws, sidx, got, async_msm, None, await_rounds)
+        proofs.replay_single(ws, sidx, got, async_msm, None, await_rounds, msm_in_stream)
         lat.append(time.perf_counter() - t0)
         results.append(got)
     dt = time.perf_counter() - t_begin
@@ -776,15 +776,17 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
     _, lat_b, got_b, times_b, _ = proof1_run(keys, dev_index, mine, async_msm=bool(args.proof1_sync_msm))
     # the order a real prover is bound to: round k's commitments are awaited (snarkvm_hip_scope_collect) before round k + 1 is issued
     _, lat_c, got_c, times_c, _ = proof1_run(keys, dev_index, mine, async_msm=True, await_rounds=True)
+    # ... with those awaited rounds on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM once the independent G2 MSM is out on its own)
+    _, lat_d, got_d, times_d, _ = proof1_run(keys, dev_index, mine, async_msm=True, await_rounds=True, msm_in_stream=True)
     # ---- checks (outside the timed regions)
     ref_ws = proofs.ProofWorkspace(keys, dev_index)
     for i, p in enumerate(mine):
         ref = []
         proofs.replay(ref_ws, p, ref)
         nref = proofs.normalize_results(ref)
-        if nref != proofs.normalize_results(got[i]) or nref != proofs.normalize_results(got_b[i]) or nref != proofs.normalize_results(got_c[i]):
+        if nref != proofs.normalize_results(got[i]) or nref != proofs.normalize_results(got_b[i]) or nref != proofs.normalize_results(got_c[i]) or nref != proofs.normalize_results(got_d[i]):
             raise SystemExit(f"bench.py: proof {p}: the one-scope replay differs from the serial replay")
-    checks["every_proof_vs_serial_replay"] = (f"all {len(mine)} timed proofs x 15 results (asynchronous commitments, commitments awaited round by round, synchronous commitments) "
+    checks["every_proof_vs_serial_replay"] = (f"all {len(mine)} timed proofs x 15 results (asynchronous commitments, commitments awaited round by round on further streams and in-stream, synchronous commitments) "
                                               f"== one synchronous call per step")
     if rank == 0 and not args.no_cpu_baseline:
         secs = [oracle_check_proof(keys, shape, got[mine.index(p)], p) for p in (mine[0], mine[-1])]
@@ -794,6 +796,7 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
         a = proof1_summary(dt_rank, lat, times, grown, len(mine))
         b = proof1_summary(sum(lat_b), lat_b, times_b, None, len(mine))
         c = proof1_summary(sum(lat_c), lat_c, times_c, None, len(mine))
+        d = proof1_summary(sum(lat_d), lat_d, times_d, None, len(mine))
         print(json.dumps({
             "metric": "Varuna-proof-shaped hot-path replays per second, ONE proof at a time from one caller thread (BASELINE.json configs[3])",
             "value": world * len(mine) / dt_job,
@@ -815,6 +818,8 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
             # Fiat-Shamir order: the host has round k's commitments in hand before it issues round k + 1 (a real prover derives the next challenge from them;
             # this replay takes its challenges as inputs, so `value` - everything enqueued at once - is the library's ceiling, this is what a prover gets)
             "commitments_awaited_round_by_round": dict(c, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM + snarkvm_hip_scope_collect(out) after every commitment round"),
+            "commitments_awaited_in_stream": dict(d, mode="the same, the awaited rounds on the scope's own stream (snarkvm_hip_scope_set_flags(... | SNARKVM_HIP_SCOPE_MSM_IN_STREAM) "
+                                                          "after the G2 MSM went to a further stream)"),
             "other_commitment_mode": dict(b, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM" if args.proof1_sync_msm else "synchronous"),
             "g1_pairs_per_s": world * len(mine) * shape.pairs() / dt_job,
             "rank_ms_per_proof": [d / len(mine) * 1e3 for d in rank_dts],
@@ -847,12 +852,15 @@ def proof_legs(dev_index, with_oracle):
     # ---- proof1
     dt, lat, got1, times, grown = proof1_run(keys, dev_index, salts)
     dt_aw, lat_aw, got_aw, _, _ = proof1_run(keys, dev_index, salts, await_rounds=True)
+    dt_is, lat_is, got_is, _, _ = proof1_run(keys, dev_index, salts, await_rounds=True, msm_in_stream=True)
     leg = dict(proof1_summary(dt, lat, times, grown, P), value=P / dt, unit="proofs/s",
                commitments_awaited_round_by_round={"ms_per_proof": dt_aw / P * 1e3, "value": P / dt_aw, "unit": "proofs/s",
                                                    "what": "the same scope, but the host waits for every round's commitments (snarkvm_hip_scope_collect) before it issues the "
                                                            "next round: the Fiat-Shamir order of a real prover"},
+               commitments_awaited_in_stream={"ms_per_proof": dt_is / P * 1e3, "value": P / dt_is, "unit": "proofs/s",
+                                              "what": "the same order, the awaited rounds on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM), the G2 MSM on a further one"},
                what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof (bench.py --workload proof1)")
-    if [proofs.normalize_results(r) for r in got_aw] != [proofs.normalize_results(r) for r in got1]:
+    if any([proofs.normalize_results(r) for r in g] != [proofs.normalize_results(r) for r in got1] for g in (got_aw, got_is)):
         raise SystemExit("bench.py: proof legs: awaiting the commitments round by round changes a result")
     out["proof1"] = leg
     # ---- proofs64 shape, 32 proofs in lock step (a scope per step, every commitment round one synchronous fused call), and the same group inside

@@ -129,8 +129,13 @@ RustError snarkvm_hip_scope_end(void);
  * and a scope that finds no further stream free runs its MSMs on the streams it has.
  * snarkvm_hip_scope_stream: the hipStream_t the scope's device-resident calls are enqueued on (NULL outside a scope) - a caller that
  * produces operands with its own kernels or copies (hipMemcpyAsync, torch.cuda.ExternalStream) orders them with the scope's calls by
- * using this stream. */
-enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1, SNARKVM_HIP_SCOPE_STABLE_INPUTS = 2 };
+ * using this stream.
+ * SNARKVM_HIP_SCOPE_MSM_IN_STREAM (with ASYNC_MSM): the MSMs are enqueued on the scope's OWN stream, in order with its transforms, instead of
+ * a further stream - no hand-off between streams; for the MSMs a caller collects (snarkvm_hip_scope_collect) before it issues anything else,
+ * beside which nothing could run anyway.  snarkvm_hip_scope_set_flags changes the flags of the open scope for the calls that follow: a prover
+ * enqueues its independent MSM (G2) on a further stream first and then runs the transcript-ordered commitment rounds in-stream, each
+ * collected before the next round's challenge is drawn, with the independent MSM filling the gaps. */
+enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1, SNARKVM_HIP_SCOPE_STABLE_INPUTS = 2, SNARKVM_HIP_SCOPE_MSM_IN_STREAM = 4 };
 /* snarkvm_hip_scope_collect(out): waits until the MSM call that was given `out` as its (first) output buffer is done and writes its outputs
  * (out == NULL: every MSM this thread's scope has enqueued so far); the scope stays open, the work queued on its own stream is NOT waited for
  * and the other enqueued MSMs stay pending.  What a prover needs between two rounds: the commitments of round k
@@ -138,6 +143,7 @@ enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1, SNARKVM_HIP_SCOPE_STABLE_INPUTS = 2 };
  * not depend on that challenge - and the tails of earlier MSMs, and an independent MSM - keep running. */
 RustError snarkvm_hip_scope_begin_ex(const void *d_any, uint32_t flags);
 RustError snarkvm_hip_scope_collect(const void *out);
+RustError snarkvm_hip_scope_set_flags(uint32_t flags);
 void *snarkvm_hip_scope_stream(void);
 
 /* Register a base vector once (SRS powers are static per proving key; the reference re-uploads

@@ -80,6 +80,7 @@ public:
     // [| SNARKVM_HIP_SCOPE_STABLE_INPUTS: the scalar vectors of those MSMs are not touched before end()]
     explicit Scope(const void* d_any = nullptr, uint32_t flags = 0) { check(snarkvm_hip_scope_begin_ex(d_any, flags)); }
     void* stream() const { return snarkvm_hip_scope_stream(); }  // the hipStream_t of the scope's calls
+    void set_flags(uint32_t flags) { check(snarkvm_hip_scope_set_flags(flags)); }  // for the calls that follow (e.g. | SNARKVM_HIP_SCOPE_MSM_IN_STREAM after the independent MSM is out)
     void collect(const void* out = nullptr) { check(snarkvm_hip_scope_collect(out)); }  // the outputs of that MSM call (null: of all enqueued so far); the scope stays open
     Scope(const Scope&) = delete;
     Scope& operator=(const Scope&) = delete;

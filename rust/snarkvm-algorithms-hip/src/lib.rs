@@ -125,6 +125,7 @@ mod sys {
         pub fn snarkvm_hip_scope_begin(d_any: *const c_void) -> Error;
         pub fn snarkvm_hip_scope_begin_ex(d_any: *const c_void, flags: u32) -> Error;
         pub fn snarkvm_hip_scope_collect(out: *const c_void) -> Error;
+        pub fn snarkvm_hip_scope_set_flags(flags: u32) -> Error;
         pub fn snarkvm_hip_scope_end() -> Error;
         pub fn snarkvm_hip_scope_stream() -> *mut c_void;
         pub fn snarkvm_hip_alloc_stats(out: *mut u64, reset: i32);
@@ -321,6 +322,9 @@ pub mod resident {
     /// With `SCOPE_ASYNC_MSM`: the caller leaves the scalar vectors of its enqueued MSMs untouched until the guard is dropped; the scope's
     /// stream then never waits for an MSM (SNARKVM_HIP_SCOPE_STABLE_INPUTS).
     pub const SCOPE_STABLE_INPUTS: u32 = 2;
+    /// With `SCOPE_ASYNC_MSM`: MSMs are enqueued on the scope's own stream, in order with its transforms (no hand-off between streams) -
+    /// for commitments that are collected before anything else is issued (SNARKVM_HIP_SCOPE_MSM_IN_STREAM).
+    pub const SCOPE_MSM_IN_STREAM: u32 = 4;
     impl Scope {
         pub fn begin(device_ptr: *const c_void) -> Result<Self, Error> {
             unsafe { sys::snarkvm_hip_scope_begin(device_ptr) }.into_result()?;
@@ -334,6 +338,11 @@ pub mod resident {
         /// commitments for the transcript; the scope stays open and the other enqueued MSMs stay pending.
         pub fn collect(&self, out: *const c_void) -> Result<(), Error> {
             unsafe { sys::snarkvm_hip_scope_collect(out) }.into_result()
+        }
+        /// Changes the scope's flags for the calls that follow (what is enqueued stays where it is): a prover issues its independent MSM
+        /// on a further stream and then switches the transcript-ordered commitment rounds to `SCOPE_MSM_IN_STREAM`.
+        pub fn set_flags(&self, flags: u32) -> Result<(), Error> {
+            unsafe { sys::snarkvm_hip_scope_set_flags(flags) }.into_result()
         }
         /// The `hipStream_t` the scope's calls are enqueued on (for the caller's own copies / kernels that feed them).
         pub fn stream(&self) -> *mut c_void {

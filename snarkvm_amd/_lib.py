@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SNARKVM_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 SYMBOLS = [
     "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm",
     "snarkvm_hip_device_count", "snarkvm_hip_batch_lanes", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_num_devices", "snarkvm_hip_ntt_device", "snarkvm_hip_ntt_device_batch",
-    "snarkvm_hip_scope_begin", "snarkvm_hip_scope_end", "snarkvm_hip_scope_begin_ex", "snarkvm_hip_scope_collect", "snarkvm_hip_scope_stream", "snarkvm_hip_alloc_stats",
+    "snarkvm_hip_scope_begin", "snarkvm_hip_scope_end", "snarkvm_hip_scope_begin_ex", "snarkvm_hip_scope_collect", "snarkvm_hip_scope_set_flags", "snarkvm_hip_scope_stream", "snarkvm_hip_alloc_stats",
     "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_free_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2",
     "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine",
     "snarkvm_hip_fr_mul_device", "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device",
@@ -62,7 +62,7 @@ def lib():
             pass
         L = ctypes.CDLL(LIB_PATH)
         err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_ntt_device", "snarkvm_hip_ntt_device_batch",
-                   "snarkvm_hip_scope_begin", "snarkvm_hip_scope_end", "snarkvm_hip_scope_begin_ex", "snarkvm_hip_scope_collect",
+                   "snarkvm_hip_scope_begin", "snarkvm_hip_scope_end", "snarkvm_hip_scope_begin_ex", "snarkvm_hip_scope_collect", "snarkvm_hip_scope_set_flags",
                    "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
                    "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device", "snarkvm_hip_synchronize",
                    "snarkvm_hip_fr_vec_op", "snarkvm_hip_fr_divide_by_linear", "snarkvm_hip_fr_batch_inversion_and_mul", "snarkvm_hip_fr_distribute_powers", "snarkvm_hip_fr_lagrange_coefficients", "snarkvm_hip_fr_divide_by_vanishing", "snarkvm_hip_fr_mul_by_vanishing",
@@ -95,6 +95,7 @@ def lib():
         L.snarkvm_hip_alloc_stats.restype = None
         L.snarkvm_hip_scope_stream.restype = ctypes.c_void_p
         L.snarkvm_hip_scope_begin_ex.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.snarkvm_hip_scope_set_flags.argtypes = [ctypes.c_uint32]
         _libc = ctypes.CDLL(None)
         _libc.free.argtypes = [ctypes.c_void_p]
         _lib = L

@@ -123,11 +123,12 @@ RustError snarkvm_hip_synchronize(void) {
 // small host results (the remainder of fr_divide_by_linear) are delivered by _end.  How a prover that keeps its polynomials in HBM
 // issues a whole round - or the same round of many proofs in lock step - without a stream synchronisation per call (~40 us each
 // on this stack: 45 transforms per proof).  Calls that leave the scope's lane (MSMs, host buffers) wait for the scope first.
+static constexpr uint32_t SCOPE_FLAGS_ALL = SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS | SNARKVM_HIP_SCOPE_MSM_IN_STREAM;
 RustError snarkvm_hip_scope_begin_ex(const void* d_any, uint32_t flags) {
     API_TRY
     thread_scope_t& sc = tl_scope();
     if (sc.lane) throw hip_failure{hipErrorInvalidValue, "scope_begin: the calling thread already has an open scope", __LINE__};
-    if (flags & ~(uint32_t)(SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS)) throw hip_failure{hipErrorInvalidValue, "scope_begin: unknown flag", __LINE__};
+    if (flags & ~SCOPE_FLAGS_ALL) throw hip_failure{hipErrorInvalidValue, "scope_begin: unknown flag", __LINE__};
     g_rt.configure();
     const int nd = (int)g_rt.devs.size();
     int dev = device_for(d_any, d_any ? 1 : 0);
@@ -159,6 +160,14 @@ RustError snarkvm_hip_scope_begin(const void* d_any) { return snarkvm_hip_scope_
 void* snarkvm_hip_scope_stream(void) {
     lane_t* l = tl_scope().lane;
     return l ? (void*)l->stream : nullptr;
+}
+RustError snarkvm_hip_scope_set_flags(uint32_t flags) {
+    API_TRY
+    thread_scope_t& sc = tl_scope();
+    if (!sc.lane) throw hip_failure{hipErrorInvalidValue, "scope_set_flags: the calling thread has no open scope", __LINE__};
+    if (flags & ~SCOPE_FLAGS_ALL) throw hip_failure{hipErrorInvalidValue, "scope_set_flags: unknown flag", __LINE__};
+    sc.flags = flags;  // applies to the calls that follow; what is enqueued stays where it is
+    API_CATCH
 }
 RustError snarkvm_hip_scope_collect(const void* out) {
     API_TRY

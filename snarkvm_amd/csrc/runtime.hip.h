@@ -1899,8 +1899,11 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
         if (g_rt.devs[dk]->physical != d->physical) return false;  // another GPU: the synchronous path sorts that out
     }
     if ((size_t)d->logical >= h.d.size() || !h.d[d->logical]) return false;
-    // the lane: the scope's MSM lanes in turn; a further one is added while fewer than SCOPE_AUX_MAX are held and one is free
-    if (sc.naux < SCOPE_AUX_MAX && !sc.aux_exhausted && (sc.naux == 0 || sc.aux_rr >= (unsigned)sc.naux)) {
+    // the lane: the scope's MSM lanes in turn; a further one is added while fewer than SCOPE_AUX_MAX are held and one is free.
+    // SNARKVM_HIP_SCOPE_MSM_IN_STREAM: the scope's own lane, in order with its transforms - no event hand-off between streams (what a caller
+    // wants who collects this MSM before it issues anything else: nothing could run beside it anyway)
+    const bool in_stream = (sc.flags & SNARKVM_HIP_SCOPE_MSM_IN_STREAM) != 0;
+    if (!in_stream && sc.naux < SCOPE_AUX_MAX && !sc.aux_exhausted && (sc.naux == 0 || sc.aux_rr >= (unsigned)sc.naux)) {
         if (lane_t* l = d->take_for_scope(false)) {
             l->begin_call();
             l->pin_used = 0;
@@ -1910,7 +1913,7 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
             sc.aux_exhausted = true;
         }
     }
-    lane_t& c = sc.naux ? *sc.aux[sc.aux_rr++ % (unsigned)sc.naux] : *sc.lane;
+    lane_t& c = (sc.naux && !in_stream) ? *sc.aux[sc.aux_rr++ % (unsigned)sc.naux] : *sc.lane;
     std::vector<size_t> all(count);
     for (size_t k = 0; k < count; k++) all[k] = k;
     const std::vector<std::vector<size_t>> jobs = msm_make_jobs(h, req, all, msm_handle_fusable(h, window_bits));

@@ -253,7 +253,7 @@ def _clocks():
     return (time.clock_gettime_ns(time.CLOCK_MONOTONIC), time.clock_gettime_ns(time.CLOCK_MONOTONIC_RAW), time.clock_gettime_ns(time.CLOCK_BOOTTIME), time.time_ns())
 
 
-def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_rounds=False):
+def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_rounds=False, msm_in_stream=False):
     """The hot-path calls of ONE proof from ONE caller thread, issued for latency (configs[3]; the reference proves one transaction at a
     time: synthesizer/snark/src/proving_key/mod.rs:37 -> VarunaSNARK::prove_batch, varuna.rs:336).  Same calls, sizes and operands as
     `replay` - the 15 results are the same group elements - but:
@@ -269,6 +269,8 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_ro
     issues the next round - the order a real prover is bound to, because the commitments of round k enter the Fiat-Shamir transcript that yields
     the challenge of round k + 1 (this replay takes its challenges as inputs, so nothing here needs them); the scope's stream, the earlier tails
     and the G2 MSM keep running meanwhile.
+    msm_in_stream=True (with await_rounds): once the G2 MSM is out on its own stream, the scope is switched to SNARKVM_HIP_SCOPE_MSM_IN_STREAM - the
+    awaited commitment rounds run on the scope's own stream, in order with the transforms, without an event hand-off between streams per round.
     marks: a list that receives (label, clocks) after every step was issued (tools/proof1_timeline.py lines them up with a kernel trace)."""
     import torch
 
@@ -335,6 +337,8 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_ro
             _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, 1 << sh.lg_g2,
                                                         ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0))
         mark("g2 msm issued")
+        if msm_in_stream and await_rounds and async_msm:
+            _lib.check(L.snarkvm_hip_scope_set_flags(3 | 4))
         load(26, nR, 1, count=2)                                                             # round 1: rows 26, 27
         ntt([26], sh.lg_r, 1); ntt([27], sh.lg_r, 0)
         mark("round 1 transforms issued")

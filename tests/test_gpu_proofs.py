@@ -229,13 +229,16 @@ def test_single_proof_scope_replay_every_result_vs_oracle():
     ws = proofs.SingleProofWorkspace(keys)
     ref = proofs.ProofWorkspace(keys)
     for salt in (0, 5, 2):
-        got_async, got_sync, got_await, serial = [], [], [], []
+        got_async, got_sync, got_await, got_in_stream, serial = [], [], [], [], []
         proofs.replay_single(ws, salt, got_async, async_msm=True)
         proofs.replay_single(ws, salt, got_sync, async_msm=False)
         proofs.replay_single(ws, salt, got_await, async_msm=True, await_rounds=True)  # snarkvm_hip_scope_collect after every commitment round
+        # ... and with those awaited rounds on the scope's own stream (snarkvm_hip_scope_set_flags: SNARKVM_HIP_SCOPE_MSM_IN_STREAM after the G2 MSM)
+        proofs.replay_single(ws, salt, got_in_stream, async_msm=True, await_rounds=True, msm_in_stream=True)
         proofs.replay(ref, salt, serial)
         _check_against_oracle(keys, shape, salt, got_async)
         assert proofs.normalize_results(got_async) == proofs.normalize_results(got_sync) == proofs.normalize_results(got_await) == proofs.normalize_results(serial)
+        assert proofs.normalize_results(got_in_stream) == proofs.normalize_results(serial)
     keys.close()
 
 
@@ -440,6 +443,27 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     _lib.check(L.snarkvm_hip_scope_end())
     for k in (0, 1, 2, 29, 59):
         assert util.affine_equal(oracle.g1_to_affine(many[k : k + 1]), oracle.g1_to_affine(oracle.g1_msm(bases[k : k + n - 64], xs[k % 3][: n - 64]))), k
+    # snarkvm_hip_scope_set_flags: the first MSM goes to a further stream, the next ones onto the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM),
+    # behind a transform of their scalars that only the scope's stream orders; collecting an in-stream MSM leaves the first one pending
+    assert L.snarkvm_hip_scope_set_flags(7).code != 0  # no open scope
+    mixed = np.zeros(3, dtype=G1_PROJECTIVE)
+    m = [ctypes.c_void_p(mixed[i : i + 1].ctypes.data) for i in range(3)]
+    work = dev[1].clone()
+    torch.cuda.synchronize()
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(dev[0].data_ptr()), 3))
+    assert L.snarkvm_hip_scope_set_flags(8).code != 0  # unknown flag: the scope keeps its flags
+    _lib.check(L.snarkvm_hip_msm_registered(m[0], rb._h, 0, n, ctypes.c_void_p(dev[0].data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_scope_set_flags(3 | 4))
+    _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(work.data_ptr()), lg, 0, 0, 0))
+    _lib.check(L.snarkvm_hip_msm_registered(m[1], rb._h, 0, n, ctypes.c_void_p(work.data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(work.data_ptr()), lg, 0, 1, 0))  # back to xs[1], behind the MSM on the same stream
+    _lib.check(L.snarkvm_hip_msm_registered(m[2], rb._h, 0, n, ctypes.c_void_p(work.data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_scope_collect(m[2]))
+    assert mixed[2:3].view(np.uint8).any() and not mixed[0:1].view(np.uint8).any() and not mixed[1:2].view(np.uint8).any()
+    _lib.check(L.snarkvm_hip_scope_end())
+    want = [oracle.g1_msm(bases, xs[0]), oracle.g1_msm(bases, oracle.ntt(xs[1], oracle.ORDER_NN, oracle.FORWARD, oracle.STANDARD)), oracle.g1_msm(bases, xs[1])]
+    for i in range(3):
+        assert util.affine_equal(oracle.g1_to_affine(mixed[i : i + 1]), oracle.g1_to_affine(want[i])), i
     rb.close()
 
 

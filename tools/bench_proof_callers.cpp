@@ -7,6 +7,7 @@
 //          -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib
 //   run:   /tmp/bench_proof_callers [g2 points file (200 B each, 2^16 of them) or -] [--scope] [threads ...]
 //          --scope: every caller issues its proof inside ONE asynchronous scope (replay_scope below) instead of one synchronous call per step
+//          --scope-await / --scope-await-in-stream: asynchronous scope, every round's commitments collected before the next round is issued (on further streams / on the scope's own)
 //          --scope-sync: the same scope without SNARKVM_HIP_SCOPE_ASYNC_MSM: the commitment rounds are synchronous calls that meet in the coalescer
 #include <hip/hip_runtime_api.h>
 
@@ -130,6 +131,7 @@ static void replay(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14)
 // w.rows: 28 vectors of NMAX elements (every committed vector keeps its row until the proof is done).
 static uint32_t g_scope_flags = SNARKVM_HIP_SCOPE_ASYNC_MSM | SNARKVM_HIP_SCOPE_STABLE_INPUTS;  // --scope-sync: 0 (synchronous, coalesced commitment rounds)
 static bool g_await_rounds = false;  // --scope-await: snarkvm_hip_scope_collect(out) after every commitment round (the Fiat-Shamir order of a real prover)
+static bool g_in_stream = false;  // --scope-await-in-stream: those awaited rounds run on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM), the G2 MSM on a further one
 static void replay_scope(const keys_t& K, workspace_t& w, size_t salt, uint8_t* out14) {
     size_t nout = 0;
     auto row = [&](int r) { return w.rows + (size_t)r * NMAX * 32; };
@@ -162,6 +164,7 @@ static void replay_scope(const keys_t& K, workspace_t& w, size_t salt, uint8_t* 
         nout += k;
     };
     if (K.hg2) RK(snarkvm_hip_msm_g2_registered(w.g2_out, K.hg2, 0, (size_t)1 << LG_G2, K.pool + 32 * (23 + salt), 1, 0));
+    if (g_in_stream && g_await_rounds && g_scope_flags) RK(snarkvm_hip_scope_set_flags(g_scope_flags | SNARKVM_HIP_SCOPE_MSM_IN_STREAM));  // the awaited rounds on the scope's own stream
     load(26, N_R, 1, 2);  // round 1
     ntt({26}, LG_R, 1), ntt({27}, LG_R, 0);
     commit_round({{row(26), N_R - 2, 2}});
@@ -203,6 +206,8 @@ int main(int argc, char** argv) {
             scope_mode = true;  // callers issue every proof inside one asynchronous scope (replay_scope)
         else if (!strcmp(argv[i], "--scope-await"))
             scope_mode = true, g_await_rounds = true;  // asynchronous scope, but every round's commitments are awaited before the next round is issued
+        else if (!strcmp(argv[i], "--scope-await-in-stream"))
+            scope_mode = true, g_await_rounds = true, g_in_stream = true;
         else if (!strcmp(argv[i], "--scope-sync"))
             scope_mode = true, g_scope_flags = 0;  // a scope per proof for the transforms and passes; the commitment rounds are synchronous calls (coalescer)
         else
@@ -264,6 +269,7 @@ int main(int argc, char** argv) {
     const double serial_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
     printf("one caller, %d proofs one after the other (including the normalisation of the reference results): %.2f ms per proof\n\n", nproofs, serial_ms / nproofs);
     printf("callers: %s\n\n", !scope_mode ? "one synchronous call per step (replay)"
+                                   : g_in_stream ? "one asynchronous scope per proof, every round's commitments awaited (snarkvm_hip_scope_collect) before the next round, the rounds on the scope's own stream (replay_scope, --scope-await-in-stream)"
                                    : g_await_rounds ? "one asynchronous scope per proof, every round's commitments awaited (snarkvm_hip_scope_collect) before the next round (replay_scope, --scope-await)"
                                    : g_scope_flags ? "one SNARKVM_HIP_SCOPE_ASYNC_MSM | _STABLE_INPUTS scope per proof (replay_scope)"
                                                    : "a scope per proof for the transforms and passes, synchronous commitment rounds through the coalescer (replay_scope, --scope-sync)");

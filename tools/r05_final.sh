@@ -26,6 +26,7 @@ import json
 try:
     d = json.load(open("gpurun_out/r05_final/r05_proof1.json"))
     print("proof1", round(d["ms_per_step"], 3), "ms/proof", d["latency"], "| awaited round by round:", round(d["commitments_awaited_round_by_round"]["ms_per_proof"], 3),
+          "| awaited, in-stream:", round(d["commitments_awaited_in_stream"]["ms_per_proof"], 3),
           "| sync commitments:", round(d["other_commitment_mode"]["ms_per_proof"], 3), d["checks"])
     d = json.load(open("gpurun_out/r05_final/r05_proofs64.json"))
     c = d["concurrent_callers"]
@@ -45,13 +46,14 @@ from snarkvm_amd import _lib, proofs
 torch.cuda.set_device(0)
 _lib.check(_lib.lib().snarkvm_hip_set_device(0))
 keys = proofs.ProverKeys(proofs.ProofShape(lg_g2=0), tables=17, window_bits=15)
-for label, mode, aw in (("asynchronous commitments", True, False), ("commitments awaited round by round (snarkvm_hip_scope_collect)", True, True), ("synchronous commitments", False, False)):
+for label, mode, aw, ins in (("asynchronous commitments", True, False, False), ("commitments awaited round by round (snarkvm_hip_scope_collect), on further streams", True, True, False),
+                             ("commitments awaited round by round, on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM)", True, True, True), ("synchronous commitments", False, False, False)):
     ws = proofs.SingleProofWorkspace(keys)
     for s in range(4):
-        proofs.replay_single(ws, s, None, mode, None, aw)
+        proofs.replay_single(ws, s, None, mode, None, aw, ins)
     lat = []
     for s in range(32):
-        t0 = time.perf_counter(); proofs.replay_single(ws, s, None, mode, None, aw); lat.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); proofs.replay_single(ws, s, None, mode, None, aw, ins); lat.append(time.perf_counter() - t0)
     lat.sort()
     print(f"one proof at a time, NO G2 MSM (14 G1 results), {label}: mean {sum(lat) / len(lat) * 1e3:.3f} ms, median {lat[16] * 1e3:.3f}, min {lat[0] * 1e3:.3f}")
 PY
@@ -81,7 +83,7 @@ from snarkvm_amd import synthetic
 open("/tmp/g2pts.bin", "wb").write(synthetic.g2_points(1 << 16).tobytes())
 PY
 g++ -std=c++17 -O2 -pthread -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bench_proof_callers.cpp -o /tmp/bench_proof_callers -L snarkvm_amd/lib -lsnarkvm_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/snarkvm_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib && {
-  for mode in "" "--scope" "--scope-await" "--scope-sync"; do
+  for mode in "" "--scope" "--scope-await" "--scope-await-in-stream" "--scope-sync"; do
     GPU_MAX_HW_QUEUES=8 timeout 200 /tmp/bench_proof_callers - $mode 1 8 16 > "$O/proof_callers_nog2$mode.md" 2> "$O/proof_callers_nog2$mode.err"; cat "$O/proof_callers_nog2$mode.md"
   done
   GPU_MAX_HW_QUEUES=8 timeout 200 /tmp/bench_proof_callers /tmp/g2pts.bin --scope-sync 1 8 16 > "$O/proof_callers_g2--scope-sync.md" 2>&1; cat "$O/proof_callers_g2--scope-sync.md"
