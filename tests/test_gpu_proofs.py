@@ -451,7 +451,7 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     work = dev[1].clone()
     torch.cuda.synchronize()
     _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(dev[0].data_ptr()), 3))
-    assert L.snarkvm_hip_scope_set_flags(8).code != 0  # unknown flag: the scope keeps its flags
+    assert L.snarkvm_hip_scope_set_flags(16).code != 0  # unknown flag: the scope keeps its flags
     _lib.check(L.snarkvm_hip_msm_registered(m[0], rb._h, 0, n, ctypes.c_void_p(dev[0].data_ptr()), 1, 0))
     _lib.check(L.snarkvm_hip_scope_set_flags(3 | 4))
     _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(work.data_ptr()), lg, 0, 0, 0))
