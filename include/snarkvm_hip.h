@@ -112,7 +112,8 @@ RustError snarkvm_hip_ntt_device_batch(void *const *d_inouts, size_t count, uint
  * 32-byte host `remainder` of snarkvm_hip_fr_divide_by_linear with on_device = 1 is delivered by scope_end.  Every other call (MSMs,
  * host buffers, a pointer on another GPU) first waits for the scope's queued work, so results are the same as without a scope - and
  * then runs on the scope's own stream: a thread inside a scope never waits for a free stream.  Scopes do not nest; a scope must be
- * ended by the thread that began it. */
+ * ended by the thread that began it (a thread that ENDS with its scope still open returns the scope's streams to the pool: the queued work is
+ * waited for, results it still owed are dropped). */
 RustError snarkvm_hip_scope_begin(const void *d_any);
 RustError snarkvm_hip_scope_end(void);
 /* The same with options.  SNARKVM_HIP_SCOPE_ASYNC_MSM: snarkvm_hip_msm_registered[_ex / _batch / _batch_ex] and

@@ -11,6 +11,24 @@
 
 runtime_t g_rt;
 thread_local thread_scope_t g_tl_scope;
+// A thread that ends inside a scope (a worker that died, a caller that forgot scope_end): its lanes return to the pool - they are a bounded resource
+// (12 of a GPU's 16 may be held by scopes) and nobody else can end this scope.  The queued work is waited for; results that were still owed (MSM
+// outputs, parked remainders) are NOT delivered: their buffers belong to a thread that is gone.
+thread_scope_t::~thread_scope_t() {
+    if (!lane) return;
+    pending.clear();
+    (void)hipStreamSynchronize(lane->stream);
+    for (int i = 0; i < naux; i++) {
+        (void)hipStreamSynchronize(aux[i]->stream);
+        aux[i]->dev->give(aux[i], true);
+    }
+    lane->in_scope = false;
+    lane->deferred.clear();
+    lane->deferred_bytes = 0;
+    if (!lane->tw_leases.empty()) ntt_tw_release(lane->dev, lane->tw_leases);
+    lane->dev->give(lane, true);
+    lane = nullptr;
+}
 std::atomic<uint64_t> g_co_stats[4];
 static std::atomic<uint64_t> g_alloc_stats[5];  // {device allocations, device bytes, pinned allocations, pinned bytes, microseconds}
 void sv_alloc_note(int slot, size_t bytes, double ms) {

@@ -453,6 +453,10 @@ struct thread_scope_t {
     unsigned aux_rr = 0;
     bool aux_exhausted = false;  // a try for a further lane failed: not tried again in this scope
     std::vector<scope_pending_t> pending;
+    thread_scope_t() = default;
+    thread_scope_t(const thread_scope_t&) = default;
+    thread_scope_t& operator=(const thread_scope_t&) = default;
+    ~thread_scope_t();  // a thread that ends with its scope open gives the lanes back (api.hip)
 };
 // ONE object per thread for the whole library: defined in api.hip.  (Rounds 3-4 kept it as a function-local static of this header,
 // i.e. one copy per translation unit: a scope opened by api.hip was invisible to the transforms and vector passes of api_fr.hip and

@@ -291,6 +291,48 @@ def test_async_msm_scope_outputs_arrive_at_scope_end_and_inputs_may_be_reused():
     rb.close()
 
 
+def test_a_thread_that_ends_inside_a_scope_gives_its_lanes_back():
+    """Scopes hold lanes, a bounded resource (12 of a GPU's 16), and only the thread that began a scope can end it.  Twenty threads, one after the
+    other, open an asynchronous scope, enqueue a transform and an MSM (which takes a second lane) and END WITHOUT scope_end: the thread-exit
+    clean-up must return the lanes - otherwise the seventh thread would wait in scope_begin forever.  Afterwards a scope on the main thread
+    works and delivers a correct result."""
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    lg = 10
+    n = 1 << lg
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    x = synthetic.random_fr_integers(n, 8200)
+    d = torch.from_numpy(x.view(np.int64).reshape(-1).copy()).cuda()
+    scratch = d.clone()
+    torch.cuda.synchronize()
+    lost = np.zeros(20, dtype=G1_PROJECTIVE)  # outputs of the abandoned scopes: never written, must stay valid anyway
+    errors = []
+
+    def leaver(t):
+        try:
+            _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(d.data_ptr()), 1))
+            _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(scratch.data_ptr()), ctypes.c_uint32(lg), 0, t & 1, 0))
+            _lib.check(L.snarkvm_hip_msm_registered(ctypes.c_void_p(lost[t : t + 1].ctypes.data), rb._h, 0, n, ctypes.c_void_p(d.data_ptr()), 1, 0))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    for t in range(20):
+        th = threading.Thread(target=leaver, args=(t,), daemon=True)
+        th.start()
+        th.join(timeout=60)
+        assert not th.is_alive(), f"thread {t} is stuck in scope_begin: the lanes of the threads that ended inside their scopes were not returned"
+    assert not errors, errors[:3]
+    out = np.zeros(1, dtype=G1_PROJECTIVE)
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(d.data_ptr()), 1))
+    _lib.check(L.snarkvm_hip_msm_registered(ctypes.c_void_p(out.ctypes.data), rb._h, 0, n, ctypes.c_void_p(d.data_ptr()), 1, 0))
+    _lib.check(L.snarkvm_hip_scope_end())
+    assert util.affine_equal(oracle.g1_to_affine(out), oracle.g1_to_affine(oracle.g1_msm(bases, x)))
+    rb.close()
+
+
 def test_many_threads_inside_scopes_issue_msms_without_deadlock():
     """Round-4 review: scope_begin pins a lane; an MSM inside the scope needed another one; eight such threads held all eight lanes
     and waited for a ninth forever.  Twelve threads open scopes (plain and asynchronous ones alternating), run a transform and an
