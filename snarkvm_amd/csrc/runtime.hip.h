@@ -1927,8 +1927,8 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
         msm_job_staging(h, j, pb, tb);
         need += pb + tb;
     }
-    if (c.pin_used + need > c.pin.cap) {  // staging full (or first use): collect what is pending, then start over with a bigger area
-        scope_flush();
+    if (c.pin_used + need > c.pin.cap) {  // staging full: collect what is pending (its planes live there), then start over with a bigger area
+        if (c.pin_used) scope_flush();    // (first use of a lane: nothing of the scope is in its area - no reason to deliver other MSMs early)
         c.pin.ensure(need > ((size_t)1 << 20) ? need : (size_t)1 << 20);
     }
     // shared by the finish closures: the requests (outputs) of this call
