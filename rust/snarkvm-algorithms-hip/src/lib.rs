@@ -88,7 +88,8 @@ pub enum NTTType {
     Coset = 1,
 }
 
-mod sys {
+/// The raw C ABI (include/snarkvm_hip.h).  Public for callers that keep their operands in device memory: the safe wrappers below take host slices.
+pub mod sys {
     use super::{Error, NTTDirection, NTTInputOutputOrder, NTTType};
     use core::ffi::c_void;
 
