@@ -44,6 +44,16 @@ G1_GEN_Y = [13572190014569192121, 15344828677741220784, 17067903700058808083, 10
 R_MOD = 8444461749428370424248824938781546531375899335154063827935233455917409239041
 
 
+def duplicate_devices(rank_devices):
+    """UUIDs that more than one rank reports (two ranks sharing a GPU make `value` meaningless as a scaling point): [] when every rank has its own device."""
+    seen = {}
+    for d in rank_devices or []:
+        u = d.get("uuid") if isinstance(d, dict) else None
+        if u:
+            seen.setdefault(u, []).append(d.get("rank"))
+    return [{"uuid": u, "ranks": r} for u, r in seen.items() if len(r) > 1]
+
+
 def weighted_sum_mod_r(scalars, start=1):
     """sum_i (start + i) * scalars[i] mod r for an (n,4) u64 array, vectorised (16-bit pieces, chunked)."""
     s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
@@ -144,6 +154,14 @@ def main():
     ap.add_argument("--lockstep-async", action="store_true", help="proofs64: the whole lock-step group in ONE asynchronous scope (measured slower: 191 vs 203 proofs/s)")
     ap.add_argument("--proof1-sync-msm", action="store_true", help="proof1: synchronous commitments (the A/B of SNARKVM_HIP_SCOPE_ASYNC_MSM)")
     ap.add_argument("--no-proof-legs", action="store_true", help="default workload: skip the proof1 / proofs64 / concurrent_callers legs")
+    ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform",
+                    help="distribution of the timed legs' scalars: uniform in [0, r), or witness-like (SURVEY.md 8d config 2: 50 %% zero, 25 %% < 2^16, 25 %% uniform; "
+                         "synthesizer/process/src/tests/test_credits.rs:2868-2925 shapes).  The default line reports BOTH for the headline, proof1 and proofs64 "
+                         "(value_witness_like, ...); this flag makes the second distribution the headline itself")
+    ap.add_argument("--ffi-only", action="store_true", help="proof1: the same proof through the reference's OWN three symbols on host buffers (what an unmodified snarkVM gets): "
+                                                             "rows stateless / SNARKVM_HIP_BASE_CACHE=16 / resident")
+    ap.add_argument("--ffi-threads", type=int, default=4, help="--ffi-only: caller threads that issue the commitments of a round (the reference's rayon workers)")
+    ap.add_argument("--proof1-all-at-once", action="store_true", help="proof1: make the everything-enqueued-at-once replay (an order no Fiat-Shamir prover can use) the headline again")
     args = ap.parse_args()
 
     import torch
@@ -274,7 +292,8 @@ def main():
     rb = RegisteredBases(device_ptr=bases_dev.data_ptr(), npoints=n, tables=args.tables,
                          window_bits=0 if (args.table_bits == 16 and args.tables == 16) or args.tables == 1 else args.table_bits)
     registration_ms = (time.perf_counter() - t0) * 1e3
-    scalars = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE + rank)
+    scalars_uniform = synthetic.random_fr_integers(n, synthetic.SEED_MSM_LARGE + rank)
+    scalars = synthetic.witness_like_from(scalars_uniform, synthetic.SEED_MSM_LARGE + rank) if args.scalars == "witness" else scalars_uniform
     d_scalars = torch.from_numpy(scalars.view(np.int64)).cuda()
     torch.cuda.synchronize()
     # Every timed step gets its OWN scalar vector (512 MiB each in HBM): step k uses the seeded vector rotated by k * STEP_SHIFT
@@ -303,15 +322,36 @@ def main():
             # K independent MSM instances (a batch of commitments) pipelined over the backend's HIP streams: the
             # latency-bound tail of one instance overlaps the accumulation of the next.  Every step does the full work.
             res = rb.msm_batch(device_ptrs=[d.data_ptr() for d in d_step], npoints=[n] * args.steps, window_bits=args.window_bits)
+        dt_own = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
         barrier()
         dt_rank = time.perf_counter() - t0
         dt = max_over_ranks(dt_rank)
-    rank_dts = gather_over_ranks(dt_rank)
+    rank_dts = gather_over_ranks(dt_own)
     print(f"[bench rank {rank}] {dt_rank / args.steps * 1e3:.3f} ms per step on this rank", file=sys.stderr)
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = world * n * args.steps / dt
     want_affine = check_results(res, scalars, "timed_msm", shifts)  # outside the timed region
     del d_step
+    # ---- the same K pipelined steps on the OTHER distribution (rank 0, N = 1): SURVEY.md 8(d) config 2 names witness-like scalars as the second one
+    other = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.no_pipeline:
+        other_name = "uniform" if args.scalars == "witness" else "witness_like"
+        sc_o = scalars_uniform if args.scalars == "witness" else synthetic.witness_like_from(scalars_uniform, synthetic.SEED_MSM_LARGE + rank)
+        d_o = torch.from_numpy(sc_o.view(np.int64)).cuda()
+        k_o = min(args.steps, 8)
+        sh_o = shifts[:k_o]
+        d_step_o = [d_o if sh == 0 else torch.roll(d_o.view(n, 4), sh, dims=0).contiguous() for sh in sh_o]
+        torch.cuda.synchronize()
+        rb.msm_batch(device_ptrs=[d_o.data_ptr()] * L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n)), npoints=[n] * L.snarkvm_hip_batch_lanes(ctypes.c_size_t(n)), window_bits=args.window_bits)
+        barrier()
+        t0 = time.perf_counter()
+        res_o = rb.msm_batch(device_ptrs=[d.data_ptr() for d in d_step_o], npoints=[n] * k_o, window_bits=args.window_bits)
+        barrier()
+        dt_o = time.perf_counter() - t0
+        check_results(res_o, sc_o, f"timed_msm_{other_name}", sh_o)
+        other = {"name": other_name, "value": n * k_o / dt_o, "ms_per_step": dt_o / k_o * 1e3, "steps": k_o}
+        del d_step_o, d_o, sc_o
+    del scalars_uniform
 
     # ------------------------------------------------------------------ per-phase kernel times (HIP events on the launch stream)
     L.snarkvm_hip_set_profiling(1)
@@ -501,6 +541,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu as oracle
 
+        oracle_build = oracle.use_native()
         cores = os.cpu_count() or 1
         threads = min(cores, 64)
         oracle.set_threads(threads)
@@ -540,6 +581,7 @@ def main():
             "sample": f"batched::msm restatement (oracle/cpu_oracle.cpp, OpenMP one task per window) on {cn} pairs of the "
                       f"same workload: {cpu_msm_dt:.2f} s; fft_in_place restatement on {cnn} elements: {cpu_ntt_dt:.2f} s",
             "host_cores": cores,
+            "build": f"g++ {oracle_build}, OpenMP",
             "ntt_value": cnn / cpu_ntt_dt,
             "ntt_unit": "elements/s",
         }
@@ -577,7 +619,9 @@ def main():
                 "madds_per_launch": madds,
                 "madds_per_s": madds / (acc_ms * 1e-3),
                 "madd_ceiling_per_s": ceil.get("g1_lazy_madd_per_s") or ceil.get("g1_madd_per_s"),
-                "frac": madds / (acc_ms * 1e-3) / (ceil.get("g1_lazy_madd_per_s") or ceil["g1_madd_per_s"]) if ceil.get("g1_madd_per_s") else None,
+                # (round 6: was `frac`.  The ceiling is the kernel's OWN addition loop run from registers - a self-reference, not a roofline; `mad_frac` below, against
+                # the chip's measured v_mad_u64_u32 issue rate, is the ALU roofline fraction)
+                "vs_register_loop": madds / (acc_ms * 1e-3) / (ceil.get("g1_lazy_madd_per_s") or ceil["g1_madd_per_s"]) if ceil.get("g1_madd_per_s") else None,
                 "mads_per_launch": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)),
                 "peak_mads_per_s": ceil.get("v_mad_u64_u32_per_s"),
                 "mad_frac": madds * float(ceil.get("g1_lazy_mads_per_madd", 2938)) / (acc_ms * 1e-3) / ceil["v_mad_u64_u32_per_s"] if ceil.get("v_mad_u64_u32_per_s") else None,
@@ -599,7 +643,7 @@ def main():
                 passes = (args.lg_ntt + 7) // 8 if args.lg_ntt <= 24 else 3  # ntt_make_plan: radix <= 2^8 up to 2^24, 2^9 beyond
                 alu_ntt["element_passes_per_launch"] = float(passes * nn)
                 alu_ntt["element_pass_ceiling_per_s"] = ceil["fr_ntt_element_passes_per_s"]
-                alu_ntt["frac"] = passes * nn / (ntt_kernel_ms * 1e-3) / ceil["fr_ntt_element_passes_per_s"]
+                alu_ntt["vs_register_loop"] = passes * nn / (ntt_kernel_ms * 1e-3) / ceil["fr_ntt_element_passes_per_s"]
         out = {
             "metric": "BLS12-377 G1 MSM scalar-point pairs/sec (+ Fr NTT elements/sec in ntt_*)",
             "value": pairs_per_s,
@@ -610,6 +654,12 @@ def main():
             "ms_per_step": ms_per_step,
             "rank_ms_per_step": [d / args.steps * 1e3 for d in rank_dts],
             "rank_devices": rank_devices,
+            # DESIGN.md 7's prediction made checkable: the sum of every rank's OWN rate (its K steps on its own clock, before the closing barrier) - what N
+            # independent instance streams deliver when nothing on the host or the fabric couples them.  `value` (all ranks' units / the slowest rank's time incl. the
+            # barrier) should sit within a few percent of it; a gap means host-side contention, two ranks on one GPU (duplicate_devices) or a slow box.
+            "predicted_value": sum(n * args.steps / d for d in rank_dts),
+            "value_over_predicted": pairs_per_s / sum(n * args.steps / d for d in rank_dts),
+            "duplicate_devices": duplicate_devices(rank_devices),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,  # the reference publishes no number for this metric
@@ -617,10 +667,14 @@ def main():
             "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": f"G1 Pippenger MSM 2^{args.lg_msm} (BASELINE.json configs[1]), bases (i+1)G registered in HBM, "
-                                   f"uniform scalars in HBM; independent instance per GPU",
+                                   f"{'witness-like (50 % zero, 25 % < 2^16, 25 % uniform)' if args.scalars == 'witness' else 'uniform'} scalars in HBM; independent instance per GPU",
+                       "scalars": args.scalars,
                        "lg_msm": args.lg_msm, "lg_ntt": args.lg_ntt, "window_bits": args.window_bits or "auto", "base_tables": args.tables, "table_bits": args.table_bits,
                        "pipelined_batch": not args.no_pipeline},
             "checks": checks,
+            # the same pipelined steps on the second distribution (rank 0, N = 1), each result against its own closed form
+            **({f"value_{other['name']}": other["value"], f"ms_per_step_{other['name']}": other["ms_per_step"], f"steps_{other['name']}": other["steps"],
+                f"{other['name']}_over_headline": other["value"] / pairs_per_s} if other else {}),
             "ntt_value": ntt_elems_per_s,
             "ntt_unit": "elements/s",
             "ntt_ms_per_transform": ntt_dt / args.ntt_steps * 1e3,
@@ -697,6 +751,7 @@ def oracle_check_proof(keys, shape, got, p):
     from snarkvm_amd import kzg10
     from snarkvm_amd.layout import G1_PROJECTIVE, G2_PROJECTIVE
 
+    oracle.use_native()  # (before the first oracle call of the process: the cpu_baseline leg times this library)
     oracle.set_threads(min(os.cpu_count() or 1, 64))
     t0 = time.perf_counter()
     want = proof_replay.expected_results(keys.pool_host, keys.g1_host, keys.g2_host, keys.point, shape.lg_r, shape.lg_k, shape.lg_g2, shape.nmax, p)
@@ -750,55 +805,151 @@ def proof1_summary(dt, lat, times, grown, count):
             "workspace_growth_in_timed_region": grown}
 
 
-def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks, rank_devices):
-    """BASELINE.json configs[3]: one Varuna-proof-shaped call list at a time from ONE caller thread, 32 timed proofs per rank (the
-    reference proves one transaction at a time: synthesizer/snark/src/proving_key/mod.rs:37 -> varuna.rs:336).  `ms_per_step` is the
-    latency of one proof.  Every timed result is compared with the serial replay (one synchronous call per step: `proofs.replay`), two
-    whole proofs with the CPU oracle; the same proofs are timed again with synchronous commitments (the A/B of the overlap)."""
-    import torch.distributed as dist
+def proof1_ffi_rows(keys, salts, threads, warm=3):
+    """The transfer_private call list through the three symbols `snarkvm-algorithms-cuda` binds, on host buffers (snarkvm_amd/proofs.py::replay_ffi), one
+    proof at a time: row `stateless` (the symbols as the reference defines them: nothing retained between calls) and row `base_cache_16`
+    (snarkvm_hip_set_base_cache(16) == SNARKVM_HIP_BASE_CACHE=16: the long-lived base vector is registered in HBM at its second sighting).
+    Returns ({row: summary}, {row: [per-proof result lists]}).  Timed per step class inside replay_ffi; the rows' results are checked by the caller."""
+    from snarkvm_amd import _lib, proofs
 
+    L = _lib.lib()
+    host = proofs.FfiProofHost(keys, threads)
+    rows, results = {}, {}
+    for name, tables in (("stateless", 0), ("base_cache_16", 16)):
+        _lib.check(L.snarkvm_hip_set_base_cache(tables))
+        for p in salts[:warm]:  # the cache registers a range at its second sighting: from the third proof on every slice is a hit
+            proofs.replay_ffi(host, p, None, {})
+        per, walls, got_all = [], [], []
+        for p in salts:
+            t, got = {}, []
+            t0 = time.perf_counter()
+            proofs.replay_ffi(host, p, got, t)
+            walls.append(time.perf_counter() - t0)
+            per.append(t)
+            got_all.append(got)
+        n = len(salts)
+        mean = lambda k: sum(x[k] for x in per) / n * 1e3  # noqa: E731
+        inside = sorted((x["ntt"] + x["polymul"] + x["msm"]) * 1e3 for x in per)
+        rows[name] = {"ms_inside_the_three_symbols_per_proof": sum(inside) / n, "median_ms": inside[n // 2], "min_ms": inside[0], "max_ms": inside[-1],
+                      "ms_by_step": {"transforms_and_per_matrix_steps": mean("ntt"), "rowcheck_product": mean("polymul"), "commitment_rounds": mean("msm")},
+                      "calls_per_proof": {"snarkvm_ntt": per[0]["ntt_calls"], "snarkvm_polymul": per[0]["polymul_calls"], "snarkvm_msm": per[0]["msm_calls"]},
+                      "g2_extension_call_ms": mean("g2"), "glue_ms_not_counted": mean("glue"), "wall_ms_per_proof_with_glue": sum(walls) / n * 1e3,
+                      "proofs": n, "caller_threads": threads}
+        results[name] = got_all
+    _lib.check(L.snarkvm_hip_set_base_cache(0))
+    host.close()
+    return rows, results
+
+
+FFI_WHAT = ("the transfer_private call list through snarkvm_ntt / snarkvm_polymul / snarkvm_msm on HOST buffers (what an unmodified snarkVM build gets): every commitment one "
+            "snarkvm_msm over a slice of ONE long-lived base vector, a round's commitments from caller threads (sonic_pc/mod.rs:186-245); the reference's CPU glue between the "
+            "calls (convert_to_bigints, divisions, <= 3-point hiding MSMs) is not counted")
+
+
+def proof1_ffi(args, dev_index):
+    """`--workload proof1 --ffi-only`: BASELINE.json configs[3] as an UNMODIFIED snarkVM would run it - the three reference symbols on host slices - beside the
+    resident path (device-resident operands, registered SRS, one scope per proof, commitments awaited in transcript order)."""
     from snarkvm_amd import proofs
 
     shape = proofs.ProofShape()
     ptab, pbits = (int(v) for v in args.proof_geometry.split("x"))
-    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits)
+    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits, scalars=args.scalars)
+    count = 16
+    salts = list(range(count))
+    t0 = time.perf_counter()
+    rows, res = proof1_ffi_rows(keys, salts, args.ffi_threads)
+    dt_rows = time.perf_counter() - t0
+    dt_res, lat_res, got_res, times_res, _ = proof1_run(keys, dev_index, salts, async_msm=True, await_rounds=True, msm_in_stream=True)
+    # ---- checks (outside the timed regions)
+    checks = {}
+    norm_res = [proofs.normalize_results(r) for r in got_res]
+    for name, got in res.items():
+        if [proofs.normalize_results(r) for r in got] != norm_res:
+            raise SystemExit(f"bench.py: --ffi-only row {name}: a result differs from the resident replay")
+    checks["every_row_vs_resident_replay"] = f"all {count} proofs x 15 results of both FFI rows == the resident one-scope replay (after affine normalisation)"
+    if not args.no_cpu_baseline:
+        secs = [oracle_check_proof(keys, shape, res[name][-1], salts[-1]) for name in res]
+        checks["proof_vs_oracle"] = f"proof {salts[-1]} of each FFI row: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py ({secs[0]:.1f} s on the host each)"
+    resident = proof1_summary(dt_res, lat_res, times_res, None, count)
+    st, ca = rows["stateless"], rows["base_cache_16"]
+    print(json.dumps({
+        "metric": "milliseconds one Varuna-proof-shaped call list spends inside the reference's three FFI symbols (BASELINE.json configs[3], unmodified snarkVM)",
+        "value": st["ms_inside_the_three_symbols_per_proof"], "unit": "ms/proof", "n_gpus": 1, "steps": count, "warmup": 3,
+        "ms_per_step": st["ms_inside_the_three_symbols_per_proof"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": FFI_WHAT, "caller_threads": args.ffi_threads, "proofs": count},
+        "stateless": st, "base_cache_16": ca,
+        "resident": dict(resident, what="device-resident operands + registered SRS + one scope per proof, commitments awaited in transcript order in-stream, G2 MSM included "
+                                          f"(registered_srs {ptab} x {pbits})"),
+        "ratios": {"stateless_over_resident": st["ms_inside_the_three_symbols_per_proof"] / resident["ms_per_proof"],
+                   "base_cache_over_resident": ca["ms_inside_the_three_symbols_per_proof"] / resident["ms_per_proof"]},
+        "wall_s_of_both_rows": dt_rows, "checks": checks}))
+    keys.close()
+
+
+def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ranks, rank_devices):
+    """BASELINE.json configs[3]: one Varuna-proof-shaped call list at a time from ONE caller thread, 32 timed proofs per rank (the
+    reference proves one transaction at a time: synthesizer/snark/src/proving_key/mod.rs:37 -> varuna.rs:336).  `ms_per_step` is the
+    latency of one proof IN THE ORDER A PROVER IS BOUND TO: the commitments of round k are in the host's hands (snarkvm_hip_scope_collect) before
+    round k + 1 is issued - they enter the Fiat-Shamir transcript that yields the next challenge (varuna.rs:336 ff.) - with the awaited rounds on the scope's
+    own stream and the independent G2 MSM on a further one.  The replay that enqueues all six rounds at once (round 5's headline; an order no prover can
+    use) is reported beside it as the library's ceiling.  Every timed result is compared with the serial replay (one synchronous call per step:
+    `proofs.replay`), two whole proofs with the CPU oracle."""
+    import torch.distributed as dist
+
+    from snarkvm_amd import proofs
+
+    if args.ffi_only:
+        if world > 1:
+            raise SystemExit("bench.py: --ffi-only is a single-GPU leg")
+        return proof1_ffi(args, dev_index)
+    shape = proofs.ProofShape()
+    ptab, pbits = (int(v) for v in args.proof_geometry.split("x"))
+    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits, scalars=args.scalars)
     count = 32
     mine = list(range(rank, count * world, world))
     checks = {}
+    modes = {"awaited_in_stream": dict(async_msm=True, await_rounds=True, msm_in_stream=True),
+             "awaited_on_further_streams": dict(async_msm=True, await_rounds=True),
+             "all_rounds_enqueued_at_once": dict(async_msm=True),
+             "synchronous_commitments": dict(async_msm=False)}
+    head = "synchronous_commitments" if args.proof1_sync_msm else ("all_rounds_enqueued_at_once" if args.proof1_all_at_once else "awaited_in_stream")
     barrier()
     t0 = time.perf_counter()
-    dt_rank, lat, got, times, grown = proof1_run(keys, dev_index, mine, async_msm=not args.proof1_sync_msm)
+    dt_rank, lat, got, times, grown = proof1_run(keys, dev_index, mine, **modes[head])
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     # proof1_run's warm-up sits inside [t0, now): the per-proof figures come from its own clock, the whole-job rate from the slowest rank's
     dt_job = max_over_ranks(dt_rank)
     rank_dts = gather_over_ranks(dt_rank)
-    _, lat_b, got_b, times_b, _ = proof1_run(keys, dev_index, mine, async_msm=bool(args.proof1_sync_msm))
-    # the order a real prover is bound to: round k's commitments are awaited (snarkvm_hip_scope_collect) before round k + 1 is issued
-    _, lat_c, got_c, times_c, _ = proof1_run(keys, dev_index, mine, async_msm=True, await_rounds=True)
-    # ... with those awaited rounds on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM once the independent G2 MSM is out on its own)
-    _, lat_d, got_d, times_d, _ = proof1_run(keys, dev_index, mine, async_msm=True, await_rounds=True, msm_in_stream=True)
+    others = {}
+    for name, kw in modes.items():
+        if name != head:
+            _, lat_o, got_o, times_o, _ = proof1_run(keys, dev_index, mine, **kw)
+            others[name] = (lat_o, got_o, times_o)
     # ---- checks (outside the timed regions)
     ref_ws = proofs.ProofWorkspace(keys, dev_index)
     for i, p in enumerate(mine):
         ref = []
         proofs.replay(ref_ws, p, ref)
         nref = proofs.normalize_results(ref)
-        if nref != proofs.normalize_results(got[i]) or nref != proofs.normalize_results(got_b[i]) or nref != proofs.normalize_results(got_c[i]) or nref != proofs.normalize_results(got_d[i]):
+        if nref != proofs.normalize_results(got[i]) or any(nref != proofs.normalize_results(o[1][i]) for o in others.values()):
             raise SystemExit(f"bench.py: proof {p}: the one-scope replay differs from the serial replay")
-    checks["every_proof_vs_serial_replay"] = (f"all {len(mine)} timed proofs x 15 results (asynchronous commitments, commitments awaited round by round on further streams and in-stream, synchronous commitments) "
-                                              f"== one synchronous call per step")
+    checks["every_proof_vs_serial_replay"] = (f"all {len(mine)} timed proofs x 15 results (commitments awaited round by round in-stream and on further streams, all rounds enqueued at once, "
+                                              f"synchronous commitments) == one synchronous call per step")
     if rank == 0 and not args.no_cpu_baseline:
         secs = [oracle_check_proof(keys, shape, got[mine.index(p)], p) for p in (mine[0], mine[-1])]
         checks["proofs_vs_oracle"] = (f"proofs {mine[0]} and {mine[-1]}: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py "
                                       f"({secs[0]:.1f} + {secs[1]:.1f} s on the host)")
     if rank == 0:
-        a = proof1_summary(dt_rank, lat, times, grown, len(mine))
-        b = proof1_summary(sum(lat_b), lat_b, times_b, None, len(mine))
-        c = proof1_summary(sum(lat_c), lat_c, times_c, None, len(mine))
-        d = proof1_summary(sum(lat_d), lat_d, times_d, None, len(mine))
+        what = {"awaited_in_stream": "one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof; the G2 MSM on a further stream, then snarkvm_hip_scope_set_flags(... | SNARKVM_HIP_SCOPE_MSM_IN_STREAM): "
+                                     "every commitment round on the scope's own stream and COLLECTED (snarkvm_hip_scope_collect) before the next round is issued - the Fiat-Shamir order",
+                "awaited_on_further_streams": "the same order, the awaited rounds on further streams of the scope (an event hand-off per round)",
+                "all_rounds_enqueued_at_once": "all six commitment rounds enqueued without waiting for any: the library's ceiling - this replay takes its challenges as inputs, "
+                                               "a real prover cannot issue round k + 1 before it has round k's commitments",
+                "synchronous_commitments": "the scope without SNARKVM_HIP_SCOPE_ASYNC_MSM: every commitment round a synchronous call"}
+        legs = {name: dict(proof1_summary(sum(o[0]), o[0], o[2], None, len(mine)), mode=what[name]) for name, o in others.items()}
         print(json.dumps({
-            "metric": "Varuna-proof-shaped hot-path replays per second, ONE proof at a time from one caller thread (BASELINE.json configs[3])",
+            "metric": "Varuna-proof-shaped hot-path replays per second, ONE proof at a time from one caller thread, commitments awaited in transcript order (BASELINE.json configs[3])",
             "value": world * len(mine) / dt_job,
             "unit": "proofs/s",
             "n_gpus": world,
@@ -812,15 +963,9 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
             "data": "synthetic",
             "config": {"workload": "one proof at a time: 14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM; "
                                    "device-resident random data, transfer_private domain sizes; one deferred-synchronisation scope per proof",
-                       "proofs_per_rank": len(mine), "registered_srs": f"{ptab} tables x {pbits}-bit windows",
-                       "commitments": "synchronous" if args.proof1_sync_msm else "SNARKVM_HIP_SCOPE_ASYNC_MSM"},
-            "latency": a,
-            # Fiat-Shamir order: the host has round k's commitments in hand before it issues round k + 1 (a real prover derives the next challenge from them;
-            # this replay takes its challenges as inputs, so `value` - everything enqueued at once - is the library's ceiling, this is what a prover gets)
-            "commitments_awaited_round_by_round": dict(c, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM + snarkvm_hip_scope_collect(out) after every commitment round"),
-            "commitments_awaited_in_stream": dict(d, mode="the same, the awaited rounds on the scope's own stream (snarkvm_hip_scope_set_flags(... | SNARKVM_HIP_SCOPE_MSM_IN_STREAM) "
-                                                          "after the G2 MSM went to a further stream)"),
-            "other_commitment_mode": dict(b, mode="SNARKVM_HIP_SCOPE_ASYNC_MSM" if args.proof1_sync_msm else "synchronous"),
+                       "proofs_per_rank": len(mine), "registered_srs": f"{ptab} tables x {pbits}-bit windows", "commitments": head, "mode": what[head], "pool_values": args.scalars},
+            "latency": proof1_summary(dt_rank, lat, times, grown, len(mine)),
+            **legs,
             "g1_pairs_per_s": world * len(mine) * shape.pairs() / dt_job,
             "rank_ms_per_proof": [d / len(mine) * 1e3 for d in rank_dts],
             "rank_devices": rank_devices,
@@ -849,20 +994,32 @@ def proof_legs(dev_index, with_oracle):
     out = {}
     P = 32
     salts = list(range(P))
-    # ---- proof1
-    dt, lat, got1, times, grown = proof1_run(keys, dev_index, salts)
+    # ---- proof1: the headline is the order a prover is bound to (round k's commitments collected before round k + 1 is issued), in-stream
+    dt_is, lat_is, got_is, times_is, grown = proof1_run(keys, dev_index, salts, await_rounds=True, msm_in_stream=True)
     dt_aw, lat_aw, got_aw, _, _ = proof1_run(keys, dev_index, salts, await_rounds=True)
-    dt_is, lat_is, got_is, _, _ = proof1_run(keys, dev_index, salts, await_rounds=True, msm_in_stream=True)
-    leg = dict(proof1_summary(dt, lat, times, grown, P), value=P / dt, unit="proofs/s",
-               commitments_awaited_round_by_round={"ms_per_proof": dt_aw / P * 1e3, "value": P / dt_aw, "unit": "proofs/s",
-                                                   "what": "the same scope, but the host waits for every round's commitments (snarkvm_hip_scope_collect) before it issues the "
-                                                           "next round: the Fiat-Shamir order of a real prover"},
-               commitments_awaited_in_stream={"ms_per_proof": dt_is / P * 1e3, "value": P / dt_is, "unit": "proofs/s",
-                                              "what": "the same order, the awaited rounds on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM), the G2 MSM on a further one"},
-               what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof (bench.py --workload proof1)")
+    dt, lat, got1, times, _ = proof1_run(keys, dev_index, salts)
+    leg = dict(proof1_summary(dt_is, lat_is, times_is, grown, P), value=P / dt_is, unit="proofs/s",
+               commitments_awaited_on_further_streams={"ms_per_proof": dt_aw / P * 1e3, "value": P / dt_aw, "unit": "proofs/s",
+                                                       "what": "the same order, the awaited rounds on further streams of the scope (an event hand-off per round)"},
+               all_rounds_enqueued_at_once={"ms_per_proof": dt / P * 1e3, "value": P / dt, "unit": "proofs/s",
+                                            "what": "the library's ceiling: all six commitment rounds enqueued without waiting for any (this replay takes its challenges as inputs; "
+                                                    "no Fiat-Shamir prover can use this order) - round 5's headline"},
+               what="one proof at a time from one caller thread, one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per proof, the G2 MSM on a further stream, every commitment round "
+                    "on the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM) and collected (snarkvm_hip_scope_collect) before the next round is issued: the "
+                    "Fiat-Shamir order of a real prover (bench.py --workload proof1)")
     if any([proofs.normalize_results(r) for r in g] != [proofs.normalize_results(r) for r in got1] for g in (got_aw, got_is)):
         raise SystemExit("bench.py: proof legs: awaiting the commitments round by round changes a result")
     out["proof1"] = leg
+    # ---- the same call list through the reference's OWN three symbols on host buffers (what an unmodified snarkVM gets; bench.py --workload proof1 --ffi-only)
+    ffi_salts = salts[:6]
+    rows, res = proof1_ffi_rows(keys, ffi_salts, 4)
+    for name, got in res.items():
+        if [proofs.normalize_results(r) for r in got] != [proofs.normalize_results(r) for r in got1[: len(ffi_salts)]]:
+            raise SystemExit(f"bench.py: proof legs: FFI row {name}: a result differs from the resident replay")
+    out["proof1_ffi"] = {"value": rows["stateless"]["ms_inside_the_three_symbols_per_proof"], "unit": "ms/proof", "higher_is_better": False,
+                         "stateless": rows["stateless"], "base_cache_16": rows["base_cache_16"],
+                         "resident_ms_per_proof": dt_is / P * 1e3, "what": FFI_WHAT,
+                         "checks": {"ffi_rows_vs_resident": f"all {len(ffi_salts)} proofs x 15 results of both rows == the resident replay (after affine normalisation)"}}
     # ---- proofs64 shape, 32 proofs in lock step (a scope per step, every commitment round one synchronous fused call), and the same group inside
     # ONE asynchronous scope (measured slower: the fused groups fill the chip by themselves)
     def lockstep(async_scope):
@@ -901,7 +1058,33 @@ def proof_legs(dev_index, with_oracle):
         oracle_check_proof(keys, shape, got_lock[p], p)
         msg = f"proof {p}: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py ({secs:.1f} s on the host)"
         leg["checks"]["one_proof_vs_oracle"] = msg
+        pf = ffi_salts[-1]
+        for name in res:
+            oracle_check_proof(keys, shape, res[name][pf], pf)
+        out["proof1_ffi"]["checks"]["one_proof_per_row_vs_oracle"] = f"proof {pf} of each row: all 14 G1 commitments / openings and the G2 MSM == oracle/proof_replay.py"
         out["proofs64"]["checks"]["one_proof_vs_oracle"] = msg
+    # ---- the same two legs on witness-shaped data (shapes: synthesizer/process/src/tests/test_credits.rs:2868-2925): a pool whose VALUES are
+    # 50 % zero / 25 % < 2^16 / 25 % uniform.  Only the 4 commitments that read the pool directly see that distribution (the other 10 commit to outputs of
+    # transforms and divisions, which are uniform whatever went in) - which is also true of a real prover, whose commitments are all to coefficient-form polynomials.
+    keys_w = proofs.ProverKeys(shape, tables=17, window_bits=15, scalars="witness")
+    dt_w, lat_w, got_w, times_w, _ = proof1_run(keys_w, dev_index, salts, await_rounds=True, msm_in_stream=True)
+    lock_w = proofs.LockstepBatch(keys_w, group=P, devices=[dev_index])
+    lock_w.run(salts)
+    _lib.check(L.snarkvm_hip_synchronize())
+    t0 = time.perf_counter()
+    _, got_lw = lock_w.run(salts, collect=True)
+    _lib.check(L.snarkvm_hip_synchronize())
+    dt_lw = time.perf_counter() - t0
+    del lock_w
+    torch.cuda.empty_cache()
+    if [proofs.normalize_results(r) for r in got_w] != [proofs.normalize_results(r) for r in got_lw]:
+        raise SystemExit("bench.py: proof legs (witness-like pool): the one-at-a-time replay and the lock-step replay differ")
+    if with_oracle:
+        oracle_check_proof(keys_w, shape, got_w[salts[-1]], salts[-1])
+    wl_check = f"all {P} proofs x 15 results identical in the one-at-a-time and the lock-step replay" + (f"; proof {salts[-1]}: all 15 results == oracle/proof_replay.py" if with_oracle else "")
+    out["proof1"]["witness_like"] = {"ms_per_proof": dt_w / P * 1e3, "value": P / dt_w, "unit": "proofs/s", "over_uniform": (P / dt_w) / out["proof1"]["value"], "checks": wl_check}
+    out["proofs64"]["witness_like"] = {"ms_per_proof": dt_lw / P * 1e3, "value": P / dt_lw, "unit": "proofs/s", "over_uniform": (P / dt_lw) / out["proofs64"]["value"], "checks": wl_check}
+    keys_w.close()
     # ---- concurrent callers: 8 threads, one MSM of 2^16 pairs per call, device-resident Montgomery scalars
     T, calls, n = 8, 24, 1 << shape.lg_r
     pool = torch.from_numpy(keys.pool_host.view(np.int64).reshape(-1)).cuda()
@@ -977,7 +1160,7 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
 
     shape = proofs.ProofShape()
     ptab, pbits = (int(v) for v in args.proof_geometry.split("x"))
-    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits)
+    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits, scalars=args.scalars)
     mine = list(range(rank, args.proofs, world))
     checks = {}
     # ---- lock step
@@ -1073,7 +1256,7 @@ def proofs64(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_
             "config": {"workload": "64 x (14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM); "
                                    "device-resident random data, transfer_private domain sizes; lock-step batch (prove_batch shape)",
                        "proofs": args.proofs, "lockstep_group": min(args.proof_group, max(1, len(mine))), "proofs_per_rank": len(mine),
-                       "registered_srs": f"{ptab} tables x {pbits}-bit windows",
+                       "registered_srs": f"{ptab} tables x {pbits}-bit windows", "pool_values": args.scalars,
                        "lockstep_form": "one SNARKVM_HIP_SCOPE_ASYNC_MSM scope per group" if args.lockstep_async else "a scope per step, synchronous commitment calls"},
             "g1_pairs_per_s": args.proofs * shape.pairs() / dt_lock,
             "g2_pairs_per_s": args.proofs * (1 << shape.lg_g2) / dt_lock,

@@ -72,7 +72,10 @@ RustError snarkvm_msm(void *out, const void *points_with_infinity, size_t npoint
  * (kzg10/mod.rs:117-119).  By setting the variable the caller promises that such vectors are immutable while the process
  * uses them (a hit is verified against raw copies of every 64th point of the slice, which cannot catch every mutation);
  * host memory is only read inside the slice the current call passed.  SNARKVM_HIP_BASE_CACHE_MB caps the HBM bytes per device
- * (default 65536).  Code that can be changed should call snarkvm_hip_register_bases* + snarkvm_hip_msm_registered*. */
+ * (default 65536).  Code that can be changed should call snarkvm_hip_register_bases* + snarkvm_hip_msm_registered*.
+ * snarkvm_hip_set_base_cache(tables) is the API form of the variable (0, 1, 2, 4, 8 or 16; overrides the environment from then on; 0 also drops
+ * every cached range) - for a host that cannot set the environment before the library is loaded. */
+RustError snarkvm_hip_set_base_cache(int tables);
 
 /* ---------------------------------------------------------------------------------------------
  * Part 2 - extension ABI (device-resident data, SRS registration, instrumentation)
@@ -94,6 +97,23 @@ RustError snarkvm_hip_set_devices(const int32_t *ids, size_t n);
 RustError snarkvm_hip_set_device(int device);
 int snarkvm_hip_num_devices(void);
 
+/* Device memory for a host that has no HIP binding of its own (a Rust prover that keeps its polynomials in HBM between the transforms
+ * and the commitments; the reference's plugin owns every device byte itself, snarkvm.cu:51,123-151): what the device-resident entry
+ * points below take as `d_*` pointers.  `device` of snarkvm_hip_malloc: index into the devices in use (snarkvm_hip_set_devices), or -1 =
+ * the device of the calling thread's open scope, logical device 0 outside a scope.  Blocks are NOT counted by snarkvm_hip_alloc_stats (that
+ * reports the library's own workspace growth).  snarkvm_hip_free waits for all queued work of the device first (hipFree).
+ * Copies with a HOST side (h2d, d2h) return when the copy is complete: `src` may be reused, `dst` may be read.  Inside a scope of the
+ * calling thread they are ordered behind the work the scope has queued on its stream (and wait for that, not for the scope's enqueued MSMs).
+ * snarkvm_hip_memcpy_d2d and snarkvm_hip_memset are device-side operations like the snarkvm_hip_fr_* kernels: inside a scope they are only
+ * enqueued on the scope's stream, in call order ("the prover produced a polynomial"); outside a scope they return when done.  d2d ranges
+ * must not overlap; the two pointers may live on different devices in use. */
+RustError snarkvm_hip_malloc(void **d_ptr, size_t bytes, int device);
+RustError snarkvm_hip_free(void *d_ptr);
+RustError snarkvm_hip_memcpy_h2d(void *d_dst, const void *src, size_t bytes);
+RustError snarkvm_hip_memcpy_d2h(void *dst, const void *d_src, size_t bytes);
+RustError snarkvm_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes);
+RustError snarkvm_hip_memset(void *d_dst, int value, size_t bytes);
+
 /* Same as snarkvm_ntt but `d_inout` is device memory (the call runs on the device that owns it). */
 RustError snarkvm_hip_ntt_device(void *d_inout, uint32_t lg_domain_size, int ntt_order, int ntt_direction,
                                  int ntt_type);
@@ -107,8 +127,8 @@ RustError snarkvm_hip_ntt_device_batch(void *const *d_inouts, size_t count, uint
 
 /* Deferred synchronisation for device-resident operands.  Between snarkvm_hip_scope_begin (d_any: any device pointer on the GPU
  * to use, or NULL for any GPU) and snarkvm_hip_scope_end, calls of THIS thread whose operands and results live in device memory
- * - snarkvm_hip_ntt_device, _ntt_device_batch, _fr_mul_device, _fr_convert_device and the snarkvm_hip_fr_* vector kernels with
- * on_device = 1 - are enqueued on one stream, in call order, and return without waiting; snarkvm_hip_scope_end waits once.  The
+ * - snarkvm_hip_ntt_device, _ntt_device_batch, _fr_mul_device, _fr_convert_device, _memcpy_d2d, _memset and the snarkvm_hip_fr_* vector
+ * kernels with on_device = 1 - are enqueued on one stream, in call order, and return without waiting; snarkvm_hip_scope_end waits once.  The
  * 32-byte host `remainder` of snarkvm_hip_fr_divide_by_linear with on_device = 1 is delivered by scope_end.  Every other call (MSMs,
  * host buffers, a pointer on another GPU) first waits for the scope's queued work, so results are the same as without a scope - and
  * then runs on the scope's own stream: a thread inside a scope never waits for a free stream.  Scopes do not nest; a scope must be
@@ -280,7 +300,8 @@ RustError snarkvm_hip_fr_vec_op(int op, void *out, const void *a, const void *b,
                                 size_t n, int on_device);
 /* `polynomial / (X - point)` and `polynomial.evaluate(point)` in one pass (KZG10::compute_witness_polynomial,
  * kzg10/mod.rs:213-236 via polynomial/mod.rs:222-256; DensePolynomial::evaluate, dense.rs:98-114): quotient gets
- * n - 1 coefficients (may be NULL when only the value is wanted), *remainder = p(point). */
+ * n - 1 coefficients (may be NULL when only the value is wanted), *remainder = p(point).  With on_device = 1 `quotient` must not
+ * overlap `poly` (coefficient ranges are owned by different workgroups: an in-place division would race); such a call is refused. */
 RustError snarkvm_hip_fr_divide_by_linear(void *quotient, void *remainder, const void *poly, size_t n,
                                           const void *point, int on_device);
 /* batch_inversion_and_mul (fields/src/lib.rs:66-129): v_i <- coeff / v_i, zero elements stay zero. */

@@ -101,6 +101,60 @@ private:
     bool open_ = true;
 };
 
+// Device memory owned through the library (snarkvm_hip_malloc / _free / _memcpy_*; rust: resident::DeviceBuffer): the operands of every `d_*`
+// argument of the extension ABI without a HIP header on the caller's side.  Host-side copies are complete on return; copy_from() / fill() inside a
+// Scope are only enqueued on the scope's stream.  Not copyable; movable.
+class DeviceBuffer {
+public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes, int device = -1) : bytes_(bytes) { check(snarkvm_hip_malloc(&p_, bytes, device)); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr, o.bytes_ = 0; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+        if (this != &o) {
+            release();
+            p_ = o.p_, bytes_ = o.bytes_;
+            o.p_ = nullptr, o.bytes_ = 0;
+        }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    void* data() const { return p_; }
+    size_t size() const { return bytes_; }
+    void* at(size_t byte_offset) const {
+        if (byte_offset > bytes_) throw std::out_of_range("DeviceBuffer::at");
+        return static_cast<char*>(p_) + byte_offset;
+    }
+    void upload(const void* src, size_t bytes, size_t byte_offset = 0) const {
+        if (byte_offset + bytes > bytes_) throw std::out_of_range("DeviceBuffer::upload");
+        check(snarkvm_hip_memcpy_h2d(at(byte_offset), src, bytes));
+    }
+    void download(void* dst, size_t bytes, size_t byte_offset = 0) const {
+        if (byte_offset + bytes > bytes_) throw std::out_of_range("DeviceBuffer::download");
+        check(snarkvm_hip_memcpy_d2h(dst, at(byte_offset), bytes));
+    }
+    void copy_from(size_t byte_offset, const void* d_src, size_t bytes) const {
+        if (byte_offset + bytes > bytes_) throw std::out_of_range("DeviceBuffer::copy_from");
+        check(snarkvm_hip_memcpy_d2d(at(byte_offset), d_src, bytes));
+    }
+    void fill(size_t byte_offset, int value, size_t bytes) const {
+        if (byte_offset + bytes > bytes_) throw std::out_of_range("DeviceBuffer::fill");
+        check(snarkvm_hip_memset(at(byte_offset), value, bytes));
+    }
+
+private:
+    void release() {
+        if (p_) {
+            RustError e = snarkvm_hip_free(p_);
+            if (e.message) std::free(e.message);
+            p_ = nullptr;
+        }
+    }
+    void* p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
 // Registered bases (an SRS resident in HBM with precomputed window tables): register once, commit per call.  `tables` x
 // `window_bits` must cover 254 bits (17 x 15 for proof-sized MSMs, 12 x 22 at 2^24).  Concurrent commit() calls of proof size
 // are fused inside the library (runtime.hip.h::msm_coalesced).
@@ -116,6 +170,7 @@ public:
         if (h_) snarkvm_hip_free_bases(h_);
     }
     size_t size() const { return n_; }
+    const snarkvm_hip_bases_t* handle() const { return h_; }  // for the raw snarkvm_hip_msm_registered* calls (device-resident scalars, batches)
     // sum_i scalars[i] * bases[offset + i]  (+ sum_j scalars[n + j] * bases[offset1 + j] when n1 > 0: KZG10's hiding term)
     Projective commit(size_t offset, size_t n, const void* scalars, bool scalars_on_device, bool scalars_montgomery = false, size_t offset1 = 0,
                       size_t n1 = 0) const {

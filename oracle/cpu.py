@@ -37,6 +37,33 @@ def build(force=False):
 
 
 _lib = None
+BUILD_FLAGS = "-O3 -march=x86-64-v3 (portable: compiled in the build container, shipped prebuilt)"
+
+
+def use_native():
+    """bench.py's cpu_baseline leg times the restatement on the GPU box's host cores: compile it THERE with -march=native (BASELINE.md 3 promises that for the
+    CPU column; the shipped liboracle.so is -march=x86-64-v3 because it is built in another container) into a temporary directory - never in-tree, a native
+    build must not travel to another machine - and make it the library this process uses.  Must be called before the first oracle call; falls back to the
+    shipped build (and says so in BUILD_FLAGS) when no compiler is at hand.  Returns the flags in effect."""
+    global _lib, _LIB_PATH, BUILD_FLAGS
+    if _lib is not None:
+        return BUILD_FLAGS
+    import tempfile
+
+    out_dir = os.path.join(tempfile.gettempdir(), f"oracle_native_{os.getuid()}")
+    out = os.path.join(out_dir, "liboracle.so")
+    src = os.path.join(_HERE, "cpu_oracle.cpp")
+    try:
+        os.makedirs(out_dir, mode=0o700, exist_ok=True)
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp", "-Wno-unused-function", "-shared", "-o", out + ".tmp", src],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            os.replace(out + ".tmp", out)
+        _LIB_PATH = out
+        BUILD_FLAGS = "-O3 -march=native (compiled on this host by oracle.use_native())"
+    except Exception as e:  # noqa: BLE001
+        BUILD_FLAGS += f"; native rebuild failed: {type(e).__name__}"
+    return BUILD_FLAGS
 
 
 def lib():

@@ -11,8 +11,9 @@ LIB_PATH = os.environ.get("SNARKVM_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 # every symbol include/snarkvm_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm",
-    "snarkvm_hip_device_count", "snarkvm_hip_batch_lanes", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_num_devices", "snarkvm_hip_ntt_device", "snarkvm_hip_ntt_device_batch",
+    "snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_base_cache",
+    "snarkvm_hip_device_count", "snarkvm_hip_batch_lanes", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_num_devices",
+    "snarkvm_hip_malloc", "snarkvm_hip_free", "snarkvm_hip_memcpy_h2d", "snarkvm_hip_memcpy_d2h", "snarkvm_hip_memcpy_d2d", "snarkvm_hip_memset", "snarkvm_hip_ntt_device", "snarkvm_hip_ntt_device_batch",
     "snarkvm_hip_scope_begin", "snarkvm_hip_scope_end", "snarkvm_hip_scope_begin_ex", "snarkvm_hip_scope_collect", "snarkvm_hip_scope_set_flags", "snarkvm_hip_scope_stream", "snarkvm_hip_alloc_stats",
     "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_free_bases", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2",
     "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine",
@@ -56,12 +57,16 @@ def lib():
         # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.
         # If torch is installed, load it first so that this library binds to the runtime that is already in the
         # process (same SONAME); two runtimes in one process leave the second one without visible GPUs.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # SNARKVM_HIP_NO_TORCH=1: a torch-free host (tests/test_gpu_devmem.py proves a whole proof's call list that way): the library then binds to the
+        # HIP runtime of /opt/rocm like any C++ / Rust caller's process does.
+        if not os.environ.get("SNARKVM_HIP_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = ctypes.CDLL(LIB_PATH)
-        err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_device", "snarkvm_hip_set_devices", "snarkvm_hip_ntt_device", "snarkvm_hip_ntt_device_batch",
+        err_fns = ["snarkvm_ntt", "snarkvm_polymul", "snarkvm_msm", "snarkvm_hip_set_base_cache", "snarkvm_hip_set_device", "snarkvm_hip_set_devices",
+                   "snarkvm_hip_malloc", "snarkvm_hip_free", "snarkvm_hip_memcpy_h2d", "snarkvm_hip_memcpy_d2h", "snarkvm_hip_memcpy_d2d", "snarkvm_hip_memset", "snarkvm_hip_ntt_device", "snarkvm_hip_ntt_device_batch",
                    "snarkvm_hip_scope_begin", "snarkvm_hip_scope_end", "snarkvm_hip_scope_begin_ex", "snarkvm_hip_scope_collect", "snarkvm_hip_scope_set_flags",
                    "snarkvm_hip_register_bases", "snarkvm_hip_register_bases_tables", "snarkvm_hip_register_bases_windowed", "snarkvm_hip_msm_registered", "snarkvm_hip_msm_g2", "snarkvm_hip_msm_registered_ex", "snarkvm_hip_msm_registered_batch", "snarkvm_hip_msm_registered_batch_ex", "snarkvm_hip_g1_to_affine", "snarkvm_hip_fr_mul_device",
                    "snarkvm_hip_fr_convert_device", "snarkvm_hip_g1_generate_bases_device", "snarkvm_hip_synchronize",
@@ -96,6 +101,12 @@ def lib():
         L.snarkvm_hip_scope_stream.restype = ctypes.c_void_p
         L.snarkvm_hip_scope_begin_ex.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         L.snarkvm_hip_scope_set_flags.argtypes = [ctypes.c_uint32]
+        L.snarkvm_hip_malloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_int]
+        L.snarkvm_hip_free.argtypes = [ctypes.c_void_p]
+        L.snarkvm_hip_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.snarkvm_hip_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.snarkvm_hip_memcpy_d2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.snarkvm_hip_memset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
         _libc = ctypes.CDLL(None)
         _libc.free.argtypes = [ctypes.c_void_p]
         _lib = L

@@ -37,22 +37,22 @@ void sv_alloc_note(int slot, size_t bytes, double ms) {
     g_alloc_stats[4].fetch_add((uint64_t)(ms * 1e3), std::memory_order_relaxed);
 }
 
-static std::mutex g_free_mu;
-static std::vector<void*> g_free_list;
-static std::atomic<size_t> g_free_pending{0};
-void sv_defer_free(void* p) {
-    std::lock_guard<std::mutex> lk(g_free_mu);
-    g_free_list.push_back(p);
-    g_free_pending.store(g_free_list.size(), std::memory_order_relaxed);
-}
-void sv_drain_frees() {
-    if (!g_free_pending.load(std::memory_order_relaxed)) return;  // the common case: one relaxed load per call
-    std::vector<void*> mine;
-    {
-        std::lock_guard<std::mutex> lk(g_free_mu);
-        mine.swap(g_free_list);
-        g_free_pending.store(0, std::memory_order_relaxed);
+// Outgrown workspace blocks (runtime.hip.h: sv_defer_free) wait on a list of the THREAD that outgrew them and are released when that thread's call ends
+// (lane_t::end_call) or its scope is flushed.  (Round 5 kept one process-wide list that every lane's end_call drained: hipFree waits for every stream
+// of the device, so a short call of thread B inherited the wait for thread A's whole queued scope - the stall the deferral exists to avoid, moved to
+// another caller.)  A thread that ends with blocks still parked releases them in the list's destructor.
+struct tl_free_list_t {
+    std::vector<void*> v;
+    ~tl_free_list_t() {
+        for (void* p : v) (void)hipFree(p);
     }
+};
+static thread_local tl_free_list_t g_tl_free;
+void sv_defer_free(void* p) { g_tl_free.v.push_back(p); }
+void sv_drain_frees() {
+    if (g_tl_free.v.empty()) return;
+    std::vector<void*> mine;
+    mine.swap(g_tl_free.v);
     for (void* p : mine) (void)hipFree(p);  // hipFree takes a pointer of any device
 }
 
@@ -133,6 +133,73 @@ RustError snarkvm_hip_synchronize(void) {
     }
     (void)hipSetDevice(prev);
     API_CATCH
+}
+
+// ---- device memory for hosts without a HIP binding (a Rust prover) ---------------------------------------------
+// Plain hipMalloc / hipFree / copies behind the C ABI, so that the device-resident entry points can be fed without torch or a HIP crate
+// on the caller's side.  Copies run on a lane like every other call: inside the calling thread's scope that is the scope's own stream
+// (ordered with its transforms), outside a scope any free lane of the device that owns the device pointer.
+RustError snarkvm_hip_malloc(void** d_ptr, size_t bytes, int device) {
+    API_TRY
+    if (!d_ptr) throw hip_failure{hipErrorInvalidValue, "snarkvm_hip_malloc: null result pointer", __LINE__};
+    *d_ptr = nullptr;
+    g_rt.configure();
+    lane_t* sl = tl_scope().lane;
+    if (device < 0) device = sl ? sl->dev->logical : 0;
+    if (device >= (int)g_rt.devs.size()) throw hip_failure{hipErrorInvalidDevice, "snarkvm_hip_malloc: logical device index out of range", __LINE__};
+    if (bytes) {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        const int phys = g_rt.devs[device]->physical;
+        if (prev != phys) HIP_TRY(hipSetDevice(phys));
+        const hipError_t e = hipMalloc(d_ptr, bytes);
+        if (prev >= 0 && prev != phys) (void)hipSetDevice(prev);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            *d_ptr = nullptr;
+            throw hip_failure{e, "snarkvm_hip_malloc: hipMalloc", __LINE__};
+        }
+    }
+    API_CATCH
+}
+RustError snarkvm_hip_free(void* d_ptr) {
+    API_TRY
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));  // waits for every stream of the owning device: nothing queued can still use the block
+    API_CATCH
+}
+RustError snarkvm_hip_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
+    if (!bytes) return ok();
+    API_BEGIN_DEV(device_for(d_dst, 1))
+    if (!d_dst || !src) throw hip_failure{hipErrorInvalidValue, "snarkvm_hip_memcpy_h2d: null pointer", __LINE__};
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));  // host side: complete on return, also inside a scope (header)
+    API_END
+}
+RustError snarkvm_hip_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
+    if (!bytes) return ok();
+    API_BEGIN_DEV(device_for(d_src, 1))
+    if (!dst || !d_src) throw hip_failure{hipErrorInvalidValue, "snarkvm_hip_memcpy_d2h: null pointer", __LINE__};
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    API_END
+}
+RustError snarkvm_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
+    if (!bytes) return ok();
+    API_BEGIN_DEV(device_for(d_dst, 1))
+    if (!d_dst || !d_src) throw hip_failure{hipErrorInvalidValue, "snarkvm_hip_memcpy_d2d: null pointer", __LINE__};
+    const uint8_t *a = (const uint8_t*)d_dst, *b = (const uint8_t*)d_src;
+    if (a < b + bytes && b < a + bytes) throw hip_failure{hipErrorInvalidValue, "snarkvm_hip_memcpy_d2d: the ranges overlap", __LINE__};
+    if (g_rt.device_of(d_src) < 0) throw hip_failure{hipErrorInvalidValue, "snarkvm_hip_memcpy_d2d: source is not on a device in use", __LINE__};
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDefault, c.stream));
+    c.sync_or_defer();
+    API_END
+}
+RustError snarkvm_hip_memset(void* d_dst, int value, size_t bytes) {
+    if (!bytes) return ok();
+    API_BEGIN_DEV(device_for(d_dst, 1))
+    HIP_TRY(hipMemsetAsync(d_dst, value, bytes, c.stream));
+    c.sync_or_defer();
+    API_END
 }
 
 // ---- deferred-synchronisation scope ---------------------------------------------------------------------
@@ -575,8 +642,11 @@ static constexpr size_t CACHE_STEP = 64, CACHE_MAX = 8;
 static std::mutex g_cache_mu;
 static std::vector<base_cache_entry> g_base_cache;
 static uint64_t g_cache_tick = 0;
+static std::atomic<int> g_base_cache_override{-1};  // snarkvm_hip_set_base_cache: >= 0 replaces the environment's value
 static int base_cache_tables() {
-    static const int t = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 0;  // off unless asked for
+    static const int env = getenv("SNARKVM_HIP_BASE_CACHE") ? atoi(getenv("SNARKVM_HIP_BASE_CACHE")) : 0;  // off unless asked for
+    const int o = g_base_cache_override.load(std::memory_order_relaxed);
+    const int t = o >= 0 ? o : env;
     return (t == 1 || t == 2 || t == 4 || t == 8 || t == 16) ? t : 0;
 }
 static size_t base_cache_cap() {
@@ -662,6 +732,22 @@ static std::shared_ptr<snarkvm_hip_bases> base_cache_lookup(const void* points, 
     e.last_use = ++g_cache_tick;
     g_base_cache.push_back(std::move(e));
     return nullptr;
+}
+
+// The API form of SNARKVM_HIP_BASE_CACHE (a host that cannot set the environment before the library is loaded; A/B runs in one process).
+// 0 also drops every cached range (calls in flight keep the tables they hold until they return).
+RustError snarkvm_hip_set_base_cache(int tables) {
+    if (!(tables == 0 || tables == 1 || tables == 2 || tables == 4 || tables == 8 || tables == 16)) return fail(1, "snarkvm_hip_set_base_cache: tables must be 0, 1, 2, 4, 8 or 16");
+    g_base_cache_override.store(tables, std::memory_order_relaxed);
+    if (tables == 0) {
+        std::vector<base_cache_entry> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            drop.swap(g_base_cache);
+        }
+        // the entries' tables are freed here, outside the lock (hipFree waits for the device)
+    }
+    return ok();
 }
 
 RustError snarkvm_msm(void* out, const void* points, size_t npoints, const void* scalars, size_t ffi_affine_sz) {

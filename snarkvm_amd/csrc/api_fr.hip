@@ -342,6 +342,11 @@ static RustError fr_divide_by_linear_impl(void* quotient, void* remainder, const
     API_BEGIN_DEV(device_for(poly, (on_device && n) ? 1 : 0))
     if (!point || (n && !poly)) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_linear: missing operand", __LINE__};
     check_strided(n, count, stride, on_device, "fr_divide_by_linear");
+    if (on_device && quotient && n > 1) {  // header: different workgroups own adjacent coefficient ranges - an in-place division would race
+        const size_t span = sizeof(fr_mem_t) * ((count - 1) * stride + n);
+        const uint8_t *q = (const uint8_t*)quotient, *p = (const uint8_t*)poly;
+        if (q < p + span && p < q + span) throw hip_failure{hipErrorInvalidValue, "fr_divide_by_linear: quotient overlaps poly (device operands must not alias)", __LINE__};
+    }
     if (n == 0) {
         if (remainder) memset(remainder, 0, sizeof(fr_mem_t) * count);
     } else {

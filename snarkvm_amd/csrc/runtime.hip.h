@@ -80,8 +80,8 @@ void sv_alloc_note(int slot, size_t bytes, double ms);  // api.hip: the process-
 // A buffer that is outgrown in the middle of a call is not freed on the spot: hipFree returns only when EVERY stream of the device is
 // idle (measured: 281 ms behind ~280 ms of kernels queued on another stream, tools/tables1_cliff.py), i.e. the second instance of a
 // pipelined batch would only be enqueued after the first one had finished, and a caller on another lane would stall behind this one.
-// The old block goes to a process-wide list and is released by sv_drain_frees() when a call ends (lane_t::end_call, scope flush), or at
-// once when an allocation fails.  (Round 4's "tables1" bench leg had six such frees inside its timed region; whether they were what
+// The old block goes to a list of the calling thread and is released by sv_drain_frees() when that thread's call ends (lane_t::end_call, scope flush),
+// or at once when an allocation fails.  Inside a long scope an outgrown block therefore stays allocated beside its replacement until the flush.  (Round 4's "tables1" bench leg had six such frees inside its timed region; whether they were what
 // the driver's 93.6 ms per step came from could not be reproduced - profiles/r05_summary.md.)
 void sv_defer_free(void* p);
 void sv_drain_frees();
@@ -1337,6 +1337,9 @@ template <class F>
 static void msm_run_sync(lane_t& c, const aff_mem_t<F>* d_bases, const uint4* d_scalars, size_t n, void* out, int window_bits,
                          const aff_mem_t<F>* d_bases1 = nullptr, size_t n0 = ~(size_t)0, int scalars_montgomery = 0, int tables = 1,
                          size_t table_stride = 0, int table_bits = 0) {
+    // A lane borrowed from the calling thread's scope: MSMs the scope enqueued on it (in-stream, or with no further lane free) keep their bit planes in
+    // `pin` from offset 0 until the scope's flush has read them - this call stages at offset 0 too (and ensure() may move the block): deliver them first.
+    if (c.in_scope && c.pin_used) scope_flush();
     c.pin.ensure(msm_plane_bytes<F>());
     const msm_pending_t pd = msm_run<F>(c, d_bases, d_scalars, n, c.pin.p, window_bits, d_bases1, n0, scalars_montgomery, tables, table_stride, true, table_bits);
     HIP_TRY(hipStreamSynchronize(c.stream));
@@ -1938,19 +1941,33 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
         HIP_TRY(hipEventRecord(ready, sc.lane->stream));
         HIP_TRY(hipStreamWaitEvent(c.stream, ready, 0));
     }
-    for (const auto& j : jobs) {
-        size_t pb, tb;
-        msm_job_staging(h, j, pb, tb);
-        uint8_t* planes = c.pin.template as<uint8_t>() + c.pin_used;
-        msm_inst_t* tab = (msm_inst_t*)(planes + pb);
-        c.pin_used += pb + tb;
-        // SNARKVM_HIP_SCOPE_STABLE_INPUTS: the caller leaves the scalar vectors alone until the scope ends - the scope's stream does not wait
-        hipEvent_t read = (&c != sc.lane && !(sc.flags & SNARKVM_HIP_SCOPE_STABLE_INPUTS)) ? c.scope_event() : nullptr;
-        const msm_pending_t pd = msm_enqueue_job<F>(c, h, d->logical, rq->data(), j, planes, tab, 1, scalars_montgomery, window_bits, read);
-        if (read) HIP_TRY(hipStreamWaitEvent(sc.lane->stream, read, 0));
-        hipEvent_t done = c.scope_event();
-        HIP_TRY(hipEventRecord(done, c.stream));
-        sc.pending.push_back(scope_pending_t{done, [rq, j, pd] { msm_finish_job<F>(rq->data(), j, pd, 4); }, req[0].out});
+    // All or nothing: a failure on job k > 0 must not leave jobs 0 .. k-1 pending - the caller sees an error and may free or reuse the `out`
+    // buffers their finishes would write at scope_end.  What this call added is taken back (after the lanes have drained: the kernels already
+    // enqueued write into the staging that is being handed back).
+    const size_t pending0 = sc.pending.size(), pin0 = c.pin_used, ev0 = c.scope_events_used;
+    try {
+        for (const auto& j : jobs) {
+            size_t pb, tb;
+            msm_job_staging(h, j, pb, tb);
+            uint8_t* planes = c.pin.template as<uint8_t>() + c.pin_used;
+            msm_inst_t* tab = (msm_inst_t*)(planes + pb);
+            c.pin_used += pb + tb;
+            // SNARKVM_HIP_SCOPE_STABLE_INPUTS: the caller leaves the scalar vectors alone until the scope ends - the scope's stream does not wait
+            hipEvent_t read = (&c != sc.lane && !(sc.flags & SNARKVM_HIP_SCOPE_STABLE_INPUTS)) ? c.scope_event() : nullptr;
+            const msm_pending_t pd = msm_enqueue_job<F>(c, h, d->logical, rq->data(), j, planes, tab, 1, scalars_montgomery, window_bits, read);
+            if (read) HIP_TRY(hipStreamWaitEvent(sc.lane->stream, read, 0));
+            hipEvent_t done = c.scope_event();
+            HIP_TRY(hipEventRecord(done, c.stream));
+            sc.pending.push_back(scope_pending_t{done, [rq, j, pd] { msm_finish_job<F>(rq->data(), j, pd, 4); }, req[0].out});
+        }
+    } catch (...) {
+        (void)hipStreamSynchronize(c.stream);
+        if (&c != sc.lane) (void)hipStreamSynchronize(sc.lane->stream);
+        (void)hipGetLastError();
+        sc.pending.erase(sc.pending.begin() + (ptrdiff_t)pending0, sc.pending.end());
+        c.pin_used = pin0;
+        c.scope_events_used = ev0;  // only this call's "read" / "done" marks were taken from c's pool since ev0, and c has drained
+        throw;
     }
     return true;
 }

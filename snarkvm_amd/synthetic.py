@@ -63,6 +63,32 @@ def witness_like_scalars(n, seed):
     return s
 
 
+def witness_like_from(scalars, seed):
+    """The witness-like distribution laid over an existing uniform vector (same shape): entry i keeps its value, becomes zero or keeps only its low 16 bits -
+    the selector of `witness_like_scalars`.  For vectors that already exist on the host (bench.py derives its second distribution from the seeded one)."""
+    s = np.array(scalars, dtype=np.uint64, copy=True).reshape(-1, 4)
+    sel = splitmix64(seed ^ 0xA5A5, s.shape[0]) % np.uint64(4)
+    s[sel < 2] = 0
+    small = sel == 2
+    s[small, 1:] = 0
+    s[small, 0] &= np.uint64(0xFFFF)
+    return s
+
+
+def witness_like_fr_montgomery(n, seed):
+    """(n,4) u64 `Fr` memory images (Montgomery form, R = 2^256) whose VALUES follow the witness-like distribution: what a prover's witness-shaped
+    coefficient vector looks like to a commitment that fuses `to_bigint` (scalars_montgomery = 1).  Python integers: meant for pools of <= 2^20 elements."""
+    w = witness_like_scalars(n, seed)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    nz = np.flatnonzero(w.any(axis=1))
+    R = (1 << 256) % R_MOD
+    mask = (1 << 64) - 1
+    for i in nz:
+        v = (int(w[i, 0]) | (int(w[i, 1]) << 64) | (int(w[i, 2]) << 128) | (int(w[i, 3]) << 192)) * R % R_MOD
+        out[i] = (v & mask, (v >> 64) & mask, (v >> 128) & mask, v >> 192)
+    return out
+
+
 # ------------------------------------------------------------------------------------------ G2 base sets
 Q_MOD = 258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177
 # G2 generator, canonical coordinates (x = x0 + x1 u, y = y0 + y1 u over Fq[u]/(u^2 + 5); curves/src/bls12_377/g2.rs:237-315)

@@ -86,6 +86,27 @@ int main(int argc, char** argv) {
             Fr zero{};
             std::vector<Fr> prod = snarkvm_hip::polymul<Fr>(fr.size(), polys, {}, zero);
             write_all(dir + "/polymul.bin", prod.data(), prod.size());
+            // the same transform and a commitment over DEVICE-resident operands, every device byte owned through the library (DeviceBuffer:
+            // snarkvm_hip_malloc / _memcpy_*), inside a scope: no HIP header, no torch in this process
+            snarkvm_hip::DeviceBuffer d_fr(fr.size() * sizeof(Fr)), d_pad(2 * fr.size() * sizeof(Fr)), d_sc(scalars.size() * sizeof(Fr));
+            d_fr.upload(fr.data(), d_fr.size());
+            d_sc.upload(scalars.data(), d_sc.size());
+            snarkvm_hip::RegisteredBases<G1Affine, G1Projective> rb(bases.data(), bases.size(), false, 17, 15);
+            G1Projective c{};
+            uint32_t lg = 0;
+            while (((size_t)1 << lg) < fr.size()) lg++;
+            {
+                snarkvm_hip::Scope scope(d_fr.data(), SNARKVM_HIP_SCOPE_ASYNC_MSM);
+                d_pad.fill(0, 0, d_pad.size());
+                d_pad.copy_from(0, d_fr.data(), d_fr.size());
+                snarkvm_hip::check(snarkvm_hip_ntt_device(d_pad.data(), lg + 1, NN, Forward, Standard));
+                snarkvm_hip::check(snarkvm_hip_msm_registered_ex(&c, rb.handle(), 0, scalars.size(), 0, 0, d_sc.data(), 1, 0, 0));  // enqueued: written by end()
+                scope.end();
+            }
+            std::vector<Fr> xd(2 * fr.size());
+            d_pad.download(xd.data(), d_pad.size());
+            write_all(dir + "/ntt_dev.bin", xd.data(), xd.size());
+            write_all(dir + "/msm_dev.bin", &c, 1);
         } catch (const snarkvm_hip::Error& e) {
             std::cerr << "snarkvm_hip::Error " << e.code << ": " << e.what() << std::endl;
             return 2;

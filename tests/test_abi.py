@@ -21,6 +21,62 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def _rust_width(t):
+    """Width class of a Rust FFI type as written in sys.rs (the twin of tools/gen_bindings.py::width_class on the C side)."""
+    t = t.strip()
+    depth = 0
+    while t.startswith("*"):
+        t = re.sub(r"^\*(const|mut)\s+", "", t)
+        depth += 1
+    if depth:
+        return ("ptr", depth)
+    if t == "Error":
+        return ("err",)
+    if t in ("NTTInputOutputOrder", "NTTDirection", "NTTType"):
+        return ("int", 4)  # #[repr(C)] enums
+    return {"usize": ("int", 8), "i32": ("int", 4), "u32": ("int", 4), "u64": ("int", 8), "f64": ("f64",)}[t]
+
+
+def test_rust_sys_matches_the_header():
+    """rust/snarkvm-algorithms-hip/src/sys.rs against include/snarkvm_hip.h: every declared function present (and nothing else), the same number
+    of arguments, the same width class per argument and for the result, pointer depth included; the three #[repr(C)] enums of lib.rs carry the
+    header's discriminants; and the committed file is exactly what tools/gen_bindings.py yields today."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_bindings", os.path.join(util.ROOT, "tools", "gen_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    funcs, consts = gen.parse_header()
+    c_side = {f["name"]: f for f in funcs}
+    assert set(c_side) == set(_lib.SYMBOLS)  # the header parser sees what the ctypes table lists
+    rust_dir = os.path.join(util.ROOT, "rust", "snarkvm-algorithms-hip", "src")
+    sys_rs = open(os.path.join(rust_dir, "sys.rs")).read()
+    block = sys_rs[sys_rs.index('extern "C" {') :]
+    rust_side = {}
+    for m in re.finditer(r"pub fn (\w+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block):
+        args = [a.split(":", 1) for a in m.group(2).split(",") if a.strip()]
+        rust_side[m.group(1)] = ([(n.strip(), _rust_width(t)) for n, t in args], _rust_width(m.group(3)) if m.group(3) else ("void",))
+    assert set(rust_side) == set(c_side), set(rust_side) ^ set(c_side)
+    for name, f in c_side.items():
+        r_args, r_ret = rust_side[name]
+        assert len(r_args) == len(f["args"]), name
+        for (rn, rw), (cn, ct) in zip(r_args, f["args"]):
+            assert rw == gen.width_class(ct), (name, cn, rw, ct)
+        assert r_ret == gen.width_class(f["ret"]), name
+    lib_rs = open(os.path.join(rust_dir, "lib.rs")).read()
+    assert "pub mod sys;" in lib_rs and 'extern "C"' not in lib_rs  # no second, hand-written declaration block
+    for enum in ("NTTInputOutputOrder", "NTTDirection", "NTTType"):
+        body = re.search(r"#\[repr\(C\)\][^{]*pub enum " + enum + r"\s*\{([^}]*)\}", lib_rs).group(1)
+        for k, v in re.findall(r"(\w+)\s*=\s*(\d+)", body):
+            assert consts[k] == int(v), (enum, k)
+    for k in ("SNARKVM_HIP_SCOPE_ASYNC_MSM", "SNARKVM_HIP_SCOPE_STABLE_INPUTS", "SNARKVM_HIP_SCOPE_MSM_IN_STREAM"):
+        assert re.search(rf"pub const {k}: u32 = {consts[k]};", sys_rs), k
+    # every sys:: item the hand-written wrappers (and INTEGRATION.md's sketches) name is a declared one
+    used = set(re.findall(r"sys::(snarkvm_\w+)", lib_rs + open(os.path.join(util.ROOT, "INTEGRATION.md")).read())) - set(gen.OPAQUE)
+    assert used and used <= set(c_side), used - set(c_side)
+    assert sys_rs == gen.generate(), "sys.rs is stale: run python tools/gen_bindings.py"
+
+
 def test_rust_error_layout():
     # sppark cuda::Error {code: i32, message: *mut c_char}: 16 bytes on x86-64
     assert ctypes.sizeof(_lib.RustError) == 16

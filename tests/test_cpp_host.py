@@ -46,6 +46,11 @@ def test_cpp_mirror_matches_oracle_on_device(tmp_path, golden):
     assert np.array_equal(np.fromfile(tmp_path / "ntt.bin", dtype=np.uint64).reshape(-1, 4), oracle.ntt(fr))
     want = oracle.polymul(10, [fr[:512], fr[512:]])
     assert np.array_equal(np.fromfile(tmp_path / "polymul.bin", dtype=np.uint64).reshape(-1, 4), want)
+    # device-resident operands owned through snarkvm_hip::DeviceBuffer inside a Scope (no HIP header, no torch in that process)
+    padded = np.concatenate([fr, np.zeros_like(fr)])
+    assert np.array_equal(np.fromfile(tmp_path / "ntt_dev.bin", dtype=np.uint64).reshape(-1, 4), oracle.ntt(padded))
+    got_dev = np.fromfile(tmp_path / "msm_dev.bin", dtype=oracle.G1_PROJECTIVE)
+    assert util.affine_equal(oracle.g1_to_affine(got_dev), oracle.g1_to_affine(oracle.g1_msm(bases, sc)))
 
 
 @pytest.mark.gpu

@@ -993,6 +993,10 @@ def test_bench_two_rank_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 2 * (1 << 16) / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the self-check of a scaling point: the sum of the ranks' own rates beside `value`, and the two ranks sharing this GPU are flagged
+    assert d["predicted_value"] >= d["value"] * 0.999 and 0 < d["value_over_predicted"] <= 1.001
+    if all(r.get("uuid") for r in d["rank_devices"]):
+        assert len(d["duplicate_devices"]) == 1 and sorted(d["duplicate_devices"][0]["ranks"]) == [0, 1]
 
 
 def test_bench_proofs64_two_rank_lockstep_on_one_gpu():

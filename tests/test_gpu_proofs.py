@@ -404,8 +404,10 @@ def test_divide_by_linear_host_operands_inside_a_scope_return_the_remainder():
 
 def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
     """The "tables1" cliff of round 4 (93.6 vs 37 ms per step on the driver's box): a 2-instance batch whose second lane had to grow its
-    workspace behind the first lane's running MSM.  After ONE batch of a shape, the next batch of that shape must not allocate
-    (snarkvm_hip_alloc_stats) and must not take longer than 1.3 x the first one (best of three later batches); results identical."""
+    workspace behind the first lane's running MSM.  After ONE batch of a shape, every later batch of that shape must not allocate
+    (snarkvm_hip_alloc_stats); and the later batches must not be slower than a WARM reference - batches 3-5 (best of three) against batch 2, which
+    allocates nothing either (round 5 compared with batch 1, the one that allocates: that clause could never fail for the reason it exists);
+    results identical."""
     import time
 
     import torch
@@ -427,7 +429,7 @@ def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
     rb1.msm(device_ptr=d_sc.data_ptr(), npoints=n)                      # one lane grows to the table-less geometry (round 4's warm-up)
     stats = (ctypes.c_uint64 * 5)()
     times, res = [], []
-    for _ in range(4):
+    for _ in range(5):
         _lib.check(L.snarkvm_hip_synchronize())
         L.snarkvm_hip_alloc_stats(stats, 1)
         t0 = time.perf_counter()
@@ -437,7 +439,7 @@ def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
         if len(times) > 1:
             assert stats[0] == 0 and stats[2] == 0, f"batch {len(times)} of the same shape allocated: {list(stats)}"
     # (a cliff is persistent: every later batch would be slow; the best of three keeps a single hiccup of the box out of the verdict)
-    assert min(times[1:]) <= 1.3 * times[0], times
+    assert min(times[2:]) <= 1.3 * times[1], times
     want = _closed(G, sc)
     for r in res:
         for k in range(2):
@@ -557,3 +559,34 @@ def test_a_bad_request_among_coalesced_callers_fails_alone():
                 want = oracle.g1_msm(bases[: 4096 + t], pool[k : k + 4096 + t])
                 assert util.affine_equal(oracle.g1_to_affine(outs[t, k : k + 1]), oracle.g1_to_affine(want)), (t, k)
     rb.close()
+
+
+# ---- round 6: the same proof through the reference's OWN three symbols on host buffers ---------------------------------------------
+
+def test_ffi_only_replay_every_result_vs_oracle_stateless_and_cached():
+    """`replay_ffi`: the proof's data flow with every hot-path step issued through snarkvm_ntt / snarkvm_polymul / snarkvm_msm on HOST buffers - what an
+    unmodified snarkVM build gets - the commitments of a round from caller threads, every MSM over a slice of one long-lived base vector.  All 15 results
+    of three proofs against the oracle, stateless and with the opt-in base cache switched on through its API form (snarkvm_hip_set_base_cache: the vector is
+    registered at its second sighting, later calls are hits and meet in the coalescer); both equal the resident replay; the call counts are the reference's."""
+    L = _lib.lib()
+    shape = proofs.ProofShape(lg_r=12, lg_k=13, lg_g2=10)
+    keys = proofs.ProverKeys(shape, seed=31)
+    host = proofs.FfiProofHost(keys, threads=4)
+    ref = proofs.ProofWorkspace(keys)
+    try:
+        for tables in (0, 16):
+            _lib.check(L.snarkvm_hip_set_base_cache(tables))
+            for salt in (0, 4, 1, 4):
+                got, serial, t = [], [], {}
+                proofs.replay_ffi(host, salt, got, t)
+                proofs.replay(ref, salt, serial)
+                _check_against_oracle(keys, shape, salt, got)
+                assert proofs.normalize_results(got) == proofs.normalize_results(serial), (tables, salt)
+                assert (t["ntt_calls"], t["polymul_calls"], t["msm_calls"]) == (20, 5, 14)
+                assert t["ntt"] > 0 and t["msm"] > 0 and t["polymul"] > 0
+        with pytest.raises(_lib.HipError):
+            _lib.check(L.snarkvm_hip_set_base_cache(3))
+    finally:
+        _lib.check(L.snarkvm_hip_set_base_cache(0))
+        host.close()
+        keys.close()
