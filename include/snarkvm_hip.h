@@ -390,6 +390,11 @@ int snarkvm_hip_selftest_fq2_lazy(const void *points, size_t npoints, uint64_t s
  * the exact arithmetic: the chain of snarkvm_hip_selftest_fq2_lazy; doublings and cancellations are resolved inside the pair arithmetic.
  * 0 = identical; > 0: first differing step; < 0: a conversion case. */
 int snarkvm_hip_selftest_fq2_pair(const void *points, size_t npoints, uint64_t seed, int iters);
+/* The sixteen-lane cooperative Fq2 addition of the G2 tail trees (csrc/hex2.hip.h: lane 4 q + p of a DPP row computes Fq sub-product p of the quad
+ * schedule's product q; pair exchange, combine, gather) run over sixteen simulated lanes on the host - the same source - against the exact addition:
+ * `iters` additions of partial sums of +- points[k], with operands at infinity, P + P and P - P among them.  0 = every lane of every addition ends
+ * with exactly the exact sum; > 0: first differing iteration. */
+int snarkvm_hip_selftest_g2_hex(const void *points, size_t npoints, uint64_t seed, int iters);
 /* The signed-limb butterfly arithmetic of the NTT passes (csrc/frs.hip.h) against the exact arithmetic, on the host: passes of up
  * to nine butterfly stages without a canonical form in between, the closing product, the bare reduction and the folded table
  * form.  0 = identical; > 0: first differing butterfly; < 0: a closing-step case. */

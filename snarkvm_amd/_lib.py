@@ -27,7 +27,7 @@ SYMBOLS = [
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize", "snarkvm_hip_coalescer_stats",
-    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_g1_lazy_tail", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_selftest_fq2_pair", "snarkvm_hip_devtest_field",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_g1_lazy_tail", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_selftest_fq2_pair", "snarkvm_hip_selftest_g2_hex", "snarkvm_hip_devtest_field",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
         L.snarkvm_hip_selftest_fr_signed.restype = ctypes.c_int
         L.snarkvm_hip_selftest_fq2_lazy.restype = ctypes.c_int
         L.snarkvm_hip_selftest_fq2_pair.restype = ctypes.c_int
+        L.snarkvm_hip_selftest_g2_hex.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_count.restype = ctypes.c_int
         L.snarkvm_hip_get_phase_name.restype = ctypes.c_char_p
         L.snarkvm_hip_get_phase_ms.restype = ctypes.c_double
@@ -101,6 +102,8 @@ def lib():
         L.snarkvm_hip_scope_stream.restype = ctypes.c_void_p
         L.snarkvm_hip_scope_begin_ex.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         L.snarkvm_hip_scope_set_flags.argtypes = [ctypes.c_uint32]
+        L.snarkvm_hip_alloc_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]  # (without argtypes a bare Python int address would travel as a 32-bit C int)
+        L.snarkvm_hip_coalescer_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.snarkvm_hip_malloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_int]
         L.snarkvm_hip_free.argtypes = [ctypes.c_void_p]
         L.snarkvm_hip_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]

@@ -62,17 +62,26 @@ def _kept_object_is_current(obj, src, flags):
     return all(os.path.getmtime(h) <= t for h in _headers() + [src])
 
 
-def build(force=False, verbose=False, fast=False, only=None, ool=False):
+TSAN_LIB = os.path.join(LIBDIR, "libsnarkvm_hip_tsan.so")
+
+
+def build(force=False, verbose=False, fast=False, only=None, ool=False, tsan=False):
     """fast=True (development only) compiles without the G2 / Fq2 instantiations.  ool=True (A/B switch): every exceptional
     path out of line (-DSV_COLD_OOL): kernels a few percent slower, see ff.hip.h.  only=[...] (development only): recompile just
     the listed translation units and link them with the objects kept from the last build of THIS checkout with THESE flags -
     refused when a kept object is older than any header (a mixed library must never reach the GPU box); the driver's build()
-    always compiles everything."""
-    if not force and not only and not needs_build():
+    always compiles everything.
+    tsan=True (diagnostics: tools/soak.py --tsan): the HOST side of every unit compiled with -fsanitize=thread (device code untouched) into a SEPARATE library,
+    lib/libsnarkvm_hip_tsan.so - never the product library; a process that loads it needs the ThreadSanitizer runtime (an instrumented executable, or
+    LD_PRELOAD of clang's libclang_rt.tsan-x86_64.so)."""
+    out_lib = TSAN_LIB if tsan else LIB
+    if not tsan and not force and not only and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"] + (["-DSV_NO_G2"] if fast else []) + (["-DSV_COLD_OOL"] if ool else [])
+    if tsan:
+        flags += ["-Xarch_host", "-fsanitize=thread", "-Xarch_host", "-g"]
     objdir = _objdir(flags)
     os.makedirs(objdir, mode=0o700, exist_ok=True)
     if os.path.islink(objdir) or os.stat(objdir).st_uid != os.getuid():
@@ -98,13 +107,13 @@ def build(force=False, verbose=False, fast=False, only=None, ool=False):
             raise subprocess.CalledProcessError(pr.returncode, cmd)
         with open(_stamp(obj), "w") as f:
             json.dump({"flags": flags, "src": os.path.realpath(path)}, f)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + objs
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
-    return LIB
+    return out_lib
 
 
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith(".hip")]
-    print(build(force="--force" in sys.argv, verbose=True, fast="--fast" in sys.argv, only=only or None, ool="--ool" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, fast="--fast" in sys.argv, only=only or None, ool="--ool" in sys.argv, tsan="--tsan" in sys.argv))

@@ -542,13 +542,22 @@ RustError snarkvm_hip_g1_group_ntt(void* inout_projective, uint32_t lg, int inve
         hipLaunchKernelGGL(fr_fill_kernel, dim3(fr_grid(h)), dim3(256), 0, st, d_tw, h, one_mem);
         fr_distribute_powers_run(c, d_tw, h, root_mem, one_mem);
         hipLaunchKernelGGL(fr_to_bigint_kernel, dim3(fr_grid(h)), dim3(256), 0, st, d_tw, (const fr_mem_t*)d_tw, h, 1);
-        for (size_t half = n / 2; half >= 1; half >>= 1)
-            hipLaunchKernelGGL(g1_ntt_stage_kernel, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, st, d_pts, n, half, (const fr_mem_t*)d_tw, n / (2 * half));
+        // four lanes per butterfly from 32 points on (group.hip.h: every lane of every wave must own a butterfly); tuning group_quad=0: one lane per butterfly
+        const bool quad = n >= 32 && tuning().group_quad;
+        for (size_t half = n / 2; half >= 1; half >>= 1) {
+            if (quad)
+                hipLaunchKernelGGL(g1_ntt_stage_quad_kernel, dim3((unsigned)(n * 2 / 64)), dim3(64), 0, st, d_pts, n, half, (const fr_mem_t*)d_tw, n / (2 * half));
+            else
+                hipLaunchKernelGGL(g1_ntt_stage_kernel, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, st, d_pts, n, half, (const fr_mem_t*)d_tw, n / (2 * half));
+        }
         hipLaunchKernelGGL(g1_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_pts, n, (int)lg);
         if (inverse) {  // * size_inv (domain.rs:190)
             fr_mem_t k_int;
             fr_t::from_u32((uint32_t)n).inverse().mont_to_int().store(&k_int);
-            hipLaunchKernelGGL(g1_scale_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_pts, n, k_int);
+            if (quad)
+                hipLaunchKernelGGL(g1_scale_quad_kernel, dim3((unsigned)(n * 4 / 64)), dim3(64), 0, st, d_pts, n, k_int);
+            else
+                hipLaunchKernelGGL(g1_scale_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_pts, n, k_int);
         }
     }
     hipLaunchKernelGGL(g1_xyzz_to_jac_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const g1_xyzz_mem_t*)d_pts, d_jac, n);

@@ -331,4 +331,50 @@ int snarkvm_hip_selftest_fq2_pair(const void* points, size_t npoints, uint64_t s
 #endif
 }
 
+// The sixteen-lane cooperative Fq2 addition of the G2 tail trees (csrc/hex2.hip.h) on sixteen SIMULATED lanes - the same source as the kernel's, every lane
+// with its own copy of the state, the pair exchange and the gathers indexing the other lanes' copies - against xyzz_t<fq2_t>::add: `iters` additions of partial
+// sums built from +- points[k] (general ZZ / ZZZ), with the cases a tree meets: an operand at infinity (either, both), P + P (every lane must ask for the
+// plain law), P + (-P).  0 = every lane of every addition ends with exactly the exact sum; > 0: first differing iteration; < 0: bad arguments.
+int snarkvm_hip_selftest_g2_hex(const void* points, size_t npoints, uint64_t seed, int iters) {
+#ifdef SV_NO_G2
+    (void)points, (void)npoints, (void)seed, (void)iters;
+    return -1;
+#else
+    if (!points || npoints < 2) return -2;
+    std::vector<aff_t<fq2_t>> pool;
+    for (size_t i = 0; i < npoints; i++) {
+        const uint32_t* src = (const uint32_t*)((const uint8_t*)points + 200 * i);
+        pool.push_back({fq2_t::from_raw_words(src), fq2_t::from_raw_words(src + 24)});
+    }
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto partial = [&](int terms) {  // a partial sum with general ZZ, ZZZ
+        xyzz_t<fq2_t> a = xyzz_t<fq2_t>::inf();
+        for (int t = 0; t < terms; t++) {
+            const uint64_t r = next();
+            a.add_affine(pool[r % npoints], ((r >> 40) & 1) != 0);
+        }
+        return a;
+    };
+    for (int it = 0; it < iters; it++) {
+        const int mode = (int)(next() % 12);
+        xyzz_t<fq2_t> a = partial(1 + (int)(next() % 3)), b = partial(1 + (int)(next() % 3));
+        if (mode == 0) b = a;                                  // doubling: the equal-x fallback on every lane
+        if (mode == 1) b = a, b.y = b.y.neg();                 // cancellation: equal x as well
+        if (mode == 2) a = xyzz_t<fq2_t>::inf();
+        if (mode == 3) b = xyzz_t<fq2_t>::inf();
+        if (mode == 4) a = xyzz_t<fq2_t>::inf(), b = xyzz_t<fq2_t>::inf();
+        xyzz_t<fq2_t> want = a;
+        want.add(b);
+        if (hex_add_host_check(a, b, want)) return it + 1;
+    }
+    return 0;
+#endif
+}
+
 }  // extern "C"

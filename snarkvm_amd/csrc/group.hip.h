@@ -11,6 +11,7 @@
 #pragma once
 #include "ec.hip.h"
 #include "ff.hip.h"
+#include "msm.hip.h"  // quad_add, quad_bcast, select_field / select_point
 
 namespace sv {
 
@@ -117,6 +118,97 @@ static __global__ void __launch_bounds__(64) g1_ntt_stage_kernel(g1_xyzz_mem_t* 
     }
     g1_store_xyzz(&pts[ia], s);
     g1_store_xyzz(&pts[ib], d);
+}
+// ---- the same stage with FOUR lanes per butterfly (round 6) ------------------------------------------------------------------------
+// One butterfly = two additions and a 253-bit scalar multiplication, ~2.2 million dependent instructions on one lane; at n = 2^16 a stage of the
+// one-thread form above is 512 waves on 1 024 SIMDs - half the chip idle, the stage as long as ONE chain (latency-bound: a lone wave issues an
+// instruction every ~4.5 cycles).  Here the four lanes of a DPP quad share every point operation of their butterfly: quad_add (msm.hip.h: the 14
+// products of add-2008-s in four rounds of one product per lane) and quad_dbl below (dbl-2008-s-1 in three rounds), and the twiddle is consumed two
+// bits at a time against {P, 2P, 3P} held in registers: per 2-bit window 2 x 3 + 4 = 10 product rounds instead of 2 x (9 + 14) = 46 dependent
+// products.  Four times the lanes fill the chip, the chain is ~4x shorter.  Same group elements (results are compared after to_affine).
+template <class F>
+__device__ __forceinline__ void quad_dbl(xyzz_t<F>& p) {
+    const uint32_t r = threadIdx.x & 3;
+    const F u = p.y.dbl();
+    F a = select_field(r == 0, u, p.x);
+    const F m1 = a * a;  // V = U^2 | XX = X^2 | - | -
+    const F v = quad_bcast<0>(m1), xx = quad_bcast<1>(m1);
+    const F m = xx.dbl() + xx;
+    a = select_field(r == 0, u, select_field(r == 1, p.x, m));
+    F b = select_field(r < 2, v, m);
+    const F m2 = a * b;  // W = U V | S = X V | M^2 | (M^2)
+    const F w = quad_bcast<0>(m2), s = quad_bcast<1>(m2);
+    const F x3 = quad_bcast<2>(m2) - s.dbl();
+    a = select_field(r == 0, m, select_field(r == 2, v, w));  // M | W | V | W
+    b = select_field(r < 2, select_field(r == 0, s - x3, p.y), select_field(r == 2, p.zz, p.zzz));
+    const F m3 = a * b;  // M (S - X3) | W Y | V ZZ | W ZZZ
+    p.x = x3;
+    p.y = quad_bcast<0>(m3) - quad_bcast<1>(m3);
+    p.zz = quad_bcast<2>(m3);
+    p.zzz = quad_bcast<3>(m3);
+}
+// k * p for a canonical integer k < 2^254 in eight words (consumed), by the four lanes of a quad together; the quad's lanes hold identical (p, k)
+// (force-inlined: as an out-of-line function - operands passed by reference through the caller's scratch frame - the first launch of the stage kernel in a
+// fresh process never returned on gfx950 / ROCm 7.2, while the same launch after kernels with larger frames had run was fine; inlined, the kernel has no calls)
+__device__ __forceinline__ g1_xyzz_t g1_quad_mul_words(const g1_xyzz_t& p, uint32_t (&k)[8]) {
+    g1_xyzz_t t2 = p;
+    quad_dbl(t2);
+    g1_xyzz_t t3 = t2;
+    quad_add(t3, p);
+    g1_xyzz_t acc = g1_xyzz_t::inf();
+#pragma unroll
+    for (int i = 7; i > 0; i--) k[i] = (k[i] << 2) | (k[i - 1] >> 30);  // bits 255, 254 are zero (k < r < 2^253): start at the window of bits 253, 252
+    k[0] <<= 2;
+#pragma unroll 1
+    for (int wdw = 0; wdw < 127; wdw++) {
+        quad_dbl(acc);
+        quad_dbl(acc);
+        const uint32_t d = k[7] >> 30;
+#pragma unroll
+        for (int i = 7; i > 0; i--) k[i] = (k[i] << 2) | (k[i - 1] >> 30);
+        k[0] <<= 2;
+        const g1_xyzz_t t = select_point(d == 1, p, select_point(d == 2, t2, t3));
+        g1_xyzz_t sum = acc;
+        quad_add(sum, t);
+        acc = select_point(d == 0, acc, sum);
+    }
+    return acc;
+}
+__device__ __forceinline__ void g1_load_words8(uint32_t (&k)[8], const fr_mem_t* src) {
+    const uint4* q = (const uint4*)src;
+    const uint4 lo = q[0], hi = q[1];
+    k[0] = lo.x, k[1] = lo.y, k[2] = lo.z, k[3] = lo.w, k[4] = hi.x, k[5] = hi.y, k[6] = hi.z, k[7] = hi.w;
+}
+// thread t: butterfly t / 4.  n / 2 butterflies, n >= 32 (every lane of every wave owns a butterfly: the quad operations are wave-wide).
+static __global__ void __launch_bounds__(64) g1_ntt_stage_quad_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, size_t half, const fr_mem_t* __restrict__ tw,
+                                                               size_t stride) {
+    const size_t t = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
+    const size_t j = t % half, blk = t / half;
+    const size_t ia = blk * 2 * half + j, ib = ia + half;
+    const g1_xyzz_t a = g1_load_xyzz(&pts[ia]), b = g1_load_xyzz(&pts[ib]);
+    g1_xyzz_t s = a;
+    quad_add(s, b);
+    g1_xyzz_t d = a;
+    quad_add(d, g1_neg(b));
+    // tw[0] = 1 multiplies like any other twiddle (a wave-uniform skip would need every butterfly of the wave at j = 0) - except in the last stage, where
+    // EVERY butterfly has j = 0: no multiplication at all (kernel-uniform)
+    if (half > 1) {
+        uint32_t k[8];
+        g1_load_words8(k, &tw[j * stride]);
+        d = g1_quad_mul_words(d, k);
+    }
+    if ((threadIdx.x & 3) == 0) {
+        g1_store_xyzz(&pts[ia], s);
+        g1_store_xyzz(&pts[ib], d);
+    }
+}
+// pts[i] <- k * pts[i], four lanes per point (n >= 16)
+static __global__ void __launch_bounds__(64) g1_scale_quad_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, fr_mem_t k_int) {
+    const size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
+    uint32_t k[8];
+    g1_load_words8(k, &k_int);
+    const g1_xyzz_t r = g1_quad_mul_words(g1_load_xyzz(&pts[i]), k);
+    if ((threadIdx.x & 3) == 0) g1_store_xyzz(&pts[i], r);
 }
 static __global__ void g1_bitrev_kernel(g1_xyzz_mem_t* __restrict__ pts, size_t n, int lg) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

@@ -23,9 +23,12 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ec.hip.h"
 #include "ffl.hip.h"
 #include "ffl2.hip.h"
+#include "hex2.hip.h"
 #include "tuning.hip.h"
 
 namespace sv {
@@ -579,21 +582,63 @@ __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
 // pairs) is a plain addition with the operands in the same order on both lanes, so that from level 2 on the four lanes of a
 // quad hold bit-identical operands and share every addition (quad_add); the wave totals go through LDS to wave 0, whose quads
 // add them pairwise and finish with the same exchange levels.  `sh`: one point per wave.
+// hex != 0 (Fq2 only; tuning hex2): from the level on where a wave holds <= 4 distinct additions - exchange distance 8 - every addition is shared by the
+// SIXTEEN lanes of a DPP row (hex2.hip.h::hex_add: one Fq product per lane and round instead of one Fq2 product), which needs the sixteen lanes to hold
+// bit-identical operands: the distance-4 level (and every later one) then adds its two operands in the same order on both sides.  Same sums, bit for bit.
+// from_quads: the four lanes of every quad already hold ONE bit-identical value (a quad-strided accumulation, tail_quad_accumulate below): the two
+// intra-quad levels - the only ones with a plain, one-lane addition - do not exist.
 template <class F>
-__device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh) {
-    {
+__device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int hex = 0, bool from_quads = false) {
+    if (!from_quads) {
         const xyzz_t<F> o = shfl_xor_point(acc, 1);
         const bool odd = (threadIdx.x & 1) != 0;
         xyzz_t<F> lo = select_point(odd, o, acc);
         lo.add(select_point(odd, acc, o));
         acc = lo;
     }
-    {
+    if (!from_quads) {
         const xyzz_t<F> o = shfl_xor_point(acc, 2);
         const bool hi = (threadIdx.x & 2) != 0;
         xyzz_t<F> lo = select_point(hi, o, acc);
         quad_add(lo, select_point(hi, acc, o));
         acc = lo;
+    }
+    if constexpr (std::is_same<F, fq2_t>::value) {
+        if (hex) {
+            {
+                const xyzz_t<F> o = shfl_xor_point(acc, 4);
+                const bool hi = (threadIdx.x & 4) != 0;
+                xyzz_t<F> lo = select_point(hi, o, acc);
+                quad_add(lo, select_point(hi, acc, o));
+                acc = lo;
+            }
+#pragma unroll 1
+            for (int off = 8; off < 64; off <<= 1) {
+                const xyzz_t<F> o = shfl_xor_point(acc, off);
+                const bool hi = (threadIdx.x & off) != 0;
+                xyzz_t<F> lo = select_point(hi, o, acc);
+                hex_add(lo, select_point(hi, acc, o), hex);
+                acc = lo;
+            }
+            if (blockDim.x == 64) return;
+            const uint32_t wv = threadIdx.x >> 6, nw = blockDim.x >> 6;  // 2 or 4 waves (<= 256 threads: four rows of wave 0 take the <= 2 pairs)
+            if ((threadIdx.x & 63) == 0) store_xyzz<F>(&sh[wv], acc);
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const uint32_t pair = (threadIdx.x >> 4) & (nw / 2 - 1);  // row -> the pair of wave totals it adds
+                acc = load_xyzz<F>(&sh[2 * pair]);
+                hex_add(acc, load_xyzz<F>(&sh[2 * pair + 1]), hex);
+#pragma unroll 1
+                for (uint32_t off = 16; off < 8 * nw; off <<= 1) {
+                    const xyzz_t<F> o = shfl_xor_point(acc, (int)off);
+                    const bool hi = (threadIdx.x & off) != 0;
+                    xyzz_t<F> lo = select_point(hi, o, acc);
+                    hex_add(lo, select_point(hi, acc, o), hex);
+                    acc = lo;
+                }
+            }
+            return;
+        }
     }
 #pragma unroll 1
     for (int off = 4; off < 64; off <<= 1) quad_add(acc, shfl_xor_point(acc, off));
@@ -674,7 +719,7 @@ static constexpr uint32_t TAIL_MAX_SEG = 2048;  // buckets per fold column (2^hb
 // buckets i, i + B, ... of the column, no LDS staging.
 template <class F, bool FLAT>
 __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
-                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb) {
+                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb, int hex, int quads) {
     __shared__ xyzz_mem_t<F> sh[16];
     __shared__ uint32_t s_off[FLAT ? TAIL_MAX_SEG + 1 : 1], s_start[FLAT ? TAIL_MAX_SEG : 1], s_tmp[FLAT ? 256 : 1];
     const uint32_t nlo = 1u << m, nhi = 1u << hb;
@@ -696,7 +741,7 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
             const uint32_t q1 = column ? q0 + cnt[k] : start[k0 + nlo - 1] + cnt[k0 + nlo - 1];
             for (uint32_t q = q0; q < q1; q += column ? 1u : blockDim.x) acc.add(load_xyzz<F>(&sums[q]));
         }
-        block_sum<F>(acc, sh);
+        block_sum<F>(acc, sh, hex);
         if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
         return;
     }
@@ -723,11 +768,33 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
     }
     const uint32_t total = s_off[nseg];
     xyzz_t<F> acc = xyzz_t<F>::inf();
-    for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
-        const uint32_t i = find_segment(s_off, nseg, p);
-        acc.add(load_xyzz<F>(&sums[s_start[i] + (p - s_off[i])]));
+    if (quads) {
+        // quad-strided: every QUAD takes positions q, q + Q, ... of the list - its four lanes load the same partial sum - and adds them with the
+        // quad-cooperative law.  No lane ever runs a plain addition alone (14 dependent field products on one lane: for Fq2 ~125 us, three times a
+        // quad-cooperative one), and the tree starts at the quads.  The trip count is block-uniform: quad_add is a wave-wide operation.
+        const uint32_t nq = blockDim.x >> 2, qid = threadIdx.x >> 2;
+        const uint32_t iters = (total + nq - 1) / nq;
+#pragma unroll 1
+        for (uint32_t it = 0; it < iters; it++) {
+            const uint32_t p = qid + it * nq;
+            xyzz_t<F> x = xyzz_t<F>::inf();
+            if (p < total) {
+                const uint32_t i = find_segment(s_off, nseg, p);
+                x = load_xyzz<F>(&sums[s_start[i] + (p - s_off[i])]);
+            }
+            if (it == 0)
+                acc = x;
+            else
+                quad_add(acc, x);
+        }
+        block_sum<F>(acc, sh, hex, true);
+    } else {
+        for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+            const uint32_t i = find_segment(s_off, nseg, p);
+            acc.add(load_xyzz<F>(&sums[s_start[i] + (p - s_off[i])]));
+        }
+        block_sum<F>(acc, sh, hex);
     }
-    block_sum<F>(acc, sh);
     if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
 }
 // 7b. grid (nbits, tail windows).  Tail window tw holds N entries, entry i has weight i + 1:
@@ -740,7 +807,7 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
 template <class F, bool DENSE>
 __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
                                                            const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ planes, uint32_t nb,
-                                                           int m, int hb) {
+                                                           int m, int hb, int hex, int quads) {
     __shared__ xyzz_mem_t<F> sh[16];
     __shared__ uint32_t s_off[DENSE ? 1 : TAIL_MAX_SEG + 1];
     const uint32_t j = blockIdx.x, tw = blockIdx.y, nbits = gridDim.x;
@@ -749,6 +816,23 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel
         const uint32_t w = tw >> 1, sub = tw & 1;
         const uint32_t N = sub ? (1u << hb) - 1 : (1u << m);
         const size_t base = ((size_t)w << (m + 1)) + ((size_t)sub << m);
+        if (quads) {  // quad-strided, as in the fold: entry i belongs to quad i mod Q
+            const uint32_t nq = blockDim.x >> 2, qid = threadIdx.x >> 2;
+            const uint32_t iters = (N + nq - 1) / nq;
+#pragma unroll 1
+            for (uint32_t it = 0; it < iters; it++) {
+                const uint32_t i = qid + it * nq;
+                xyzz_t<F> x = xyzz_t<F>::inf();
+                if (i < N && (((i + 1) >> j) & 1)) x = load_xyzz<F>(&sums[base + i]);
+                if (it == 0)
+                    acc = x;
+                else
+                    quad_add(acc, x);
+            }
+            block_sum<F>(acc, sh, hex, true);
+            if (threadIdx.x == 0) store_xyzz<F>(&planes[(size_t)tw * nbits + j], acc);
+            return;
+        }
         for (uint32_t i = threadIdx.x; i < N; i += blockDim.x)
             if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[base + i]));
     } else {
@@ -763,7 +847,7 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel
             if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[p0 + p]));
         }
     }
-    block_sum<F>(acc, sh);
+    block_sum<F>(acc, sh, hex);
     if (threadIdx.x == 0) store_xyzz<F>(&planes[(size_t)tw * nbits + j], acc);
 }
 

@@ -855,6 +855,11 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
                             const uint32_t* start, const uint32_t* cnt, bool flat, const msm_pending_t& pd, void* host_planes) {
     hipStream_t st = c.stream;
     c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
+    const bool is_g2 = sizeof(F) == sizeof(fq2_t);
+    const int hex = is_g2 ? tuning().hex2 : 0;  // G2: the upper tree levels on sixteen lanes per addition (hex2.hip.h); 2 = gathers by DPP row broadcast, 1 = by ds_bpermute
+    // quad-strided accumulation in front of the trees (msm.hip.h), a bit mask: 1 = G2 bit planes, 2 = G2 fold, 4 = G1 bit planes, 8 = G1 fold.  Measured on the
+    // 2^16 G2 tail (tools/g2_tail.sh, 17 x 15 geometry): bit planes 235 -> 202 us (186 with hex2 = 2), fold 375 -> 404 us - hence the default 1.
+    const int quads_planes = (tuning().tail_quads >> (is_g2 ? 0 : 2)) & 1, quads_fold = (tuning().tail_quads >> (is_g2 ? 1 : 3)) & 1;
     if (g.fold) {
         c.fold_sums.ensure(((size_t)nwin << (g.fold_m + 1)) * sizeof(xyzz_mem_t<F>));
         // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
@@ -864,20 +869,23 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
         // (G2 kernels hold one wave per SIMD: 256-thread workgroups sit one per CU, so 384 of them take two turns on 256 CUs; 128-thread
         // workgroups sit two per CU and lose one level of the tree besides - tuning fold_threads2)
         unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
-        if (sizeof(F) > 64 && fold_threads == 256u && (tuning().fold_threads2 == 128 || tuning().fold_threads2 == 64)) fold_threads = (unsigned)tuning().fold_threads2;
+        // (measured, 17 x 15 geometry = 256 workgroups: 256 threads 0.38 ms, 128 threads 0.53 ms, 64 threads 0.83 ms - the halved workgroup only pays when the
+        // grid would otherwise take two turns, tools/g2_tail.sh)
+        if (sizeof(F) > 64 && fold_threads == 256u && fold_blocks > 256u && (tuning().fold_threads2 == 128 || tuning().fold_threads2 == 64)) fold_threads = (unsigned)tuning().fold_threads2;
         if (flat || fold_threads != 64u)
             hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
-                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb);
+                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex, quads_fold);
         else
             hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
-                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb);
-        const unsigned plane_threads = g.fold_m <= 6 ? 64u : g.fold_m == 7 ? 128u : 256u;  // one lane per entry of a plane (<= 2^fold_m)
+                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex, quads_fold);
+        // one lane per entry of a plane (<= 2^fold_m); quad-strided: one QUAD per entry, up to 64 quads
+        const unsigned plane_threads = quads_planes ? (g.fold_m <= 4 ? 64u : g.fold_m == 5 ? 128u : 256u) : (g.fold_m <= 6 ? 64u : g.fold_m == 7 ? 128u : 256u);
         hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)g.nbits, (unsigned)g.tail_windows), dim3(plane_threads), 0, st,
                            (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, g.fold_m, g.fold_hb);
+                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, g.fold_m, g.fold_hb, hex, quads_planes);
     } else {
         hipLaunchKernelGGL((msm_bitplane_kernel<F, false>), dim3((unsigned)g.nbits, (unsigned)g.tail_windows), dim3(256), 0, st, sums, start, cnt,
-                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0);
+                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0, hex, 0);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_planes, c.planes.p, (size_t)pd.nplanes * sizeof(xyzz_mem_t<F>), hipMemcpyDeviceToHost, st));

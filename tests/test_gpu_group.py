@@ -78,3 +78,37 @@ def test_lagrange_basis_commits_like_the_monomial_basis(golden):
     assert util.affine_equal(kzg10.to_affine(c1), kzg10.to_affine(c2))
     pw.close()
     lb.close()
+
+
+@pytest.mark.parametrize("lg", [12, 16])
+def test_group_ntt_at_the_sizes_it_exists_for(lg):
+    """UniversalParams::lagrange_basis runs at 2^16 and beyond (kzg10/data_structures.rs:68-72).  The four-lanes-per-butterfly stages (group.hip.h: quad-cooperative
+    additions / doublings, 2-bit windowed twiddle multiplication) against the oracle's group iFFT and FFT at 2^12 and 2^16 - every point - plus the round trip, and
+    against the one-lane-per-butterfly form of round 5 at 2^12 (tuning group_quad=0 in a child process: the same group elements)."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    n = 1 << lg
+    aff = oracle.g1_gen_bases(util.g1_generator_affine(), 3, n)
+    proj = _to_projective(aff)
+    t0 = time.perf_counter()
+    got = group.group_ntt(proj, inverse=True)
+    dt = time.perf_counter() - t0
+    want = oracle.g1_group_ntt(proj, inverse=True)
+    assert util.affine_equal(oracle.g1_to_affine(got), oracle.g1_to_affine(want)), lg
+    fwd = group.group_ntt(got, inverse=False)
+    assert util.affine_equal(oracle.g1_to_affine(fwd), aff), lg
+    print(f"group iFFT 2^{lg}: {dt * 1e3:.1f} ms through the C ABI (host buffers)")
+    if lg == 12:
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from snarkvm_amd import group; from snarkvm_amd.layout import G1_PROJECTIVE; "
+                "p = np.fromfile(sys.argv[1], dtype=G1_PROJECTIVE); group.group_ntt(p, inverse=True).tofile(sys.argv[2])" % util.ROOT)
+        src, dst = f"/tmp/group_ntt_in_{os.getpid()}.bin", f"/tmp/group_ntt_out_{os.getpid()}.bin"
+        proj.tofile(src)
+        r = subprocess.run([sys.executable, "-c", code, src, dst], env=dict(os.environ, SNARKVM_HIP_TUNING="group_quad=0"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        old = np.fromfile(dst, dtype=oracle.G1_PROJECTIVE)
+        assert util.affine_equal(oracle.g1_to_affine(old), oracle.g1_to_affine(want))
+        os.remove(src)
+        os.remove(dst)

@@ -237,3 +237,15 @@ def test_fq2_lane_pair_arithmetic_matches_exact():
     for seed in (1, 7, 0xC0FFEE, 99):
         rc = L.snarkvm_hip_selftest_fq2_pair(ctypes.c_void_p(pts.ctypes.data), ctypes.c_size_t(pts.shape[0]), ctypes.c_uint64(seed), ctypes.c_int(1500))
         assert rc == 0, (seed, rc)
+
+
+def test_g2_sixteen_lane_cooperative_addition_matches_exact():
+    """csrc/hex2.hip.h (round 6): the Fq2 XYZZ addition of the G2 tail trees dealt to the SIXTEEN lanes of a DPP row - lane 4 q + p computes Fq sub-product p
+    of the quad schedule's product q, a pair exchange, c0 = P0 - 5 P1 / c1 = P2 + P3, a gather per round - run on the host over sixteen simulated lanes
+    (the same source, the exchanges index the other lanes' copies) against xyzz_t<fq2_t>::add: every coordinate on every lane, operands at infinity,
+    P + P (every lane asks for the plain law) and P - P included."""
+    L = _lib.lib()
+    pts = synthetic.g2_points(48, distinct=48)
+    for seed in (1, 7, 0xC0FFEE, 2026):
+        rc = L.snarkvm_hip_selftest_g2_hex(ctypes.c_void_p(pts.ctypes.data), ctypes.c_size_t(pts.shape[0]), ctypes.c_uint64(seed), ctypes.c_int(600))
+        assert rc == 0, (seed, rc)
