@@ -158,6 +158,9 @@ def main():
                     help="distribution of the timed legs' scalars: uniform in [0, r), or witness-like (SURVEY.md 8d config 2: 50 %% zero, 25 %% < 2^16, 25 %% uniform; "
                          "synthesizer/process/src/tests/test_credits.rs:2868-2925 shapes).  The default line reports BOTH for the headline, proof1 and proofs64 "
                          "(value_witness_like, ...); this flag makes the second distribution the headline itself")
+    ap.add_argument("--proof-mem", choices=["torch", "hip"], default="hip",
+                    help="proof1: who owns the proof's device buffers and issues its operand copies - \"hip\": snarkvm_hip_malloc / _memcpy_d2d / _memset through the C ABI (what a "
+                         "Rust host does; no torch on the data path), \"torch\": tensors and strided tensor copies on the scope's stream (rounds 4 - 5)")
     ap.add_argument("--ffi-only", action="store_true", help="proof1: the same proof through the reference's OWN three symbols on host buffers (what an unmodified snarkVM gets): "
                                                              "rows stateless / SNARKVM_HIP_BASE_CACHE=16 / resident")
     ap.add_argument("--ffi-threads", type=int, default=4, help="--ffi-only: caller threads that issue the commitments of a round (the reference's rayon workers)")
@@ -591,7 +594,7 @@ def main():
     # Only quoted for the configuration they were collected on; PMC collection cannot run inside this process.
     default_cfg = args.lg_msm == 24 and args.lg_ntt == 24 and args.tables == 12 and args.table_bits == 22 and not args.window_bits
     pmc, pmc_source = {}, None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         if default_cfg and load_profile_json(name):
             pmc = load_profile_json(name).get("kernels", {})
             pmc_source = f"look-up, not measured in this run: profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration on the builder's box)"
@@ -912,7 +915,7 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
         return proof1_ffi(args, dev_index)
     shape = proofs.ProofShape()
     ptab, pbits = (int(v) for v in args.proof_geometry.split("x"))
-    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits, scalars=args.scalars)
+    keys = proofs.ProverKeys(shape, tables=ptab, window_bits=pbits, scalars=args.scalars, mem=args.proof_mem)
     count = 32
     mine = list(range(rank, count * world, world))
     checks = {}
@@ -971,7 +974,8 @@ def proof1(args, rank, world, dev_index, barrier, max_over_ranks, gather_over_ra
             "data": "synthetic",
             "config": {"workload": "one proof at a time: 14 G1 commitments / openings of 2^16-2^17 pairs in 6 rounds, ~45 Fr NTTs of 2^16-2^18, polynomial passes, one 2^16 G2 MSM; "
                                    "device-resident random data, transfer_private domain sizes; one deferred-synchronisation scope per proof",
-                       "proofs_per_rank": len(mine), "registered_srs": f"{ptab} tables x {pbits}-bit windows", "commitments": head, "mode": what[head], "pool_values": args.scalars},
+                       "proofs_per_rank": len(mine), "registered_srs": f"{ptab} tables x {pbits}-bit windows", "commitments": head, "mode": what[head], "pool_values": args.scalars,
+                       "device_buffers": "snarkvm_hip_malloc + snarkvm_hip_memcpy_d2d / _memset through the C ABI (no torch on the data path)" if args.proof_mem == "hip" else "torch tensors"},
             "latency": proof1_summary(dt_rank, lat, times, grown, len(mine)),
             **legs,
             "g1_pairs_per_s": world * len(mine) * shape.pairs() / dt_job,

@@ -250,10 +250,20 @@ struct device_t {
     void init() {  // the calling thread has this device current
         std::lock_guard<std::mutex> lk(init_mu);
         if (ready) return;
+        // The upper half of the lanes runs on LOW-priority streams (tuning aux_low_prio): a scope hands its asynchronous MSMs - the work that is NOT on the caller's
+        // critical path: the independent G2 MSM of a proof, commitments whose results are only due at scope_end - to those lanes (take_for_scope searches from the
+        // top), ordinary calls and the scopes' own lanes take from the bottom.  When the chip is contended the dispatcher serves the critical stream first and the
+        // background MSM fills the gaps the transcript order leaves (one proof in Fiat-Shamir order idles the GPU ~1.3 ms between its rounds).  With more than
+        // LANES / 2 concurrent callers ordinary calls reach those lanes too: they then simply share one priority level among themselves.
+        int prio_low = 0, prio_high = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = prio_high = 0;  // (numerically: low >= high)
         for (int l = 0; l < LANES; l++) {
             lane[l].dev = this;
             lane[l].index = l;
-            HIP_TRY(hipStreamCreateWithFlags(&lane[l].stream, hipStreamNonBlocking));
+            if (l >= LANES / 2 && tuning().aux_low_prio && prio_low != prio_high)
+                HIP_TRY(hipStreamCreateWithPriority(&lane[l].stream, hipStreamNonBlocking, prio_low));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&lane[l].stream, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&lane[l].alt, hipStreamNonBlocking));
             for (auto& e : lane[l].ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
@@ -325,12 +335,15 @@ struct device_t {
             cv.wait(lk, room);
         else if (!room())
             return nullptr;
-        for (int l = 0; l < LANES; l++)
+        // a scope's own lane: from the bottom (normal priority); its further MSM lanes: from the top (low-priority streams, see init)
+        for (int i = 0; i < LANES; i++) {
+            const int l = block ? i : LANES - 1 - i;
             if (!(busy & (1u << l))) {
                 busy |= 1u << l;
                 scope_held++;
                 return &lane[l];
             }
+        }
         return nullptr;
     }
     void give(lane_t* l, bool from_scope = false) {
@@ -858,7 +871,7 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
     const bool is_g2 = sizeof(F) == sizeof(fq2_t);
     const int hex = is_g2 ? tuning().hex2 : 0;  // G2: the upper tree levels on sixteen lanes per addition (hex2.hip.h); 2 = gathers by DPP row broadcast, 1 = by ds_bpermute
     // quad-strided accumulation in front of the trees (msm.hip.h), a bit mask: 1 = G2 bit planes, 2 = G2 fold, 4 = G1 bit planes, 8 = G1 fold.  Measured on the
-    // 2^16 G2 tail (tools/g2_tail.sh, 17 x 15 geometry): bit planes 235 -> 202 us (186 with hex2 = 2), fold 375 -> 404 us - hence the default 1.
+    // 2^16 G2 tail (tools/g2_tail.sh, 17 x 15 geometry): bit planes 235 -> 202 us (186 with hex2 = 2), fold 375 -> 404 us; on one proof in transcript order (bench.py --workload proof1): 8.54 -> 8.29 - 8.37 ms with 13, 8.41 with 9, 8.37 with 15 - hence the default 13.
     const int quads_planes = (tuning().tail_quads >> (is_g2 ? 0 : 2)) & 1, quads_fold = (tuning().tail_quads >> (is_g2 ? 1 : 3)) & 1;
     if (g.fold) {
         c.fold_sums.ensure(((size_t)nwin << (g.fold_m + 1)) * sizeof(xyzz_mem_t<F>));

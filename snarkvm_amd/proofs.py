@@ -264,6 +264,8 @@ class SingleProofWorkspace:
             from .devmem import HipMem
 
             self.device = None
+            # (snarkvm_hip_malloc counts LOGICAL devices - entries of the library's device list; a process that drives one GPU, whatever its CUDA index, has logical device 0)
+            device_index = device_index if device_index < _lib.lib().snarkvm_hip_num_devices() else 0
             self.pool = HipMem.from_numpy(keys.pool_host, device_index)
             self.work = HipMem(self.ROWS * self.row_bytes, device_index)
             self.work.fill(0, 0, self.work.nbytes)
