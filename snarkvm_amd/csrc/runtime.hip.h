@@ -872,7 +872,11 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
     const int hex = is_g2 ? tuning().hex2 : 0;  // G2: the upper tree levels on sixteen lanes per addition (hex2.hip.h); 2 = gathers by DPP row broadcast, 1 = by ds_bpermute
     // quad-strided accumulation in front of the trees (msm.hip.h), a bit mask: 1 = G2 bit planes, 2 = G2 fold, 4 = G1 bit planes, 8 = G1 fold.  Measured on the
     // 2^16 G2 tail (tools/g2_tail.sh, 17 x 15 geometry): bit planes 235 -> 202 us (186 with hex2 = 2), fold 375 -> 404 us; on one proof in transcript order (bench.py --workload proof1): 8.54 -> 8.29 - 8.37 ms with 13, 8.41 with 9, 8.37 with 15 - hence the default 13.
-    const int quads_planes = (tuning().tail_quads >> (is_g2 ? 0 : 2)) & 1, quads_fold = (tuning().tail_quads >> (is_g2 ? 1 : 3)) & 1;
+    // ... and only in the LATENCY regime (a small MSM's tail: a handful of entries per workgroup, the chip not full).  A big MSM's fold / bit planes are throughput-bound -
+    // one wave per output walking thousands of entries - and four lanes repeating every addition there is four times the work: measured at 2^24 (12 x 22 geometry)
+    // fold 1.31 -> 1.66 ms, bit planes 0.18 -> 0.20 ms (profiles/r06_summary.md), so the mask applies to folds that run 128 / 256 threads per output and planes of <= 256 entries.
+    int quads_planes = (tuning().tail_quads >> (is_g2 ? 0 : 2)) & 1, quads_fold = (tuning().tail_quads >> (is_g2 ? 1 : 3)) & 1;
+    if (g.fold_m > 8) quads_planes = 0;
     if (g.fold) {
         c.fold_sums.ensure(((size_t)nwin << (g.fold_m + 1)) * sizeof(xyzz_mem_t<F>));
         // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
@@ -885,6 +889,7 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
         // (measured, 17 x 15 geometry = 256 workgroups: 256 threads 0.38 ms, 128 threads 0.53 ms, 64 threads 0.83 ms - the halved workgroup only pays when the
         // grid would otherwise take two turns, tools/g2_tail.sh)
         if (sizeof(F) > 64 && fold_threads == 256u && fold_blocks > 256u && (tuning().fold_threads2 == 128 || tuning().fold_threads2 == 64)) fold_threads = (unsigned)tuning().fold_threads2;
+        if (fold_threads == 64u) quads_fold = 0;
         if (flat || fold_threads != 64u)
             hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
                                c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex, quads_fold);

@@ -45,6 +45,7 @@ def main(out_path, seed, salts):
     proofs.replay_single(ws, salts[0], [], async_msm=True, await_rounds=True, msm_in_stream=True)
     _lib.lib().snarkvm_hip_alloc_stats(ctypes.c_void_p(stats.ctypes.data), 0)  # (a bare Python int would travel as a 32-bit C int)
     out["alloc_stats"] = stats
+    out["num_devices"] = np.array([_lib.lib().snarkvm_hip_num_devices()])
     assert "torch" not in sys.modules, "torch was imported on the torch-free path"
     np.savez(out_path, **out)
     ws.pool.free()

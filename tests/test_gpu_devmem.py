@@ -124,5 +124,8 @@ def test_torch_free_process_replays_a_proof_every_result_vs_oracle(tmp_path):
                 ref = proofs.normalize_results(got)
             else:
                 assert proofs.normalize_results(got) == ref, (salt, mode)
-    assert not res["alloc_stats"][:4].any(), res["alloc_stats"]
+    # (several logical devices: device pointers are dealt round-robin over the logical devices of their GPU, a later replay may meet a lane for the first time -
+    # the same reason test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower skips there)
+    if int(res["num_devices"][0]) == 1:
+        assert not res["alloc_stats"][:4].any(), res["alloc_stats"]
     keys.close()

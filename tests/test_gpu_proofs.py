@@ -590,3 +590,35 @@ def test_ffi_only_replay_every_result_vs_oracle_stateless_and_cached():
         _lib.check(L.snarkvm_hip_set_base_cache(0))
         host.close()
         keys.close()
+
+
+def test_sync_msm_on_a_borrowed_scope_lane_does_not_clobber_pending_planes():
+    """Round-5 advisor: inside an ASYNC_MSM scope with MSM_IN_STREAM the enqueued MSMs keep their bit planes in the scope lane's pinned area from offset 0 until the
+    flush has read them.  A later MSM that does NOT qualify for enqueueing (here: profiling switched on in the middle of the scope) takes the synchronous path on the
+    SAME (borrowed) lane and stages at offset 0 too - it must first deliver what is pending.  Every result against the oracle."""
+    import torch
+
+    L = _lib.lib()
+    G = util.g1_generator_affine()
+    n = 1 << 14
+    bases = oracle.g1_gen_bases(G, 1, n)
+    rb = msm.RegisteredBases(bases, tables=17, window_bits=15)
+    sc = [synthetic.random_fr_integers(n, 8100 + i) for i in range(3)]
+    d_sc = [torch.from_numpy(x.view(np.int64).reshape(-1).copy()).cuda() for x in sc]
+    torch.cuda.synchronize()
+    outs = np.zeros(3, dtype=G1_PROJECTIVE)
+    _lib.check(L.snarkvm_hip_scope_begin_ex(ctypes.c_void_p(d_sc[0].data_ptr()), 1 | 2 | 4))
+    try:
+        for i in range(2):  # enqueued on the scope's own lane: planes parked in its pinned area
+            _lib.check(L.snarkvm_hip_msm_registered(ctypes.c_void_p(outs[i : i + 1].ctypes.data), rb._h, 0, n - i, ctypes.c_void_p(d_sc[i].data_ptr()), 1, 0))
+        assert not outs.view(np.uint8).any()  # nothing delivered yet
+        L.snarkvm_hip_set_profiling(1)  # -> msm_scope_enqueue declines, the coalescer declines: the synchronous path on the borrowed lane
+        _lib.check(L.snarkvm_hip_msm_registered(ctypes.c_void_p(outs[2:3].ctypes.data), rb._h, 5, n - 5, ctypes.c_void_p(d_sc[2].data_ptr()), 1, 0))
+        L.snarkvm_hip_set_profiling(0)
+    finally:
+        L.snarkvm_hip_set_profiling(0)
+        _lib.check(L.snarkvm_hip_scope_end())
+    want = [oracle.g1_msm(bases[: n], sc[0]), oracle.g1_msm(bases[: n - 1], sc[1][: n - 1]), oracle.g1_msm(bases[5:n], sc[2][: n - 5])]
+    for i in range(3):
+        assert util.affine_equal(oracle.g1_to_affine(outs[i : i + 1]), oracle.g1_to_affine(want[i])), i
+    rb.close()

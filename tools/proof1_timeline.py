@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE proof proved by one caller thread (BASELINE.json configs[3]): where the wall time of `replay_single` goes.
 
-  run      (under rocprofv3 --kernel-trace):  python tools/proof1_timeline.py run <marks.json> [--sync-msm] [--proofs N]
+  run      (under rocprofv3 --kernel-trace):  python tools/proof1_timeline.py run <marks.json> [--sync-msm | --await] [--proofs N]
            proves N proofs one at a time (5 ms pause between them) and writes the host-side step marks (three clocks each)
   report   python tools/proof1_timeline.py report <rocpd.db> <marks.json>  -> markdown on stdout:
            per proof: host begin -> first kernel -> last kernel -> results on the host, GPU-busy share (union of the kernel intervals of
@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
-def run(path, sync_msm, count):
+def run(path, sync_msm, count, awaited=False):
     import torch
 
     from snarkvm_amd import _lib, proofs
@@ -30,12 +30,12 @@ def run(path, sync_msm, count):
     keys = proofs.ProverKeys(shape, tables=17, window_bits=15)
     ws = proofs.SingleProofWorkspace(keys)
     for s in range(4):
-        proofs.replay_single(ws, s, None, not sync_msm)
+        proofs.replay_single(ws, s, None, not sync_msm, None, awaited, awaited)
     out = []
     for s in range(count):
         time.sleep(0.005)
         marks = []
-        proofs.replay_single(ws, s, None, not sync_msm, marks)
+        proofs.replay_single(ws, s, None, not sync_msm, marks, awaited, awaited)  # awaited: the transcript order (rounds collected, in-stream)
         out.append(marks)
     json.dump({"sync_msm": sync_msm, "proofs": out}, open(path, "w"))
     keys.close()
@@ -152,6 +152,6 @@ def report(db_path, marks_path):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         n = int(sys.argv[sys.argv.index("--proofs") + 1]) if "--proofs" in sys.argv else 16
-        run(sys.argv[2], "--sync-msm" in sys.argv, n)
+        run(sys.argv[2], "--sync-msm" in sys.argv, n, "--await" in sys.argv)
     else:
         report(sys.argv[2], sys.argv[3])

@@ -57,7 +57,11 @@ def main():
     env = dict(os.environ)
     env.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.tsan:
-        env["TSAN_OPTIONS"] = env.get("TSAN_OPTIONS", "halt_on_error=0 report_signal_unsafe=0 history_size=4 second_deadlock_stack=1")
+        # The HIP / HSA runtimes are not instrumented: their internal synchronisation (own atomics, futexes, doorbells) is invisible to the tool, so every
+        # heap word they recycle between their threads looks like a race.  Reports whose racing access sits INSIDE those libraries are suppressed; what stays
+        # are races whose accesses are in this library, in the soak, or in instrumented code they call.
+        supp = os.path.join(ROOT, "tools", "tsan_suppressions.txt")
+        env["TSAN_OPTIONS"] = env.get("TSAN_OPTIONS", f"halt_on_error=0 report_signal_unsafe=0 history_size=4 second_deadlock_stack=1 exitcode=0 suppressions={supp}")
     r = subprocess.run([exe, str(args.seconds), str(args.threads), str(args.seed), str(args.devices)], capture_output=True, text=True, env=env,
                        timeout=args.seconds + 900)
     line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
@@ -67,12 +71,23 @@ def main():
     if args.tsan:
         reports = re.split(r"(?m)^==================\n", r.stderr)
         reports = [x for x in reports if "WARNING: ThreadSanitizer" in x]
-        ours = [x for x in reports if re.search(r"(runtime\.hip\.h|api\w*\.hip|msm\w*\.hip\.h|ntt\.hip\.h|poly\.hip\.h|soak\.cpp)", x)]
-        rep["tsan"] = {"reports": len(reports), "reports_naming_this_library_or_the_soak": len(ours),
-                       "kinds": sorted({m.group(1) for x in reports for m in [re.search(r"WARNING: ThreadSanitizer: ([^(\n]+)", x)] if m})}
+
+        def where(x):  # the module / source location of the SUMMARY line = the racing access the tool blames
+            m = re.search(r"SUMMARY: ThreadSanitizer: [^/(]*\(?([^\s)]+)", x)
+            return m.group(1) if m else "?"
+
+        runtime_internal = [x for x in reports if re.search(r"libamdhip64|libhsa-runtime64|libhsakmt|librocprofiler|libdrm", where(x))]
+        ours = [x for x in reports if x not in runtime_internal]
+        by_site = {}
+        for x in ours:
+            by_site[where(x)] = by_site.get(where(x), 0) + 1
+        rep["tsan"] = {"reports_after_suppressions": len(reports), "inside_the_uninstrumented_hip_hsa_runtimes": len(runtime_internal), "in_this_library_or_the_soak": len(ours),
+                       "sites": by_site, "kinds": sorted({m.group(1).strip() for x in reports for m in [re.search(r"WARNING: ThreadSanitizer: ([^(\n]+)", x)] if m}),
+                       "suppressed_by_tool": (re.findall(r"ThreadSanitizer: Matched (\d+) suppressions", r.stderr) or ["0"])[-1]}
+        rep["ok"] = bool(rep.get("ok")) and not ours
         if args.out:
             with open(os.path.splitext(args.out)[0] + ".tsan.txt", "w") as f:
-                f.write("\n==================\n".join(ours[:20]) if ours else (r.stderr[-20000:] if reports else "no ThreadSanitizer reports\n"))
+                f.write("\n==================\n".join(ours[:40]) if ours else ("no ThreadSanitizer report names this library or the soak\n" + "\n==================\n".join(runtime_internal[:3])))
     else:
         rep["stderr_tail"] = r.stderr[-1500:]
     print(json.dumps(rep))
@@ -80,7 +95,7 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
             json.dump(rep, f, indent=1)
-    sys.exit(0 if rep.get("ok") and r.returncode == 0 else 1)
+    sys.exit(0 if rep.get("ok") and (r.returncode == 0 or args.tsan) else 1)
 
 
 if __name__ == "__main__":
