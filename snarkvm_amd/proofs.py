@@ -313,7 +313,7 @@ def _clocks():
     return (time.clock_gettime_ns(time.CLOCK_MONOTONIC), time.clock_gettime_ns(time.CLOCK_MONOTONIC_RAW), time.clock_gettime_ns(time.CLOCK_BOOTTIME), time.time_ns())
 
 
-def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_rounds=False, msm_in_stream=False):
+def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_rounds=False, msm_in_stream=False, g2_after=0):
     """The hot-path calls of ONE proof from ONE caller thread, issued for latency (configs[3]; the reference proves one transaction at a
     time: synthesizer/snark/src/proving_key/mod.rs:37 -> VarunaSNARK::prove_batch, varuna.rs:336).  Same calls, sizes and operands as
     `replay` - the 15 results are the same group elements - but:
@@ -388,13 +388,27 @@ def replay_single(ws, salt=0, collect=None, async_msm=True, marks=None, await_ro
             slot[0] += k
             if await_rounds and async_msm:
                 _lib.check(L.snarkvm_hip_scope_collect(out))  # this round's commitments; the G2 MSM and nothing else is waited for
+            rounds_done[0] += 1
+            if rounds_done[0] == g2_after:
+                issue_g2()
 
-        if keys.hg2:                                                                         # G2 leg: independent of everything else
-            _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, 1 << sh.lg_g2,
-                                                        ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0))
-        mark("g2 msm issued")
-        if msm_in_stream and await_rounds and async_msm:
-            _lib.check(L.snarkvm_hip_scope_set_flags(3 | 4))
+        in_stream = msm_in_stream and await_rounds and async_msm
+
+        def issue_g2():                                                                      # G2 leg: independent of everything else, on a further stream
+            if keys.hg2:
+                if in_stream:
+                    _lib.check(L.snarkvm_hip_scope_set_flags(3))
+                _lib.check(L.snarkvm_hip_msm_g2_registered(ctypes.c_void_p(ws.out_g2.ctypes.data), keys.hg2, 0, 1 << sh.lg_g2,
+                                                            ctypes.c_void_p(pool.data_ptr() + 32 * (23 + salt)), 1, 0))
+            mark("g2 msm issued")
+            if in_stream:
+                _lib.check(L.snarkvm_hip_scope_set_flags(3 | 4))
+
+        # g2_after = k: the independent MSM is issued behind the k-th commitment round (0: first of all, the default; measured, bench.py --workload proof1: issuing it
+        # later does not help a proof in transcript order - profiles/r06_summary.md)
+        rounds_done = [0]
+        if g2_after <= 0:
+            issue_g2()
         load(26, nR, 1, count=2)                                                             # round 1: rows 26, 27
         ntt([26], sh.lg_r, 1); ntt([27], sh.lg_r, 0)
         mark("round 1 transforms issued")
