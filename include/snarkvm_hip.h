@@ -395,6 +395,11 @@ int snarkvm_hip_selftest_fq2_pair(const void *points, size_t npoints, uint64_t s
  * `iters` additions of partial sums of +- points[k], with operands at infinity, P + P and P - P among them.  0 = every lane of every addition ends
  * with exactly the exact sum; > 0: first differing iteration. */
 int snarkvm_hip_selftest_g2_hex(const void *points, size_t npoints, uint64_t seed, int iters);
+/* Device check: the G2 fold / bit-plane kernels launched `iters` times over one fixed set of partial-sum lists (2^(m + hb) buckets) must leave
+ * the same group elements.  report[10]: [0] fold launches differing from the first, [1] differing fold slots, [2] bit-plane launches differing,
+ * [3] differing planes, [4..7] first differing fold slots, [8], [9] fold slots / planes the fast kernels handed to the fix kernels (equal x met). */
+RustError snarkvm_hip_devtest_g2_tail_repeat(const void *points, size_t npoints, int m, int hb, int threads, int plane_threads,
+                                             int hex, int quads, int iters, uint32_t *report);
 /* The signed-limb butterfly arithmetic of the NTT passes (csrc/frs.hip.h) against the exact arithmetic, on the host: passes of up
  * to nine butterfly stages without a canonical form in between, the closing product, the bare reduction and the folded table
  * form.  0 = identical; > 0: first differing butterfly; < 0: a closing-step case. */

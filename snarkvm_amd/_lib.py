@@ -27,7 +27,7 @@ SYMBOLS = [
     "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
     "snarkvm_hip_set_profiling", "snarkvm_hip_get_phase_count", "snarkvm_hip_get_phase_name",
     "snarkvm_hip_get_phase_ms", "snarkvm_hip_synchronize", "snarkvm_hip_coalescer_stats",
-    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_g1_lazy_tail", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_selftest_fq2_pair", "snarkvm_hip_selftest_g2_hex", "snarkvm_hip_devtest_field",
+    "snarkvm_hip_selftest_field", "snarkvm_hip_selftest_g1_msm_naive", "snarkvm_hip_selftest_msm_plan", "snarkvm_hip_selftest_g1_finish", "snarkvm_hip_selftest_fq_lazy", "snarkvm_hip_selftest_g1_lazy_tail", "snarkvm_hip_selftest_fr_signed", "snarkvm_hip_selftest_fq2_lazy", "snarkvm_hip_selftest_fq2_pair", "snarkvm_hip_selftest_g2_hex", "snarkvm_hip_devtest_field", "snarkvm_hip_devtest_g2_tail_repeat",
 ]
 
 
@@ -75,7 +75,7 @@ def lib():
                    "snarkvm_hip_register_bases_serialized", "snarkvm_hip_g1_deserialize", "snarkvm_hip_g1_serialize", "snarkvm_hip_g1_sum", "snarkvm_hip_g2_deserialize", "snarkvm_hip_g2_serialize", "snarkvm_hip_g2_deserialize_compressed", "snarkvm_hip_g2_serialize_compressed",
                    "snarkvm_hip_register_bases_g2", "snarkvm_hip_msm_g2_registered", "snarkvm_hip_msm_g2_registered_batch",
                    "snarkvm_hip_g1_fixed_base_msm", "snarkvm_hip_g1_group_ntt",
-                   "snarkvm_hip_devtest_field"]
+                   "snarkvm_hip_devtest_field", "snarkvm_hip_devtest_g2_tail_repeat"]
         for name in err_fns:
             getattr(L, name).restype = RustError
         L.snarkvm_hip_device_count.restype = ctypes.c_int

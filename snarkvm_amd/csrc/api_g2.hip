@@ -331,6 +331,98 @@ int snarkvm_hip_selftest_fq2_pair(const void* points, size_t npoints, uint64_t s
 #endif
 }
 
+// The G2 fold and bit-plane kernels launched `iters` times over ONE fixed set of per-bucket partial-sum lists (2^(m + hb) buckets of one window; 0, 1 or 2
+// entries per bucket - the sparse shape of a small MSM over window tables - built from +- points[k]): every launch must leave the same group elements.
+// A difference is a race or a lost register, whatever the points are.  threads: per fold workgroup (64, 128, 256);
+// plane_threads likewise; hex / quads: the kernels' switches.  report[0] = fold launches that differ from the first, report[1] = differing fold slots in
+// total, report[2] = bit-plane launches that differ from the first, report[3] = differing planes in total, report[4 .. 7] = the first differing fold slots, report[8], [9] = fold slots / planes of the first launch the fast
+// kernels flagged for the fix kernels (equal x coordinates met on the way).
+RustError snarkvm_hip_devtest_g2_tail_repeat(const void* points, size_t npoints, int m, int hb, int threads, int plane_threads, int hex, int quads, int iters,
+                                             uint32_t* report) {
+    API_BEGIN
+#ifdef SV_NO_G2
+    (void)points, (void)npoints, (void)m, (void)hb, (void)threads, (void)plane_threads, (void)hex, (void)quads, (void)iters, (void)report;
+    throw hip_failure{hipErrorNotSupported, "this development build was compiled without G2 (SV_NO_G2)", __LINE__};
+#else
+    if (!points || npoints < 2 || !report || m < 1 || hb < 1 || hb > m || m + hb > 16 || iters < 2 || (threads != 64 && threads != 128 && threads != 256) ||
+        (plane_threads != 64 && plane_threads != 128 && plane_threads != 256))
+        throw hip_failure{hipErrorInvalidValue, "devtest_g2_tail_repeat: bad arguments", __LINE__};
+    typedef xyzz_mem_t<fq2_t> mem_t;
+    const uint32_t nb = 1u << (m + hb);
+    std::vector<uint32_t> cnt(nb), start(nb);
+    uint32_t E = 0;
+    for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t h = (k * 2654435761u) >> 28;
+        cnt[k] = h == 0 ? 2 : h == 1 ? 0 : 1;
+        start[k] = E;
+        E += cnt[k];
+    }
+    std::vector<mem_t> sums(E);
+    for (uint32_t q = 0; q < E; q++) {
+        const uint32_t* src = (const uint32_t*)((const uint8_t*)points + 200 * (size_t)((q * 7u + 3u) % npoints));
+        xyzz_t<fq2_t> a = xyzz_t<fq2_t>::inf();
+        a.add_affine({fq2_t::from_raw_words(src), fq2_t::from_raw_words(src + 24)}, ((q >> 3) & 1) != 0);
+        store_xyzz<fq2_t>(&sums[q], a);
+    }
+    const size_t nslots = (size_t)1 << (m + 1), nbits = (size_t)m + 1, nplanes = 2 * nbits;
+    c.part_a.ensure(E * sizeof(mem_t));
+    c.cnt_a.ensure(nb * 4);
+    c.start_a.ensure(nb * 4);
+    c.fold_sums.ensure(2 * nslots * sizeof(mem_t));  // [0]: the first launch's output (the bit planes read it), [1]: the launch under test
+    c.planes.ensure(nplanes * sizeof(mem_t));
+    c.tail_flags.ensure((nslots + nplanes) * 4);
+    std::vector<uint32_t> flag_copy(nslots + nplanes, 0);
+    HIP_TRY(hipMemcpyAsync(c.part_a.p, sums.data(), E * sizeof(mem_t), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.cnt_a.p, cnt.data(), nb * 4, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.start_a.p, start.data(), nb * 4, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemsetAsync(c.fold_sums.p, 0, 2 * nslots * sizeof(mem_t), c.stream));
+    std::vector<uint8_t> first(nslots * sizeof(mem_t)), got(nslots * sizeof(mem_t)), p_first(nplanes * sizeof(mem_t)), p_got(nplanes * sizeof(mem_t));
+    for (int i = 0; i < 10; i++) report[i] = 0;
+    int nfirst = 0;
+    auto same_point = [](const xyzz_t<fq2_t>& a, const xyzz_t<fq2_t>& b) {  // as group elements (the coordinates of a point at infinity are arbitrary)
+        if (a.is_inf() || b.is_inf()) return a.is_inf() == b.is_inf();
+        return a.x * b.zz == b.x * a.zz && a.y * b.zzz == b.y * a.zzz;
+    };
+    for (int it = 0; it < iters; it++) {
+        mem_t* out = c.fold_sums.as<mem_t>() + (it ? nslots : 0);
+        uint32_t* fold_flags = c.tail_flags.as<uint32_t>();
+        uint32_t* plane_flags = fold_flags + nslots;
+        const dim3 fold_grid((1u << m) + (1u << hb), 1u), plane_grid((unsigned)nbits, 2u);
+        hipLaunchKernelGGL((msm_fold_kernel<fq2_t, true>), fold_grid, dim3((unsigned)threads), 0, c.stream, (const mem_t*)c.part_a.as<mem_t>(),
+                           (const uint32_t*)c.start_a.as<uint32_t>(), (const uint32_t*)c.cnt_a.as<uint32_t>(), out, m, hb, hex, quads & 2 ? 1 : 0, fold_flags);
+        hipLaunchKernelGGL((msm_fold_fix_kernel<fq2_t>), fold_grid, dim3(64), 0, c.stream, (const mem_t*)c.part_a.as<mem_t>(), (const uint32_t*)c.start_a.as<uint32_t>(),
+                           (const uint32_t*)c.cnt_a.as<uint32_t>(), out, m, hb, (const uint32_t*)fold_flags);
+        hipLaunchKernelGGL((msm_bitplane_kernel<fq2_t, true>), plane_grid, dim3((unsigned)plane_threads), 0, c.stream, (const mem_t*)c.fold_sums.as<mem_t>(),
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, c.planes.as<mem_t>(), nb, m, hb, hex, quads & 1, plane_flags);
+        hipLaunchKernelGGL((msm_bitplane_fix_kernel<fq2_t, true>), plane_grid, dim3(64), 0, c.stream, (const mem_t*)c.fold_sums.as<mem_t>(), (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, c.planes.as<mem_t>(), nb, m, hb, (const uint32_t*)plane_flags);
+        if (!it) HIP_TRY(hipMemcpyAsync(flag_copy.data(), fold_flags, (nslots + nplanes) * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(it ? got.data() : first.data(), out, nslots * sizeof(mem_t), hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(it ? p_got.data() : p_first.data(), c.planes.p, nplanes * sizeof(mem_t), hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (!it) continue;
+        uint32_t bad = 0;
+        for (size_t sl = 0; sl + 1 < nslots; sl++)  // (the last slot is never written)
+            if (!same_point(load_xyzz<fq2_t>((const mem_t*)&first[sl * sizeof(mem_t)]), load_xyzz<fq2_t>((const mem_t*)&got[sl * sizeof(mem_t)]))) {
+                bad++;
+                if (nfirst < 4) report[4 + nfirst++] = (uint32_t)sl;
+            }
+        report[0] += bad ? 1 : 0;
+        report[1] += bad;
+        bad = 0;
+        for (size_t pl = 0; pl < nplanes; pl++)
+            if (!same_point(load_xyzz<fq2_t>((const mem_t*)&p_first[pl * sizeof(mem_t)]), load_xyzz<fq2_t>((const mem_t*)&p_got[pl * sizeof(mem_t)]))) bad++;
+        report[2] += bad ? 1 : 0;
+        report[3] += bad;
+    }
+    report[8] = report[9] = 0;  // outputs of the first launch the fast kernels flagged (fold slots, planes): the fix kernels' share of the work
+    for (size_t sl = 0; sl + 1 < nslots; sl++) report[8] += flag_copy[sl] ? 1 : 0;  // (the unwritten slots' flags are whatever the buffer held)
+    for (size_t pl = 0; pl < nplanes; pl++) report[9] += flag_copy[nslots + pl] ? 1 : 0;
+#endif
+    API_END
+}
+
 // The sixteen-lane cooperative Fq2 addition of the G2 tail trees (csrc/hex2.hip.h) on sixteen SIMULATED lanes - the same source as the kernel's, every lane
 // with its own copy of the state, the pair exchange and the gathers indexing the other lanes' copies - against xyzz_t<fq2_t>::add: `iters` additions of partial
 // sums built from +- points[k] (general ZZ / ZZZ), with the cases a tree meets: an operand at infinity (either, both), P + P (every lane must ask for the

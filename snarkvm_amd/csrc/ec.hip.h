@@ -94,7 +94,11 @@ struct xyzz_t {
     // (out of line: -5 % there), and so does everything over Fq (out of line: the 2^16 tail 0.184 vs 0.167 ms) unless the
     // A/B switch -DSV_COLD_OOL asks otherwise (`python -m snarkvm_amd.build --ool`).
     // The callee works on copies (an object whose address escapes would live in scratch for the caller).
+#if defined(SV_TU_TAIL)  // the tail units hold no device-function call at all: their only full additions sit in the small fix kernels (msm.hip.h)
+    static constexpr bool COLD_DBL_OOL = false;
+#else
     static constexpr bool COLD_DBL_OOL = sizeof(F) > 64;
+#endif
     static SV_COLD void cold_dbl_affine(xyzz_t* out, const aff_t<F>* p) { *out = dbl_affine(*p); }
     static SV_COLD void cold_dbl(xyzz_t* out, const xyzz_t* a) { *out = a->dbl(); }
     static __host__ __device__ __noinline__ void cold_dbl_ool(xyzz_t* out, const xyzz_t* a) { *out = a->dbl(); }
@@ -132,7 +136,12 @@ struct xyzz_t {
         zzz = zzz * ppp;
     }
     // this += o  (add-2008-s)
-    SV_HD void add(const xyzz_t& o) {
+    SV_HD void add(const xyzz_t& o) { add_impl<false>(o, nullptr); }
+    // this += o without the exceptional cases: equal x coordinates (P + P, P - P) set `dbl` and leave *this as it was.  For the kernels that keep the
+    // exceptional law out of their code and have the flagged outputs recomputed by a second, plain kernel (msm.hip.h: the Fq2 fold / bit planes).
+    SV_HD void add_flag(const xyzz_t& o, bool& dbl) { add_impl<true>(o, &dbl); }
+    template <bool FLAG>
+    SV_HD void add_impl(const xyzz_t& o, bool* dbl) {
         if (o.is_inf()) return;
         if (is_inf()) {
             *this = o;
@@ -145,7 +154,9 @@ struct xyzz_t {
         F pp_ = u2 - u1;
         F r = s2 - s1;
         if (pp_.is_zero()) {
-            if (r.is_zero()) {
+            if constexpr (FLAG) {
+                *dbl = true;
+            } else if (r.is_zero()) {
                 const xyzz_t self = *this;
                 xyzz_t d;
                 if constexpr (COLD_DBL_OOL)

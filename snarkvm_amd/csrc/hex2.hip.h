@@ -13,8 +13,7 @@
 //      its sub-product p:   p = 0: a.c0 b.c0   p = 1: a.c1 b.c1   p = 2: a.c0 b.c1   p = 3: a.c1 b.c0
 //   2. pair exchange inside the quad (lane p <-> p ^ 1, one `quad_perm:[1,0,3,2]` per limb); lanes 0, 1 form c0 = P0 - 5 P1 (u^2 = -5,
 //      curves/src/bls12_377/fq2.rs:27-93), lanes 2, 3 form c1 = P2 + P3
-//   3. gather: every lane reads c0 of slot q' from lane 4 q' and c1 from lane 4 q' + 2 of its row (DPP `row_newbcast`, one VALU move per limb; the
-//      A/B form goes through ds_bpermute), for the slots of the round that carry a product - afterwards all sixteen lanes hold the round's Fq2
+//   3. gather: every lane reads c0 of slot q' from lane 4 q' and c1 from lane 4 q' + 2 of its row (DPP `row_newbcast`, one VALU move per limb), for the slots of the round that carry a product - afterwards all sixteen lanes hold the round's Fq2
 //      results, identically.
 // The values are canonical Montgomery residues (ff.hip.h: every operation returns the reduced representative), so the sum is BIT-IDENTICAL to
 // quad_add's and to xyzz_t<fq2_t>::add's: same formula, same field values, one limb image per value.
@@ -171,15 +170,10 @@ static inline int hex_add_host_check(const xyzz_t<fq2_t>& a, const xyzz_t<fq2_t>
 
 #if defined(__HIPCC__)
 // ---- the GPU row ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ fq_t hex_row_read(const fq_t& a, int src) {  // lane `src` (0 .. 15) of the caller's row
-    fq_t r;
-#pragma unroll
-    for (int i = 0; i < fq_t::N; i++) r.v[i] = (uint32_t)__shfl((int)a.v[i], src, 16);
-    return r;
-}
 // DPP `row_newbcast:N` (gfx90a+): every lane of a row reads lane N of ITS row inside the VALU - no LDS round trip, no s_waitcnt.  (The first
 // form of this file gathered with ds_bpermute: 364 of them per addition, each batch followed by an exposed LDS latency - measured, the sixteen-lane
-// addition then cost what the four-lane one costs, tools/g2_tail.sh.)  tools/exp/dpp_bcast.hip checks the control's semantics on the hardware.
+// addition then cost what the four-lane one costs, profiles/r06_g2_tail.md; that variant is gone.)  tools/exp/dpp_bcast.hip checks the control's semantics
+// on the hardware.
 template <int LANE>
 __device__ __forceinline__ fq_t hex_row_bcast(const fq_t& a) {
     fq_t r;
@@ -187,7 +181,6 @@ __device__ __forceinline__ fq_t hex_row_bcast(const fq_t& a) {
     for (int i = 0; i < fq_t::N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0x150 + LANE, 0xf, 0xf, true);
     return r;
 }
-template <bool DPP>
 struct hex_dev {
     hex_lane_t& s;
     template <class Fn>
@@ -201,13 +194,8 @@ struct hex_dev {
     template <int Q>
     __device__ __forceinline__ void gather_slot(unsigned mask) {
         if ((mask >> Q) & 1) {
-            if constexpr (DPP) {
-                s.m[Q].c0 = hex_row_bcast<4 * Q>(s.comb);
-                s.m[Q].c1 = hex_row_bcast<4 * Q + 2>(s.comb);
-            } else {
-                s.m[Q].c0 = hex_row_read(s.comb, 4 * Q);
-                s.m[Q].c1 = hex_row_read(s.comb, 4 * Q + 2);
-            }
+            s.m[Q].c0 = hex_row_bcast<4 * Q>(s.comb);
+            s.m[Q].c1 = hex_row_bcast<4 * Q + 2>(s.comb);
         }
     }
     __device__ __forceinline__ void gather(unsigned mask) {
@@ -217,24 +205,20 @@ struct hex_dev {
         gather_slot<3>(mask);
     }
 };
-// the cold path (equal x coordinates somewhere in the wave: P = +-Q, one pair in 2^377 for random operands): the plain law, out of line
-static __device__ __noinline__ void hex_add_plain_ool(xyzz_t<fq2_t>* acc, const xyzz_t<fq2_t>* o) { acc->add(*o); }
 // acc += o.  Precondition: the sixteen lanes of every row hold bit-identical (acc, o); postcondition: they hold the bit-identical sum.
 // Every lane of the wave must call it (the gathers are wave operations).
-template <bool DPP>
-__device__ __forceinline__ void hex_add_t(xyzz_t<fq2_t>& acc, const xyzz_t<fq2_t>& o) {
+// Equal x coordinates (P = U2 - U1 = 0; every lane of the row sees it after round 1) anywhere in the wave set `dbl` and abandon the addition: the kernel marks its
+// output and msm_*_fix_kernel (msm.hip.h) recomputes it with the plain law.  No device-function call, no second copy of the law in the kernel.
+__device__ __forceinline__ void hex_add(xyzz_t<fq2_t>& acc, const xyzz_t<fq2_t>& o, bool& dbl) {
     hex_lane_t s;
     s.A = acc;
     s.B = o;
-    hex_dev<DPP> ex{s};
+    hex_dev ex{s};
     const bool inf1 = acc.is_inf(), inf2 = o.is_inf();
     hex_add_round1(ex);
     const bool same_x = !inf1 && !inf2 && s.P.is_zero();
-    if (__ballot(same_x) != 0) {  // wave-uniform: every lane of every row takes the plain law
-        xyzz_t<fq2_t> a2 = acc;
-        const xyzz_t<fq2_t> o2 = o;
-        hex_add_plain_ool(&a2, &o2);
-        acc = a2;
+    if (__ballot(same_x) != 0) {  // wave-uniform
+        dbl = true;               // (every lane of the wave: the flag is per output anyway)
         return;
     }
     hex_add_rounds234(ex);
@@ -242,13 +226,6 @@ __device__ __forceinline__ void hex_add_t(xyzz_t<fq2_t>& acc, const xyzz_t<fq2_t
     acc.y = hex_pick(inf2, acc.y, hex_pick(inf1, o.y, s.res.y));
     acc.zz = hex_pick(inf2, acc.zz, hex_pick(inf1, o.zz, s.res.zz));
     acc.zzz = hex_pick(inf2, acc.zzz, hex_pick(inf1, o.zzz, s.res.zzz));
-}
-// hex: 1 = gathers through ds_bpermute, 2 = through DPP row broadcasts (wave-uniform)
-__device__ __forceinline__ void hex_add(xyzz_t<fq2_t>& acc, const xyzz_t<fq2_t>& o, int hex) {
-    if (hex >= 2)
-        hex_add_t<true>(acc, o);
-    else
-        hex_add_t<false>(acc, o);
 }
 #endif
 

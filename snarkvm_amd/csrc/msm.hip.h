@@ -527,24 +527,24 @@ __device__ __forceinline__ xyzz_t<F> select_point(bool c, const xyzz_t<F>& a, co
 //   round 4   ZZZ3 = ZZZ1 ZZZ2 PPP | -  | R (Q - X3)   | S1 PPP            with X3 = R^2 - PPP - 2 Q
 // Operands move between the lanes as DPP quad permutations.  Infinity operands are a final select; P = +-Q (U1 == U2) in any
 // quad sends the whole wave through the plain formula (wave-uniform branch; every lane of a quad takes the same path).
-// the cold fallback of quad_add (equal x coordinates somewhere in the wave): inlined for Fq, out of line for Fq2 (see ec.hip.h)
+// Fq2 (TAIL_FLAGGED): the fallback is not in the kernel.  Equal x coordinates anywhere in the wave set `dbl` and abandon the addition - the kernel marks its output
+// and msm_*_fix_kernel recomputes it with the plain law.
+// The Fq2 tail kernels therefore hold neither a second copy of the addition law per site (~48 000 instructions each) nor a device-function call: round 6
+// measured calls inside these ~260 000-instruction kernels coming back with live registers of the caller overwritten, with the compiler's interprocedural
+// register allocation on AND off, from one source revision to the next (tests/test_gpu_parity.py::test_msm_of_repeated_points_repeats_and_matches_the_oracle).
 template <class F>
-static __device__ __noinline__ void quad_add_plain_ool(xyzz_t<F>* acc, const xyzz_t<F>* o) {
-    acc->add(*o);
-}
+struct TAIL_FLAGGED {
+    static constexpr bool value = sizeof(F) > 64;
+};
 template <class F>
-__device__ __forceinline__ void quad_add_plain(xyzz_t<F>* acc, const xyzz_t<F>* o) {
-#if defined(SV_COLD_OOL)
-    quad_add_plain_ool<F>(acc, o);
-#else
-    if constexpr (sizeof(F) > 64)
-        quad_add_plain_ool<F>(acc, o);
+__device__ __forceinline__ void tail_add(xyzz_t<F>& acc, const xyzz_t<F>& o, bool& dbl) {  // the plain one-lane addition of a tail kernel
+    if constexpr (TAIL_FLAGGED<F>::value)
+        acc.add_flag(o, dbl);
     else
-        acc->add(*o);
-#endif
+        acc.add(o);
 }
 template <class F>
-__device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
+__device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o, bool& dbl) {
     const uint32_t r = threadIdx.x & 3;
     const bool inf1 = acc.is_inf(), inf2 = o.is_inf();
     F a = select_field(r < 2, select_field(r == 0, acc.x, o.x), select_field(r == 2, acc.y, o.y));
@@ -553,11 +553,11 @@ __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
     const F t = quad_perm_field<0xB1>(m1);       // U2 | U1 | S2 | S1   (lanes swapped inside pairs)
     const F d = select_field((r & 1) != 0, m1, t) - select_field((r & 1) != 0, t, m1);  // P | P | R | R
     const bool same_x = !inf1 && !inf2 && r < 2 && d.is_zero();
-    if (__ballot(same_x) != 0) {
-        xyzz_t<F> a2 = acc;
-        const xyzz_t<F> o2 = o;
-        quad_add_plain<F>(&a2, &o2);
-        acc = a2;
+    if (__ballot(same_x) != 0) {  // wave-uniform
+        if constexpr (TAIL_FLAGGED<F>::value)
+            dbl = true;  // (every lane of the wave: the flag is per output anyway)
+        else
+            acc.add(o);  // Fq: the plain law, inlined
         return;
     }
     a = select_field((r & 1) == 0, d, select_field(r == 1, acc.zz, acc.zzz));
@@ -578,6 +578,12 @@ __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
     res.zzz = quad_bcast<0>(m4);
     acc = select_point(inf2, acc, select_point(inf1, o, res));
 }
+template <class F>
+__device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {  // callers outside the tail kernels (group.hip.h: G1 only)
+    static_assert(!TAIL_FLAGGED<F>::value, "the Fq2 form reports P + P instead of computing it");
+    bool unused = false;
+    quad_add(acc, o, unused);
+}
 // Sum of `acc` over the lanes of a workgroup of 64, 256 or 1024 threads; the result is valid in thread 0.  Level 1 (lane
 // pairs) is a plain addition with the operands in the same order on both lanes, so that from level 2 on the four lanes of a
 // quad hold bit-identical operands and share every addition (quad_add); the wave totals go through LDS to wave 0, whose quads
@@ -588,19 +594,19 @@ __device__ __forceinline__ void quad_add(xyzz_t<F>& acc, const xyzz_t<F>& o) {
 // from_quads: the four lanes of every quad already hold ONE bit-identical value (a quad-strided accumulation, tail_quad_accumulate below): the two
 // intra-quad levels - the only ones with a plain, one-lane addition - do not exist.
 template <class F>
-__device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int hex = 0, bool from_quads = false) {
+__device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int hex, bool from_quads, bool& dbl) {
     if (!from_quads) {
         const xyzz_t<F> o = shfl_xor_point(acc, 1);
         const bool odd = (threadIdx.x & 1) != 0;
         xyzz_t<F> lo = select_point(odd, o, acc);
-        lo.add(select_point(odd, acc, o));
+        tail_add(lo, select_point(odd, acc, o), dbl);
         acc = lo;
     }
     if (!from_quads) {
         const xyzz_t<F> o = shfl_xor_point(acc, 2);
         const bool hi = (threadIdx.x & 2) != 0;
         xyzz_t<F> lo = select_point(hi, o, acc);
-        quad_add(lo, select_point(hi, acc, o));
+        quad_add(lo, select_point(hi, acc, o), dbl);
         acc = lo;
     }
     if constexpr (std::is_same<F, fq2_t>::value) {
@@ -609,7 +615,7 @@ __device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int
                 const xyzz_t<F> o = shfl_xor_point(acc, 4);
                 const bool hi = (threadIdx.x & 4) != 0;
                 xyzz_t<F> lo = select_point(hi, o, acc);
-                quad_add(lo, select_point(hi, acc, o));
+                quad_add(lo, select_point(hi, acc, o), dbl);
                 acc = lo;
             }
 #pragma unroll 1
@@ -617,7 +623,7 @@ __device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int
                 const xyzz_t<F> o = shfl_xor_point(acc, off);
                 const bool hi = (threadIdx.x & off) != 0;
                 xyzz_t<F> lo = select_point(hi, o, acc);
-                hex_add(lo, select_point(hi, acc, o), hex);
+                hex_add(lo, select_point(hi, acc, o), dbl);
                 acc = lo;
             }
             if (blockDim.x == 64) return;
@@ -627,13 +633,13 @@ __device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int
             if (threadIdx.x < 64) {
                 const uint32_t pair = (threadIdx.x >> 4) & (nw / 2 - 1);  // row -> the pair of wave totals it adds
                 acc = load_xyzz<F>(&sh[2 * pair]);
-                hex_add(acc, load_xyzz<F>(&sh[2 * pair + 1]), hex);
+                hex_add(acc, load_xyzz<F>(&sh[2 * pair + 1]), dbl);
 #pragma unroll 1
                 for (uint32_t off = 16; off < 8 * nw; off <<= 1) {
                     const xyzz_t<F> o = shfl_xor_point(acc, (int)off);
                     const bool hi = (threadIdx.x & off) != 0;
                     xyzz_t<F> lo = select_point(hi, o, acc);
-                    hex_add(lo, select_point(hi, acc, o), hex);
+                    hex_add(lo, select_point(hi, acc, o), dbl);
                     acc = lo;
                 }
             }
@@ -641,7 +647,7 @@ __device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int
         }
     }
 #pragma unroll 1
-    for (int off = 4; off < 64; off <<= 1) quad_add(acc, shfl_xor_point(acc, off));
+    for (int off = 4; off < 64; off <<= 1) quad_add(acc, shfl_xor_point(acc, off), dbl);
     if (blockDim.x == 64) return;
     const uint32_t wv = threadIdx.x >> 6, nw = blockDim.x >> 6;  // 4 or 16 waves
     if ((threadIdx.x & 63) == 0) store_xyzz<F>(&sh[wv], acc);
@@ -649,10 +655,20 @@ __device__ __forceinline__ void block_sum(xyzz_t<F>& acc, xyzz_mem_t<F>* sh, int
     if (threadIdx.x < 64) {
         const uint32_t pair = (threadIdx.x >> 2) & (nw / 2 - 1);  // quad -> the pair of wave totals it adds
         acc = load_xyzz<F>(&sh[2 * pair]);
-        quad_add(acc, load_xyzz<F>(&sh[2 * pair + 1]));
+        quad_add(acc, load_xyzz<F>(&sh[2 * pair + 1]), dbl);
 #pragma unroll 1
-        for (uint32_t off = 4; off < 2 * nw; off <<= 1) quad_add(acc, shfl_xor_point(acc, (int)off));
+        for (uint32_t off = 4; off < 2 * nw; off <<= 1) quad_add(acc, shfl_xor_point(acc, (int)off), dbl);
     }
+}
+// The end of a tail kernel: thread 0 stores the workgroup's sum; Fq2: and whether ANY addition on the way met equal x coordinates - the output is then meaningless and
+// msm_*_fix_kernel (below) recomputes it.  Every thread of the workgroup must arrive.
+template <class F>
+__device__ __forceinline__ void tail_store(xyzz_mem_t<F>* out, uint32_t* flags, size_t slot, const xyzz_t<F>& acc, bool dbl) {
+    if constexpr (TAIL_FLAGGED<F>::value) {
+        const int any = __syncthreads_or(dbl ? 1 : 0);
+        if (threadIdx.x == 0) flags[slot] = (uint32_t)any;
+    }
+    if (threadIdx.x == 0) store_xyzz<F>(&out[slot], acc);
 }
 // Register budget of the tail kernels: the G1 kernels need ~270 registers without a bound and would then run ONE 256-thread
 // workgroup per CU - the 384 workgroups of a 2^15-bucket fold would take two rounds on 256 CUs; two waves per SIMD (256
@@ -719,7 +735,8 @@ static constexpr uint32_t TAIL_MAX_SEG = 2048;  // buckets per fold column (2^hb
 // buckets i, i + B, ... of the column, no LDS staging.
 template <class F, bool FLAT>
 __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
-                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb, int hex, int quads) {
+                                                       const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ out, int m, int hb, int hex, int quads,
+                                                       uint32_t* __restrict__ flags) {
     __shared__ xyzz_mem_t<F> sh[16];
     __shared__ uint32_t s_off[FLAT ? TAIL_MAX_SEG + 1 : 1], s_start[FLAT ? TAIL_MAX_SEG : 1], s_tmp[FLAT ? 256 : 1];
     const uint32_t nlo = 1u << m, nhi = 1u << hb;
@@ -730,6 +747,8 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
     const bool column = blockIdx.x >= nhi;
     const uint32_t fixed = column ? blockIdx.x - nhi : blockIdx.x;
     if (!column && fixed == 0) return;
+    const size_t slot = ((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1);
+    bool dbl = false;  // Fq2: some addition met equal x coordinates (tail_store)
     if (!FLAT) {
         xyzz_t<F> acc = xyzz_t<F>::inf();
         // one loop for both shapes: a column is nhi buckets at stride 2^m, a row one contiguous range of partial sums
@@ -739,10 +758,10 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
             const uint32_t k = kbase + (i << m) + fixed;
             const uint32_t q0 = column ? start[k] : start[k0] + threadIdx.x;
             const uint32_t q1 = column ? q0 + cnt[k] : start[k0 + nlo - 1] + cnt[k0 + nlo - 1];
-            for (uint32_t q = q0; q < q1; q += column ? 1u : blockDim.x) acc.add(load_xyzz<F>(&sums[q]));
+            for (uint32_t q = q0; q < q1; q += column ? 1u : blockDim.x) tail_add(acc, load_xyzz<F>(&sums[q]), dbl);
         }
-        block_sum<F>(acc, sh, hex);
-        if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
+        block_sum<F>(acc, sh, hex, false, dbl);
+        tail_store<F>(out, flags, slot, acc, dbl);
         return;
     }
     uint32_t nseg;
@@ -785,17 +804,45 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
             if (it == 0)
                 acc = x;
             else
-                quad_add(acc, x);
+                quad_add(acc, x, dbl);
         }
-        block_sum<F>(acc, sh, hex, true);
+        block_sum<F>(acc, sh, hex, true, dbl);
     } else {
         for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
             const uint32_t i = find_segment(s_off, nseg, p);
-            acc.add(load_xyzz<F>(&sums[s_start[i] + (p - s_off[i])]));
+            tail_add(acc, load_xyzz<F>(&sums[s_start[i] + (p - s_off[i])]), dbl);
         }
-        block_sum<F>(acc, sh, hex);
+        block_sum<F>(acc, sh, hex, false, dbl);
     }
-    if (threadIdx.x == 0) store_xyzz<F>(&out[((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1)], acc);
+    tail_store<F>(out, flags, slot, acc, dbl);
+}
+// The fold output `slot` again, for the outputs msm_fold_kernel flagged (Fq2: an addition met equal x coordinates - P + P or P - P): ONE wave per output and the plain law with its doubling, two
+// sites.  Same grid as the fold; an unflagged workgroup returns at once (the common case: ~3 us per launch).  Equal partial sums are what a tiled or repeated base
+// vector produces (the reference's own MSM benches tile a handful of points, benches/msm/variable_base.rs:29-32) - rare per output, not per run.
+template <class F>
+__global__ void __launch_bounds__(64) msm_fold_fix_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start, const uint32_t* __restrict__ cnt,
+                                                          xyzz_mem_t<F>* __restrict__ out, int m, int hb, const uint32_t* __restrict__ flags) {
+    const uint32_t nlo = 1u << m, nhi = 1u << hb;
+    const uint32_t w = blockIdx.y;
+    const uint32_t kbase = w << (m + hb);
+    const bool column = blockIdx.x >= nhi;
+    const uint32_t fixed = column ? blockIdx.x - nhi : blockIdx.x;
+    if (!column && fixed == 0) return;
+    const size_t slot = ((size_t)w << (m + 1)) + (column ? fixed : nlo + fixed - 1);
+    if (!flags[slot]) return;
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    const uint32_t k0 = kbase + (fixed << m);
+    const uint32_t nouter = column ? nhi : 1u;
+    for (uint32_t i = column ? threadIdx.x : 0u; i < nouter; i += column ? 64u : 1u) {
+        const uint32_t k = kbase + (i << m) + fixed;
+        const uint32_t q0 = column ? start[k] : start[k0] + threadIdx.x;
+        const uint32_t q1 = column ? q0 + cnt[k] : start[k0 + nlo - 1] + cnt[k0 + nlo - 1];
+#pragma unroll 1
+        for (uint32_t q = q0; q < q1; q += column ? 1u : 64u) acc.add(load_xyzz<F>(&sums[q]));
+    }
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) acc.add(shfl_xor_point(acc, off));
+    if (threadIdx.x == 0) store_xyzz<F>(&out[slot], acc);
 }
 // 7b. grid (nbits, tail windows).  Tail window tw holds N entries, entry i has weight i + 1:
 //   DENSE (after a fold): tw = 2 * w + sub; sub 0 = the L sums (N = 2^m), sub 1 = the H sums (N = 2^hb - 1); entry i is
@@ -807,11 +854,13 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_fold_kernel(con
 template <class F, bool DENSE>
 __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start,
                                                            const uint32_t* __restrict__ cnt, xyzz_mem_t<F>* __restrict__ planes, uint32_t nb,
-                                                           int m, int hb, int hex, int quads) {
+                                                           int m, int hb, int hex, int quads, uint32_t* __restrict__ flags) {
     __shared__ xyzz_mem_t<F> sh[16];
     __shared__ uint32_t s_off[DENSE ? 1 : TAIL_MAX_SEG + 1];
     const uint32_t j = blockIdx.x, tw = blockIdx.y, nbits = gridDim.x;
+    const size_t slot = (size_t)tw * nbits + j;
     xyzz_t<F> acc = xyzz_t<F>::inf();
+    bool dbl = false;  // Fq2: some addition met equal x coordinates (tail_store)
     if (DENSE) {
         const uint32_t w = tw >> 1, sub = tw & 1;
         const uint32_t N = sub ? (1u << hb) - 1 : (1u << m);
@@ -827,14 +876,14 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel
                 if (it == 0)
                     acc = x;
                 else
-                    quad_add(acc, x);
+                    quad_add(acc, x, dbl);
             }
-            block_sum<F>(acc, sh, hex, true);
-            if (threadIdx.x == 0) store_xyzz<F>(&planes[(size_t)tw * nbits + j], acc);
+            block_sum<F>(acc, sh, hex, true, dbl);
+            tail_store<F>(planes, flags, slot, acc, dbl);
             return;
         }
         for (uint32_t i = threadIdx.x; i < N; i += blockDim.x)
-            if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[base + i]));
+            if (((i + 1) >> j) & 1) tail_add(acc, load_xyzz<F>(&sums[base + i]), dbl);
     } else {
         const size_t base = (size_t)tw * nb;
         const uint32_t p0 = start[base];
@@ -844,12 +893,67 @@ __global__ void __launch_bounds__(256, TAIL_WAVES<F>::value) msm_bitplane_kernel
         const uint32_t total = s_off[nb];
         for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
             const uint32_t i = find_segment(s_off, nb, p);
-            if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[p0 + p]));
+            if (((i + 1) >> j) & 1) tail_add(acc, load_xyzz<F>(&sums[p0 + p]), dbl);
         }
     }
-    block_sum<F>(acc, sh, hex);
-    if (threadIdx.x == 0) store_xyzz<F>(&planes[(size_t)tw * nbits + j], acc);
+    block_sum<F>(acc, sh, hex, false, dbl);
+    tail_store<F>(planes, flags, slot, acc, dbl);
 }
+// The bit plane `slot` again, for the planes msm_bitplane_kernel flagged (see msm_fold_fix_kernel): one wave, the plain law.
+template <class F, bool DENSE>
+__global__ void __launch_bounds__(64) msm_bitplane_fix_kernel(const xyzz_mem_t<F>* __restrict__ sums, const uint32_t* __restrict__ start, const uint32_t* __restrict__ cnt,
+                                                              xyzz_mem_t<F>* __restrict__ planes, uint32_t nb, int m, int hb, const uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_off[DENSE ? 1 : TAIL_MAX_SEG + 1];
+    const uint32_t j = blockIdx.x, tw = blockIdx.y, nbits = gridDim.x;
+    const size_t slot = (size_t)tw * nbits + j;
+    if (!flags[slot]) return;
+    xyzz_t<F> acc = xyzz_t<F>::inf();
+    // one loop for both shapes: positions p of a list of `total` entries, entry p has weight wgt(p) and lives at sums[first + p]
+    size_t first;
+    uint32_t total;
+    if (DENSE) {
+        const uint32_t w = tw >> 1, sub = tw & 1;
+        total = sub ? (1u << hb) - 1 : (1u << m);
+        first = ((size_t)w << (m + 1)) + ((size_t)sub << m);
+    } else {
+        const size_t base = (size_t)tw * nb;
+        const uint32_t p0 = start[base];
+        for (uint32_t i = threadIdx.x; i < nb; i += 64u) s_off[i] = start[base + i] - p0;
+        if (threadIdx.x == 0) s_off[nb] = start[base + nb - 1] + cnt[base + nb - 1] - p0;
+        __syncthreads();
+        total = s_off[nb];
+        first = p0;
+    }
+#pragma unroll 1
+    for (uint32_t p = threadIdx.x; p < total; p += 64u) {
+        const uint32_t i = DENSE ? p : find_segment(s_off, nb, p);
+        if (((i + 1) >> j) & 1) acc.add(load_xyzz<F>(&sums[first + p]));
+    }
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) acc.add(shfl_xor_point(acc, off));
+    if (threadIdx.x == 0) store_xyzz<F>(&planes[slot], acc);
+}
+
+// The fold / bit-plane kernels are the largest functions of the library - every level of block_sum is an inlined cooperative addition - and the long pole of the build.
+// Their instantiations live in translation units of their own (csrc/tail_g1.hip, csrc/tail_g2.hip, csrc/tail_g2_planes.hip, csrc/tail_g2_fix.hip), compiled in parallel with the units that LAUNCH them; everywhere
+// else they are only declared (a launch references the kernel's host-side handle, an ordinary external symbol).
+#define SV_TAIL_FOLD_KERNELS(PREFIX, F)                                                                                                                             \
+    PREFIX template __global__ void msm_fold_kernel<F, true>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, int, int, int, int, uint32_t*);          \
+    PREFIX template __global__ void msm_fold_kernel<F, false>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, int, int, int, int, uint32_t*);
+#define SV_TAIL_PLANE_KERNELS(PREFIX, F)                                                                                                                            \
+    PREFIX template __global__ void msm_bitplane_kernel<F, true>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, uint32_t, int, int, int, int, uint32_t*); \
+    PREFIX template __global__ void msm_bitplane_kernel<F, false>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, uint32_t, int, int, int, int, uint32_t*);
+#define SV_TAIL_KERNELS(PREFIX, F) SV_TAIL_FOLD_KERNELS(PREFIX, F) SV_TAIL_PLANE_KERNELS(PREFIX, F)
+#define SV_TAIL_FIX_KERNELS(PREFIX, F)                                                                                                                              \
+    PREFIX template __global__ void msm_fold_fix_kernel<F>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, int, int, const uint32_t*);          \
+    PREFIX template __global__ void msm_bitplane_fix_kernel<F, true>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, uint32_t, int, int, const uint32_t*); \
+    PREFIX template __global__ void msm_bitplane_fix_kernel<F, false>(const xyzz_mem_t<F>*, const uint32_t*, const uint32_t*, xyzz_mem_t<F>*, uint32_t, int, int, const uint32_t*);
+#ifndef SV_TU_TAIL
+SV_TAIL_KERNELS(extern, fq_t)
+SV_TAIL_KERNELS(extern, fqz_t)
+SV_TAIL_KERNELS(extern, fq2_t)
+SV_TAIL_FIX_KERNELS(extern, fq2_t)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Base tables for registered (static) bases: next[i] = 2^shift * prev[i], affine.  Lets one bucket window serve

@@ -153,6 +153,7 @@ struct lane_t {
     dev_buf rv1, rl1, rcounts2, roff2, rbinstart, rntiles, rtstart, rbsize;  // radix-partition sort (msm_sort.hip.h)
     dev_buf rv2, rl2, rmid_size, rmid_boff;                                   // its middle level (wide windows)
     dev_buf fold_sums;                                                        // two-axis bucket fold
+    dev_buf tail_flags;                                                       // Fq2 tail: outputs whose tree met equal x coordinates (recomputed by the fix kernels)
     dev_buf sink_acc;                                                         // bucket sink of a chunked MSM (msm_bucket_sink_t)
     dev_buf fchunk;                                                           // chunk sums / offsets of the fused level-1 scan
     dev_buf bases_tmp, scalars_tmp, gen_pts, gen_prod;
@@ -869,7 +870,7 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
     hipStream_t st = c.stream;
     c.planes.ensure((size_t)pd.nplanes * sizeof(xyzz_mem_t<F>));
     const bool is_g2 = sizeof(F) == sizeof(fq2_t);
-    const int hex = is_g2 ? tuning().hex2 : 0;  // G2: the upper tree levels on sixteen lanes per addition (hex2.hip.h); 2 = gathers by DPP row broadcast, 1 = by ds_bpermute
+    const int hex = (is_g2 && tuning().hex2) ? 1 : 0;  // G2: the upper tree levels on sixteen lanes per addition (hex2.hip.h)
     // quad-strided accumulation in front of the trees (msm.hip.h), a bit mask: 1 = G2 bit planes, 2 = G2 fold, 4 = G1 bit planes, 8 = G1 fold.  Measured on the
     // 2^16 G2 tail (tools/g2_tail.sh, 17 x 15 geometry): bit planes 235 -> 202 us (186 with hex2 = 2), fold 375 -> 404 us; on one proof in transcript order (bench.py --workload proof1): 8.54 -> 8.29 - 8.37 ms with 13, 8.41 with 9, 8.37 with 15 - hence the default 13.
     // ... and only in the LATENCY regime (a small MSM's tail: a handful of entries per workgroup, the chip not full).  A big MSM's fold / bit planes are throughput-bound -
@@ -877,6 +878,16 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
     // fold 1.31 -> 1.66 ms, bit planes 0.18 -> 0.20 ms (profiles/r06_summary.md), so the mask applies to folds that run 128 / 256 threads per output and planes of <= 256 entries.
     int quads_planes = (tuning().tail_quads >> (is_g2 ? 0 : 2)) & 1, quads_fold = (tuning().tail_quads >> (is_g2 ? 1 : 3)) & 1;
     if (g.fold_m > 8) quads_planes = 0;
+    // Fq2: the kernels never compute P + P or P - P (msm.hip.h TAIL_FLAGGED): they flag the outputs whose additions met equal x coordinates, and a one-wave kernel per output kind
+    // recomputes those with the plain law - an unflagged workgroup returns at once.  Flags: [fold slots | planes].
+    uint32_t* fold_flags = nullptr;
+    uint32_t* plane_flags = nullptr;
+    if (is_g2) {
+        const size_t nslots = g.fold ? ((size_t)nwin << (g.fold_m + 1)) : 0;
+        c.tail_flags.ensure((nslots + (size_t)pd.nplanes) * 4);
+        fold_flags = c.tail_flags.as<uint32_t>();
+        plane_flags = fold_flags + nslots;
+    }
     if (g.fold) {
         c.fold_sums.ensure(((size_t)nwin << (g.fold_m + 1)) * sizeof(xyzz_mem_t<F>));
         // 256 threads per output keep the serial part of a small fold short - as long as the whole grid is resident at once
@@ -889,21 +900,32 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
         // (measured, 17 x 15 geometry = 256 workgroups: 256 threads 0.38 ms, 128 threads 0.53 ms, 64 threads 0.83 ms - the halved workgroup only pays when the
         // grid would otherwise take two turns, tools/g2_tail.sh)
         if (sizeof(F) > 64 && fold_threads == 256u && fold_blocks > 256u && (tuning().fold_threads2 == 128 || tuning().fold_threads2 == 64)) fold_threads = (unsigned)tuning().fold_threads2;
+        if (sizeof(F) > 64 && fold_threads == 256u && fold_blocks <= 256u && (tuning().fold_small2 == 128 || tuning().fold_small2 == 64)) fold_threads = (unsigned)tuning().fold_small2;
         if (fold_threads == 64u) quads_fold = 0;
+        const dim3 fold_grid((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin);
         if (flat || fold_threads != 64u)
-            hipLaunchKernelGGL((msm_fold_kernel<F, true>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
-                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex, quads_fold);
+            hipLaunchKernelGGL((msm_fold_kernel<F, true>), fold_grid, dim3(fold_threads), 0, st, sums, start, cnt, c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex,
+                               quads_fold, fold_flags);
         else
-            hipLaunchKernelGGL((msm_fold_kernel<F, false>), dim3((1u << g.fold_m) + (1u << g.fold_hb), (unsigned)nwin), dim3(fold_threads), 0, st, sums, start, cnt,
-                               c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex, quads_fold);
+            hipLaunchKernelGGL((msm_fold_kernel<F, false>), fold_grid, dim3(fold_threads), 0, st, sums, start, cnt, c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb, hex,
+                               quads_fold, fold_flags);
+        if constexpr (TAIL_FLAGGED<F>::value)
+            hipLaunchKernelGGL((msm_fold_fix_kernel<F>), fold_grid, dim3(64), 0, st, sums, start, cnt, c.fold_sums.as<xyzz_mem_t<F>>(), g.fold_m, g.fold_hb,
+                               (const uint32_t*)fold_flags);
         // one lane per entry of a plane (<= 2^fold_m); quad-strided: one QUAD per entry, up to 64 quads
         const unsigned plane_threads = quads_planes ? (g.fold_m <= 4 ? 64u : g.fold_m == 5 ? 128u : 256u) : (g.fold_m <= 6 ? 64u : g.fold_m == 7 ? 128u : 256u);
-        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), dim3((unsigned)g.nbits, (unsigned)g.tail_windows), dim3(plane_threads), 0, st,
-                           (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, g.fold_m, g.fold_hb, hex, quads_planes);
+        const dim3 plane_grid((unsigned)g.nbits, (unsigned)g.tail_windows);
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, true>), plane_grid, dim3(plane_threads), 0, st, (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(),
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, c.planes.as<xyzz_mem_t<F>>(), pl.nb, g.fold_m, g.fold_hb, hex, quads_planes, plane_flags);
+        if constexpr (TAIL_FLAGGED<F>::value)
+            hipLaunchKernelGGL((msm_bitplane_fix_kernel<F, true>), plane_grid, dim3(64), 0, st, (const xyzz_mem_t<F>*)c.fold_sums.as<xyzz_mem_t<F>>(), (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, c.planes.as<xyzz_mem_t<F>>(), pl.nb, g.fold_m, g.fold_hb, (const uint32_t*)plane_flags);
     } else {
-        hipLaunchKernelGGL((msm_bitplane_kernel<F, false>), dim3((unsigned)g.nbits, (unsigned)g.tail_windows), dim3(256), 0, st, sums, start, cnt,
-                           c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0, hex, 0);
+        const dim3 plane_grid((unsigned)g.nbits, (unsigned)g.tail_windows);
+        hipLaunchKernelGGL((msm_bitplane_kernel<F, false>), plane_grid, dim3(256), 0, st, sums, start, cnt, c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0, hex, 0, plane_flags);
+        if constexpr (TAIL_FLAGGED<F>::value)
+            hipLaunchKernelGGL((msm_bitplane_fix_kernel<F, false>), plane_grid, dim3(64), 0, st, sums, start, cnt, c.planes.as<xyzz_mem_t<F>>(), pl.nb, 0, 0,
+                               (const uint32_t*)plane_flags);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_planes, c.planes.p, (size_t)pd.nplanes * sizeof(xyzz_mem_t<F>), hipMemcpyDeviceToHost, st));

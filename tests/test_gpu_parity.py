@@ -813,6 +813,58 @@ def test_g2_registered_tables_vs_oracle(golden, tables, window_bits):
     rb.close()
 
 
+@pytest.mark.parametrize("tables,window_bits", [(17, 15), (16, 16), (19, 14), (22, 12), (1, 0)])
+def test_msm_of_repeated_points_repeats_and_matches_the_oracle(tables, window_bits):
+    """1 024 bases that are SIXTEEN distinct points tiled (the reference's MSM benches tile a small set too, benches/msm/variable_base.rs:29-32): equal
+    partial sums meet all over the fold / bit-plane trees, so every cooperative addition takes its equal-x fallback (P + P, P - P: the out-of-line plain
+    law) again and again - the path a random vector exercises once in 2^377.  Twelve calls each: the buckets fill in another order every time (scatter
+    atomics), every call must give `standard::msm`'s sum.  Round 6 found this path returning another wrong sum on every call for G2 when the compiler's
+    out-of-line fallbacks came back with registers of the caller overwritten (snarkvm_amd/build.py; the Fq2 tail kernels now hold no call: msm.hip.h
+    TAIL_FLAGGED) - invisible to the single-shot parity tests over distinct points."""
+    from snarkvm_amd.msm import RegisteredBases, RegisteredBasesG2
+
+    n = 1024
+    sc = synthetic.random_fr_integers(n, 1600 + tables)
+    g2 = synthetic.g2_points(n, distinct=16)
+    want2 = oracle.g2_to_affine(oracle.g2_msm(g2.view(oracle.G2_AFFINE), sc, oracle.MSM_STANDARD)).tobytes()
+    rg = RegisteredBasesG2(g2, tables=tables, window_bits=window_bits)
+    try:
+        for rep in range(12):
+            assert oracle.g2_to_affine(rg.msm(sc)).tobytes() == want2, ("g2", rep)
+    finally:
+        rg.close()
+    g1 = np.tile(oracle.g1_gen_bases(util.g1_generator_affine(), 5, 16), n // 16)
+    want1 = oracle.g1_to_affine(oracle.g1_msm(g1, sc)).tobytes()
+    rb = RegisteredBases(g1, tables=tables, window_bits=window_bits)
+    try:
+        for rep in range(12):
+            assert oracle.g1_to_affine(rb.msm(sc)).tobytes() == want1, ("g1", rep)
+    finally:
+        rb.close()
+
+
+@pytest.mark.parametrize("m,hb", [(7, 7), (7, 6), (8, 7)])
+def test_g2_tail_kernels_give_the_same_sums_on_every_launch(m, hb):
+    """snarkvm_hip_devtest_g2_tail_repeat: the Fq2 fold and bit-plane kernels over ONE fixed set of per-bucket lists built from a few repeated points (equal-x
+    fallbacks everywhere), launched 40 times at every workgroup size and with the cooperative-addition switches on and off: the same group elements every time."""
+    import ctypes
+
+    from snarkvm_amd import _lib
+
+    L = _lib.lib()
+    pts = synthetic.g2_points(512)
+    for threads in (64, 128, 256):
+        for hex2 in (0, 1):
+            for quads in (0, 3):
+                if threads == 64 and quads:
+                    continue
+                rep = np.zeros(10, dtype=np.uint32)
+                _lib.check(L.snarkvm_hip_devtest_g2_tail_repeat(ctypes.c_void_p(pts.ctypes.data), ctypes.c_size_t(512), m, hb, threads, 256 if quads else 128, hex2, quads, 40,
+                                                                ctypes.c_void_p(rep.ctypes.data)))
+                assert not rep[:4].any(), (threads, hex2, quads, rep.tolist())
+                assert rep[8] > 0, "the repeated points of this input must send some outputs through the fix kernel"
+
+
 def test_ffi_base_cache_is_transparent(tmp_path):
     """SNARKVM_HIP_BASE_CACHE (opt-in extension; `snarkvm_msm` is stateless without it): the FFI reusing device copies of base
     ranges it has seen - same results for repeated calls, sub-slices with an offset, a superseding bigger range, and memory

@@ -1,7 +1,7 @@
 #!/bin/bash
 # sweep of the G2 tail variants on the GPU box: bash tools/g2_tail.sh <out dir> ; per-kernel times from rocprofv3 --kernel-trace --stats
 out=${1:-gpurun_out/g2_tail}; mkdir -p $out; export TMPDIR=/tmp
-TUNES=${TUNES:-"hex2=2,tail_quads=1 hex2=1,tail_quads=1 hex2=0,tail_quads=1 hex2=2,tail_quads=0 hex2=0,tail_quads=0"}
+TUNES=${TUNES:-"hex2=1,tail_quads=13 hex2=0,tail_quads=13 hex2=1,tail_quads=0 hex2=0,tail_quads=0 hex2=1,tail_quads=15"}
 for tune in $TUNES; do
   tag=$(echo $tune | tr ',=' '__')
   SNARKVM_HIP_TUNING=$tune timeout 120 python tools/g2_tail.py > $out/$tag.json 2> $out/$tag.err

@@ -58,7 +58,7 @@ for label, mode, aw, ins in (("commitments awaited round by round on the scope's
 PY
 cat $O/r06_proof1_without_g2.txt
 # G2: the tail sweep (per-kernel times under rocprofv3) and the size table
-TUNES="hex2=2,tail_quads=13 hex2=0,tail_quads=0 hex2=0,tail_quads=0,fold_threads2=128" timeout 900 bash tools/g2_tail.sh $O/g2tail > /dev/null 2>&1; grep -E "^==|msm_fold|msm_bitplane|ms_per_sync" $O/g2tail/summary.txt | cut -c1-200
+TUNES="hex2=1,tail_quads=13 hex2=0,tail_quads=0 hex2=0,tail_quads=0,fold_threads2=128" timeout 900 bash tools/g2_tail.sh $O/g2tail > /dev/null 2>&1; grep -E "^==|msm_fold|msm_bitplane|ms_per_sync" $O/g2tail/summary.txt | cut -c1-200
 timeout 200 python tools/bench_g2.py > $O/g2.md 2> $O/g2.err; cut -c1-75 $O/g2.md | tail -4
 timeout 300 python tools/group_ntt_timing.py $O/r06_group_ntt_timing.md > /dev/null 2> $O/group_ntt.err; cat $O/r06_group_ntt_timing.md
 # the soak: 5 GPU-minutes on one device, 2 minutes on two logical devices
