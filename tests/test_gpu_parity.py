@@ -843,6 +843,43 @@ def test_msm_of_repeated_points_repeats_and_matches_the_oracle(tables, window_bi
         rb.close()
 
 
+def test_repeated_points_at_sizes_that_reach_the_other_exceptional_paths():
+    """The same shape at sizes whose buckets hold many entries, so that the accumulate kernels (G1: the lazy law's exact exceptional addition; G2: the lane-pair
+    doubling), the reduce rounds and the bucket merge meet equal points too: 2^18 G1 pairs over 16 distinct points (host buffers, then registered tables), 2^14
+    G2 pairs over 4 distinct points (host buffers, 17 x 15 tables, a fused batch of three) - three calls each, every one against the oracle."""
+    from snarkvm_amd.msm import RegisteredBases, RegisteredBasesG2, msm_g2
+
+    n = 1 << 18
+    g1 = np.tile(oracle.g1_gen_bases(util.g1_generator_affine(), 9, 16), n // 16)
+    sc = synthetic.random_fr_integers(n, 181818)
+    want1 = oracle.g1_to_affine(oracle.g1_msm(g1, sc)).tobytes()
+    for rep in range(3):
+        assert oracle.g1_to_affine(plugin.msm(g1, sc)).tobytes() == want1, ("g1 host", rep)
+    for tables, wb in ((1, 0), (17, 15), (13, 20)):
+        rb = RegisteredBases(g1, tables=tables, window_bits=wb)
+        try:
+            for rep in range(3):
+                assert oracle.g1_to_affine(rb.msm(sc)).tobytes() == want1, ("g1", tables, rep)
+        finally:
+            rb.close()
+    m = 1 << 14
+    g2 = synthetic.g2_points(m, distinct=4)
+    sc2 = synthetic.random_fr_integers(m, 141414)
+    want2 = oracle.g2_to_affine(oracle.g2_msm(g2.view(oracle.G2_AFFINE), sc2, oracle.MSM_STANDARD)).tobytes()
+    for rep in range(3):
+        assert oracle.g2_to_affine(msm_g2(g2, sc2)).tobytes() == want2, ("g2 host", rep)
+    rg = RegisteredBasesG2(g2, tables=17, window_bits=15)
+    try:
+        for rep in range(3):
+            assert oracle.g2_to_affine(rg.msm(sc2)).tobytes() == want2, ("g2", rep)
+        res = rg.msm_batch([sc2, sc2[: m // 2], sc2])
+        assert oracle.g2_to_affine(res[0:1]).tobytes() == want2 and oracle.g2_to_affine(res[2:3]).tobytes() == want2
+        want_half = oracle.g2_to_affine(oracle.g2_msm(g2.view(oracle.G2_AFFINE)[: m // 2], sc2[: m // 2], oracle.MSM_STANDARD)).tobytes()
+        assert oracle.g2_to_affine(res[1:2]).tobytes() == want_half
+    finally:
+        rg.close()
+
+
 @pytest.mark.parametrize("m,hb", [(7, 7), (7, 6), (8, 7)])
 def test_g2_tail_kernels_give_the_same_sums_on_every_launch(m, hb):
     """snarkvm_hip_devtest_g2_tail_repeat: the Fq2 fold and bit-plane kernels over ONE fixed set of per-bucket lists built from a few repeated points (equal-x
