@@ -159,7 +159,9 @@ RustError snarkvm_hip_scope_end(void);
 enum { SNARKVM_HIP_SCOPE_ASYNC_MSM = 1, SNARKVM_HIP_SCOPE_STABLE_INPUTS = 2, SNARKVM_HIP_SCOPE_MSM_IN_STREAM = 4 };
 /* snarkvm_hip_scope_collect(out): waits until the MSM call that was given `out` as its (first) output buffer is done and writes its outputs
  * (out == NULL: every MSM this thread's scope has enqueued so far); the scope stays open, the work queued on its own stream is NOT waited for
- * and the other enqueued MSMs stay pending.  What a prover needs between two rounds: the commitments of round k
+ * and the other enqueued MSMs stay pending - except that outputs of other MSMs whose results have ALREADY arrived may be written too while this
+ * call would only wait (their `out` buffers are owed by scope_end at the latest; this moves their host finish off the end of the scope).
+ * What a prover needs between two rounds: the commitments of round k
  * go into the Fiat-Shamir transcript before the challenge of round k + 1 exists (snark/varuna/varuna.rs:336 ff.), while transforms that do
  * not depend on that challenge - and the tails of earlier MSMs, and an independent MSM - keep running. */
 RustError snarkvm_hip_scope_begin_ex(const void *d_any, uint32_t flags);

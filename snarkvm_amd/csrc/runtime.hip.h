@@ -509,6 +509,34 @@ static void scope_collect(const void* tag) {
     thread_scope_t& sc = tl_scope();
     if (!sc.lane) return;
     std::exception_ptr err;
+    if (tag) {
+        // While this thread would only WAIT for `tag`'s results, it delivers what has already arrived for the others (a proof in transcript order: the independent
+        // G2 MSM issued first is ready two or three rounds later - its Horner chain over Fq2, ~0.15 ms of host time, then runs under a commitment round's kernels
+        // instead of behind the last round at scope_end).  Only while the wanted results are not there yet: they are never delayed by more than one such finish.
+        auto ready = [](const scope_pending_t& p) {
+            const hipError_t e = hipEventQuery(p.done);
+            if (e == hipSuccess) return true;
+            (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: it must not surface in a later launch check)
+            return false;
+        };
+        auto wanted_ready = [&]() {
+            for (const scope_pending_t& p : sc.pending)
+                if (p.tag == tag && !ready(p)) return false;
+            return true;
+        };
+        for (size_t i = 0; i < sc.pending.size() && !wanted_ready();) {
+            if (sc.pending[i].tag != tag && ready(sc.pending[i])) {
+                try {
+                    sc.pending[i].finish();
+                } catch (...) {
+                    if (!err) err = std::current_exception();
+                }
+                sc.pending.erase(sc.pending.begin() + (ptrdiff_t)i);
+            } else {
+                i++;
+            }
+        }
+    }
     std::vector<scope_pending_t> keep;
     for (scope_pending_t& p : sc.pending) {
         if (tag && p.tag != tag) {

@@ -449,9 +449,10 @@ def test_second_batch_of_a_shape_allocates_nothing_and_is_not_slower():
 
 
 def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
-    """snarkvm_hip_scope_collect(out): inside an asynchronous scope two MSM calls are enqueued; collecting the SECOND one writes its output and
-    leaves the first one's buffer untouched (its host finish has not run); collect(NULL) then delivers the rest, the scope is still open (a
-    further transform and MSM go through), scope_end delivers those.  Every result against the oracle."""
+    """snarkvm_hip_scope_collect(out): inside an asynchronous scope two MSM calls are enqueued; collecting the SECOND one writes its output (the
+    first one's may be written too if its results had already arrived while the call waited - it is owed by scope_end at the latest; a call
+    that has not been issued yet is never touched); collect(NULL) then delivers the rest, the scope is still open (a further transform and MSM
+    go through), scope_end delivers those.  Every result against the oracle."""
     import torch
 
     L = _lib.lib()
@@ -469,7 +470,7 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     _lib.check(L.snarkvm_hip_msm_registered(o[0], rb._h, 0, n, ctypes.c_void_p(dev[0].data_ptr()), 1, 0))
     _lib.check(L.snarkvm_hip_msm_registered(o[1], rb._h, 0, n - 5, ctypes.c_void_p(dev[1].data_ptr()), 1, 0))
     _lib.check(L.snarkvm_hip_scope_collect(o[1]))
-    assert outs[1:2].view(np.uint8).any() and not outs[0:1].view(np.uint8).any() and not outs[2:3].view(np.uint8).any()
+    assert outs[1:2].view(np.uint8).any() and not outs[2:3].view(np.uint8).any()
     _lib.check(L.snarkvm_hip_scope_collect(None))
     assert outs[0:1].view(np.uint8).any()
     _lib.check(L.snarkvm_hip_msm_registered(o[2], rb._h, 7, n - 7, ctypes.c_void_p(dev[2].data_ptr()), 1, 0))
@@ -489,7 +490,7 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     for k in (0, 1, 2, 29, 59):
         assert util.affine_equal(oracle.g1_to_affine(many[k : k + 1]), oracle.g1_to_affine(oracle.g1_msm(bases[k : k + n - 64], xs[k % 3][: n - 64]))), k
     # snarkvm_hip_scope_set_flags: the first MSM goes to a further stream, the next ones onto the scope's own stream (SNARKVM_HIP_SCOPE_MSM_IN_STREAM),
-    # behind a transform of their scalars that only the scope's stream orders; collecting an in-stream MSM leaves the first one pending
+    # behind a transform of their scalars that only the scope's stream orders; collecting the last in-stream MSM delivers it whatever the others' state
     assert L.snarkvm_hip_scope_set_flags(7).code != 0  # no open scope
     mixed = np.zeros(3, dtype=G1_PROJECTIVE)
     m = [ctypes.c_void_p(mixed[i : i + 1].ctypes.data) for i in range(3)]
@@ -504,7 +505,7 @@ def test_scope_collect_delivers_one_call_and_leaves_the_others_pending():
     _lib.check(L.snarkvm_hip_ntt_device(ctypes.c_void_p(work.data_ptr()), lg, 0, 1, 0))  # back to xs[1], behind the MSM on the same stream
     _lib.check(L.snarkvm_hip_msm_registered(m[2], rb._h, 0, n, ctypes.c_void_p(work.data_ptr()), 1, 0))
     _lib.check(L.snarkvm_hip_scope_collect(m[2]))
-    assert mixed[2:3].view(np.uint8).any() and not mixed[0:1].view(np.uint8).any() and not mixed[1:2].view(np.uint8).any()
+    assert mixed[2:3].view(np.uint8).any()
     _lib.check(L.snarkvm_hip_scope_end())
     want = [oracle.g1_msm(bases, xs[0]), oracle.g1_msm(bases, oracle.ntt(xs[1], oracle.ORDER_NN, oracle.FORWARD, oracle.STANDARD)), oracle.g1_msm(bases, xs[1])]
     for i in range(3):
