@@ -925,6 +925,9 @@ static void msm_tail_launch(lane_t& c, const msm_plan_t& pl, const msm_tail_geom
         // (G2 kernels hold one wave per SIMD: 256-thread workgroups sit one per CU, so 384 of them take two turns on 256 CUs; 128-thread
         // workgroups sit two per CU and lose one level of the tree besides - tuning fold_threads2)
         unsigned fold_threads = (nbt >= (1u << 18) || fold_blocks > 512u) ? 64u : 256u;
+        // a fused group of three or four proof-sized G1 instances (768 / 1 024 workgroups; commitment rounds 4 and 5 of a proof): 128 threads per output still put the
+        // whole grid on the chip at once (<= 2 048 waves at two per SIMD) and halve the serial walk of a lone wave - tuning fold_mid (64: round 5's one wave per output)
+        if (sizeof(F) <= 64 && nbt < (1u << 18) && fold_blocks > 512u && fold_blocks <= 1024u && tuning().fold_mid == 128) fold_threads = 128u;
         // (measured, 17 x 15 geometry = 256 workgroups: 256 threads 0.38 ms, 128 threads 0.53 ms, 64 threads 0.83 ms - the halved workgroup only pays when the
         // grid would otherwise take two turns, tools/g2_tail.sh)
         if (sizeof(F) > 64 && fold_threads == 256u && fold_blocks > 256u && (tuning().fold_threads2 == 128 || tuning().fold_threads2 == 64)) fold_threads = (unsigned)tuning().fold_threads2;

@@ -63,6 +63,8 @@
 //   hex2            1        G2 tail trees: from exchange distance 8 on, every addition on the sixteen lanes of a DPP row (hex2.hip.h, gathers by DPP row
 //                            broadcast; the ds_bpermute form of round 6 measured no gain and is gone); 0: four lanes (quad_add) throughout
 //   tail_quads      13       fold / bit planes: quad-strided accumulation in front of the trees (no plain one-lane addition), bit mask: 1 = G2 bit planes, 2 = G2 fold (measured slower: off), 4 = G1 bit planes, 8 = G1 fold
+//   fold_small2     256      G2: threads per output of a fold of <= 256 workgroups (one turn of the chip; 128 / 64: round 5's halved workgroup - an A/B and bisection switch)
+//   fold_mid        128      G1: threads per output of a fold of 513 .. 1 024 workgroups (a fused group of 3 - 4 proof-sized instances); 64: one wave per output
 //   pair2           1        G2 accumulation on a lane pair (ffl2p.hip.h: c0 on the even lane, c1 on the odd lane; 0: both components in one lane, ffl2.hip.h)
 //   horner2         1        p / (X - z): three launches with a scan inside every workgroup (0: the four-level chunk recursion of round 3)
 #pragma once
@@ -78,7 +80,7 @@ struct tuning_t {
     int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
-    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 1, horner2 = 1, pair2 = 1, hex2 = 1, group_quad = 1, tail_quads = 13, aux_low_prio = 0, fold_small2 = 256;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 1, horner2 = 1, pair2 = 1, hex2 = 1, group_quad = 1, tail_quads = 13, aux_low_prio = 0, fold_small2 = 256, fold_mid = 128;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -90,7 +92,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2) SV_TUNE_KEY(pair2) SV_TUNE_KEY(hex2) SV_TUNE_KEY(group_quad) SV_TUNE_KEY(tail_quads) SV_TUNE_KEY(aux_low_prio) SV_TUNE_KEY(fold_small2)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2) SV_TUNE_KEY(pair2) SV_TUNE_KEY(hex2) SV_TUNE_KEY(group_quad) SV_TUNE_KEY(tail_quads) SV_TUNE_KEY(aux_low_prio) SV_TUNE_KEY(fold_small2) SV_TUNE_KEY(fold_mid)
 #undef SV_TUNE_KEY
         return false;
     }
