@@ -34,9 +34,13 @@
 //   fold_flat       1        flattened-list fold for every MSM (0: per-bucket lists for big ones)
 //   fuse_batch      1        small instances of a batch travel as fused multi-instance groups
 //   fuse_max_k      64       instances per fused group
-//   fuse_reduce     1        reduce rounds of a fused group before its fold (0: none; 1: +1.6 % on the lock-step proof replay and a bound on
-//                            what an all-equal scalar vector can leave in one bucket; -1: one round for groups of >= 8 instances only.  Round 5,
-//                            one proof at a time, three interleaved runs each: 7.29 ms per proof with 1, 7.45 with 0, 7.40 with -1)
+//   fuse_reduce     -1       reduce rounds of a fused group before its fold (0: none; 1: one for every group: +1.6 % on the lock-step proof replay and a bound
+//                            on what an all-equal scalar vector can leave in one bucket; -1: one round for groups of >= 8 instances only).  Round 5 chose 1 on
+//                            a proof with every round enqueued at once (7.29 ms against 7.45 with 0, 7.40 with -1).  Round 6, the proof in TRANSCRIPT order (a
+//                            round's group of 1 - 4 instances is alone on the critical path: its reduce round is 0.11 ms in front of a fold that takes the
+//                            partial sums as they are), three interleaved runs on one box: 1: 8.16 - 8.19 ms per proof, witness-like pool 7.54 - 7.62;
+//                            0: 8.01 - 8.09 / 6.98 - 6.99; -1: 8.04 / 7.05 - 7.12; everything at once 6.71 - 6.81 with 1, 6.81 - 6.89 with -1; lock step
+//                            (groups of 64) 207.4 against 206.0 proofs/s - hence -1.
 //   coalesce        1        concurrent callers of small registered MSMs are fused by an in-library dispatcher
 //   coalesce_us     40       how long a dispatcher waits for further callers when others are inside the library
 //   lanes           0        lanes a batch cycles through (0: 8 below 2^20 pairs, 3 above)
@@ -77,7 +81,7 @@ namespace sv {
 struct tuning_t {
     int lazy = 1, lazy2 = 1, fused = 1, hist = 2, prefetch = 2;
     long acc_lds = 96 * 1024;
-    int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = 1, coalesce = 1, coalesce_us = 40, lanes = 0;
+    int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = -1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
     int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 1, horner2 = 1, pair2 = 1, hex2 = 1, group_quad = 1, tail_quads = 13, aux_low_prio = 0, fold_small2 = 256, fold_mid = 128;
