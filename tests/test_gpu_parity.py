@@ -860,6 +860,10 @@ def test_repeated_points_at_sizes_that_reach_the_other_exceptional_paths():
         try:
             for rep in range(3):
                 assert oracle.g1_to_affine(rb.msm(sc)).tobytes() == want1, ("g1", tables, rep)
+            if tables == 17:  # a fused group of three (768 fold workgroups: the 128-thread fold of tuning fold_mid)
+                res = rb.msm_batch([sc, sc[: n // 2], sc])
+                assert oracle.g1_to_affine(res[0:1]).tobytes() == want1 and oracle.g1_to_affine(res[2:3]).tobytes() == want1
+                assert oracle.g1_to_affine(res[1:2]).tobytes() == oracle.g1_to_affine(oracle.g1_msm(g1[: n // 2], sc[: n // 2])).tobytes()
         finally:
             rb.close()
     m = 1 << 14
