@@ -261,7 +261,13 @@ struct device_t {
         for (int l = 0; l < LANES; l++) {
             lane[l].dev = this;
             lane[l].index = l;
-            if (l >= LANES / 2 && tuning().aux_low_prio && prio_low != prio_high)
+            if (l >= LANES / 2 && tuning().aux_cus > 0) {
+                // (experiment, tuning aux_cus = N: the same lanes on streams that may only use the first N compute units of the mask order - a background MSM
+                // then cannot take the whole chip away from the critical stream for the length of its fold)
+                uint32_t mask[8] = {0};
+                for (int b = 0; b < tuning().aux_cus && b < 256; b++) mask[b >> 5] |= 1u << (b & 31);
+                HIP_TRY(hipExtStreamCreateWithCUMask(&lane[l].stream, 8, mask));
+            } else if (l >= LANES / 2 && tuning().aux_low_prio && prio_low != prio_high)
                 HIP_TRY(hipStreamCreateWithPriority(&lane[l].stream, hipStreamNonBlocking, prio_low));
             else
                 HIP_TRY(hipStreamCreateWithFlags(&lane[l].stream, hipStreamNonBlocking));

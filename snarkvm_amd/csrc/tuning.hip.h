@@ -69,6 +69,11 @@
 //   tail_quads      13       fold / bit planes: quad-strided accumulation in front of the trees (no plain one-lane addition), bit mask: 1 = G2 bit planes, 2 = G2 fold (measured slower: off), 4 = G1 bit planes, 8 = G1 fold
 //   fold_small2     256      G2: threads per output of a fold of <= 256 workgroups (one turn of the chip; 128 / 64: round 5's halved workgroup - an A/B and bisection switch)
 //   fold_mid        128      G1: threads per output of a fold of 513 .. 1 024 workgroups (a fused group of 3 - 4 proof-sized instances); 64: one wave per output
+//   aux_cus         0        experiment: N > 0 creates the upper half of the lanes (where a scope puts its further MSM streams) with a compute-unit mask of N CUs.
+//                            One proof in transcript order, whose only further-stream MSM is the independent G2 one: 8.06 ms with 0, 7.83 - 7.90 with 128, 7.88 - 7.95
+//                            with 192, 8.54 with 64, 9.8 - 10.1 with 32 (two alternating runs, one box) - a background MSM confined to half the chip disturbs the
+//                            critical stream less.  Not the default and not an ABI flag: every mode that puts commitment ROUNDS on those lanes is 1.5 - 5x slower
+//                            under the mask, and the reference's prover issues no such MSM (profiles/r06_summary.md).
 //   pair2           1        G2 accumulation on a lane pair (ffl2p.hip.h: c0 on the even lane, c1 on the odd lane; 0: both components in one lane, ffl2.hip.h)
 //   horner2         1        p / (X - z): three launches with a scan inside every workgroup (0: the four-level chunk recursion of round 3)
 #pragma once
@@ -84,7 +89,7 @@ struct tuning_t {
     int acc_one_wg = 0, reduce_rounds = 1, fold_flat = 1, fuse_batch = 1, fuse_max_k = 64, fuse_reduce = -1, coalesce = 1, coalesce_us = 40, lanes = 0;
     int msm_chunk_lg = 20, scalar_chunk_lg = 22, taper = 1, ring_lanes = 3, seg = 0, seg2 = 0, fold_l = 0, scan1 = 1;
     int ntt_min_tiles = 256, ntt_full_tw = 1, ntt_fold = 1, ntt_signed = 0, ntt_batch = 1;
-    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 1, horner2 = 1, pair2 = 1, hex2 = 1, group_quad = 1, tail_quads = 13, aux_low_prio = 0, fold_small2 = 256, fold_mid = 128;
+    int xcd = 1, fold_threads2 = 128, coalesce_slots = 2, ramp = 3, scalar_geo = 4, lazy_tail = 1, horner2 = 1, pair2 = 1, hex2 = 1, group_quad = 1, tail_quads = 13, aux_low_prio = 0, fold_small2 = 256, fold_mid = 128, aux_cus = 0;
 
     bool set(const char* key, long v) {
 #define SV_TUNE_KEY(name)                  \
@@ -96,7 +101,7 @@ struct tuning_t {
         SV_TUNE_KEY(acc_one_wg) SV_TUNE_KEY(reduce_rounds) SV_TUNE_KEY(fold_flat) SV_TUNE_KEY(fuse_batch) SV_TUNE_KEY(fuse_max_k) SV_TUNE_KEY(fuse_reduce) SV_TUNE_KEY(coalesce)
         SV_TUNE_KEY(coalesce_us) SV_TUNE_KEY(lanes) SV_TUNE_KEY(msm_chunk_lg) SV_TUNE_KEY(scalar_chunk_lg) SV_TUNE_KEY(taper) SV_TUNE_KEY(ring_lanes) SV_TUNE_KEY(seg) SV_TUNE_KEY(seg2)
         SV_TUNE_KEY(fold_l) SV_TUNE_KEY(scan1) SV_TUNE_KEY(ntt_min_tiles) SV_TUNE_KEY(ntt_full_tw) SV_TUNE_KEY(ntt_fold) SV_TUNE_KEY(ntt_signed)
-        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2) SV_TUNE_KEY(pair2) SV_TUNE_KEY(hex2) SV_TUNE_KEY(group_quad) SV_TUNE_KEY(tail_quads) SV_TUNE_KEY(aux_low_prio) SV_TUNE_KEY(fold_small2) SV_TUNE_KEY(fold_mid)
+        SV_TUNE_KEY(ntt_batch) SV_TUNE_KEY(xcd) SV_TUNE_KEY(fold_threads2) SV_TUNE_KEY(coalesce_slots) SV_TUNE_KEY(ramp) SV_TUNE_KEY(scalar_geo) SV_TUNE_KEY(lazy_tail) SV_TUNE_KEY(horner2) SV_TUNE_KEY(pair2) SV_TUNE_KEY(hex2) SV_TUNE_KEY(group_quad) SV_TUNE_KEY(tail_quads) SV_TUNE_KEY(aux_low_prio) SV_TUNE_KEY(fold_small2) SV_TUNE_KEY(fold_mid) SV_TUNE_KEY(aux_cus)
 #undef SV_TUNE_KEY
         return false;
     }
