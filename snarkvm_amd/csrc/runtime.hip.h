@@ -2015,6 +2015,10 @@ static bool msm_scope_enqueue(const bases_handle_t<F>& h, const msm_req_t* req, 
         msm_job_staging(h, j, pb, tb);
         need += pb + tb;
     }
+    // a scope's staging area is at least 1 MB from its first MSM on the lane: how far `pin_used` climbs inside a scope depends on when the pending MSMs happen to be
+    // delivered (scope_collect hands over what has arrived) - an area sized by other paths (a few KB of planes) would be outgrown in SOME replay of a warmed shape
+    // only, with a flush of the whole scope in front of the allocation
+    if (c.pin_used == 0 && c.pin.cap < ((size_t)1 << 20)) c.pin.ensure((size_t)1 << 20);
     if (c.pin_used + need > c.pin.cap) {  // staging full: collect what is pending (its planes live there), then start over with a bigger area
         if (c.pin_used) scope_flush();    // (first use of a lane: nothing of the scope is in its area - no reason to deliver other MSMs early)
         c.pin.ensure(need > ((size_t)1 << 20) ? need : (size_t)1 << 20);
