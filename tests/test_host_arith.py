@@ -243,7 +243,8 @@ def test_g2_sixteen_lane_cooperative_addition_matches_exact():
     """csrc/hex2.hip.h (round 6): the Fq2 XYZZ addition of the G2 tail trees dealt to the SIXTEEN lanes of a DPP row - lane 4 q + p computes Fq sub-product p
     of the quad schedule's product q, a pair exchange, c0 = P0 - 5 P1 / c1 = P2 + P3, a gather per round - run on the host over sixteen simulated lanes
     (the same source, the exchanges index the other lanes' copies) against xyzz_t<fq2_t>::add: every coordinate on every lane, operands at infinity,
-    P + P (every lane asks for the plain law) and P - P included."""
+    P + P and P - P (every lane sees the equal x coordinates and abandons the addition) included; and the flagged plain addition of the tail kernels
+    (xyzz_t::add_flag): equal x coordinates raise the flag and leave the accumulator alone, everything else is the exact sum."""
     L = _lib.lib()
     pts = synthetic.g2_points(48, distinct=48)
     for seed in (1, 7, 0xC0FFEE, 2026):
